@@ -1,0 +1,120 @@
+"""ctypes binding of ``liberd_hip.so`` (the C ABI declared in ``include/erd_hip.h``).
+
+There is NO fallback: if the library is missing or a call fails, the product
+raises.  (The CPU restatement under ``oracle/`` is test infrastructure and is
+never imported from here.)"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liberd_hip.so")
+
+ERD_MAX_SEG = 5
+ERD_MAX_TAPS = 9
+
+c_float_p = C.c_void_p  # raw device pointers travel as integers
+i64 = C.c_int64
+i32 = C.c_int
+f32 = C.c_float
+
+
+class ConvSeg(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("res", C.c_void_p), ("alpha", C.c_void_p),
+                ("N", i32), ("IH", i32), ("IW", i32), ("GH", i32), ("GW", i32), ("OH", i32), ("OW", i32),
+                ("in_nstride", i64), ("out_nstride", i64), ("res_nstride", i64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("nseg", i32), ("seg", ConvSeg * ERD_MAX_SEG), ("w", C.c_void_p),
+                ("Cin", i32), ("Cout", i32), ("wrow", i32), ("ntaps", i32),
+                ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS), ("wk", i32 * ERD_MAX_TAPS),
+                ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p),
+                ("N", i32), ("IH", i32), ("IW", i32), ("GH", i32), ("GW", i32), ("OH", i32), ("OW", i32),
+                ("x_nstride", i64), ("dz_nstride", i64),
+                ("Cin", i32), ("Cout", i32), ("ntaps", i32),
+                ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS),
+                ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
+                ("part", C.c_void_p), ("nsplit", i32)]
+
+
+class Levels(C.Structure):
+    _fields_ = [("nseg", i32), ("off", i64 * ERD_MAX_SEG), ("cnt", i64 * ERD_MAX_SEG)]
+
+
+P = C.c_void_p
+_SIGNATURES = {
+    # name: argtypes (restype is always int unless noted)
+    "erd_conv_igemm": [C.POINTER(ConvDesc), P],
+    "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
+    "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
+    "erd_weight_transpose": [P, P, P, i32, i32, i32, i32, P],
+    "erd_stem_conv7x7_bn_relu": [P, P, P, P, P, i32, i32, i32, P],
+    "erd_maxpool3x3s2": [P, P, i32, i32, i32, i32, P],
+    "erd_bn_fold": [P, P, P, P, f32, P, P, i64, P],
+    "erd_relu_bwd_colsum": [P, P, P, i64, i32, i64, i64, P, i32, P],
+    "erd_bn_dgamma": [P, P, P, P, f32, P, i32, i32, P],
+    "erd_gn_relu_fwd": [P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), f32, P],
+    "erd_gn_relu_bwd": [P, P, P, P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), P],
+    "erd_upsample2x_add": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, P],
+    "erd_upsample2x_add_bwd": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, P],
+    "erd_colsum": [P, i64, i32, P, i32, P],
+    "erd_level_scale": [P, P, P, i32, i64, i32, C.POINTER(Levels), P],
+    "erd_level_scale_bwd": [P, P, P, P, P, i32, i64, i32, C.POINTER(Levels), P],
+    "erd_sgd_momentum": [P, P, P, i64, f32, f32, f32, f32, i32, P],
+    "erd_ers_select": [P, P, i32, i64, i32, i32, P, P, P, P, P, P, P, P],
+    "erd_grid_anchors": [P, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, P],
+    "erd_atss_assign": [P, P, C.POINTER(i64), i32, i64, P, P, P, i32, i32, i32, i32, P, P, P, P, P, P],
+    "erd_gfl_losses_fwd": [P, P, P, P, P, P, C.POINTER(i64), C.POINTER(i32), i32, i32, i64, i32, i32, P, P, P, P],
+    "erd_gfl_losses_bwd": [P, P, P, P, P, P, C.POINTER(i64), C.POINTER(i32), i32, i32, i64, i32, i32, P, P, P, P,
+                           P, P],
+    "erd_l2_distill": [P, P, P, P, i32, i64, i32, i32, i32, P, P],
+    "erd_l2_distill_bwd": [P, P, P, P, P, i32, i64, i32, i32, i32, P, P],
+    "erd_distill_nms": [P, P, P, P, P, i32, i64, i32, f32, P, P, P, C.c_size_t, P],
+    "erd_kd_kl": [P, P, P, P, i32, i64, i32, i32, f32, P, P],
+    "erd_kd_kl_bwd": [P, P, P, P, P, i32, i64, i32, i32, f32, P, P],
+    "erd_loss_finalize": [P, P, P, P, P, i32, i32, i32, f32, f32, f32, f32, f32, P, P, P, P],
+}
+
+EXPORTS = ["erd_abi_version", "erd_last_error"] + sorted(_SIGNATURES)
+
+_lib = None
+
+
+class ErdHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen liberd_hip.so (once).  Raises ErdHipError if it is not built -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ErdHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C erd_amd/csrc`).  erd_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.erd_abi_version.restype = C.c_int
+    lib.erd_last_error.restype = C.c_char_p
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    if lib.erd_abi_version() != 1:
+        raise ErdHipError("liberd_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise ErdHipError(f"{name} failed (rc={rc}): {lib.erd_last_error().decode(errors='replace')}")

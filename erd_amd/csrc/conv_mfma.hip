@@ -1,0 +1,503 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Data layout: activations NHWC fp32, weights [Cout][taps][Cin] (K contiguous for both GEMM
+// operands).  One workgroup = 256 threads = 4 waves computes a BM x BN tile of
+// out[pixel][cout] = sum_{tap,ci} in[pixel shifted by tap][ci] * w[cout][tap][ci].
+//
+//  * A (pixels) and B (couts) K-slices of 32 floats (=128 B rows) are staged global->VGPR->LDS
+//    with a 16-B-chunk XOR swizzle (chunk ^= (row>>1)&7) so that the ds_read_b128 fragment reads
+//    (16-lane groups of distinct rows, same chunk) and the ds_write_b128 stores (8 lanes = one row)
+//    are bank-conflict free; double-buffered, one barrier per K-slice, next slice's global loads
+//    issued before the MFMAs of the current one.
+//  * each lane reads 4 consecutive k of its row with one ds_read_b128 and feeds them to 4 MFMAs:
+//    the k-pairing (k, k+4) differs from memory order but is the same for A and B, which is all a
+//    dot product needs.
+//  * the epilogue applies folded-BN scale/shift | bias, a per-level scalar, a residual and ReLU
+//    while the accumulators are still in registers, and writes 128-B rows (32 couts of one pixel).
+//
+// Forward conv, stride-1 input-gradient and the 4 parity classes of a stride-2 input-gradient are
+// all expressed through the tap list of erd_conv_desc (include/erd_hip.h).
+#include "erd_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;        // floats per K-slice (one 128-B row)
+constexpr int NTHREADS = 256;
+
+struct RowInfo {
+    int in_off;   // element offset of image n in `in`
+    int ih0, iw0; // a*in_stride, b*in_stride
+    int out_off;  // element offset of the output pixel (-1: row past the end)
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_desc p) {
+    constexpr int FM = BM / (WAVES_M * 32);
+    constexpr int FN = BN / (WAVES_N * 32);
+    constexpr int AJ = BM / 32;  // float4 loads per thread for A
+    constexpr int BJ = BN / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*8]
+    float4* Bs = As + 2 * BM * 8;                                  // [2][BN*8]
+    RowInfo* rows = reinterpret_cast<RowInfo*>(Bs + 2 * BN * 8);   // [BM]
+
+    const int tid = threadIdx.x;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int nt = blockIdx.x % ntn;
+    int mt = blockIdx.x / ntn;
+
+    // ---- which segment (level) does this M-tile belong to -----------------------------------
+    int s = 0;
+#pragma unroll 1
+    for (; s < p.nseg - 1; ++s) {
+        const int M = p.seg[s].N * p.seg[s].GH * p.seg[s].GW;
+        const int tiles = (M + BM - 1) / BM;
+        if (mt < tiles) break;
+        mt -= tiles;
+    }
+    const erd_conv_seg& sg = p.seg[s];
+    const int IH = sg.IH, IW = sg.IW, Cin = p.Cin;
+    const float* __restrict__ in = sg.in;
+    const float* __restrict__ w = p.w;
+
+    if (tid < BM) {
+        const int GHW = sg.GH * sg.GW;
+        const int M = sg.N * GHW;
+        const int m = mt * BM + tid;
+        RowInfo ri;
+        if (m < M) {
+            const int n = m / GHW;
+            const int rem = m - n * GHW;
+            const int a = rem / sg.GW;
+            const int b = rem - a * sg.GW;
+            ri.in_off = (int)(n * sg.in_nstride);
+            ri.ih0 = a * p.in_stride;
+            ri.iw0 = b * p.in_stride;
+            ri.out_off = (int)(n * sg.out_nstride) +
+                         ((a * p.out_stride + p.oy) * sg.OW + (b * p.out_stride + p.ox)) * p.Cout;
+        } else {
+            ri.in_off = 0;
+            ri.ih0 = -(1 << 28);
+            ri.iw0 = -(1 << 28);
+            ri.out_off = -1;
+        }
+        rows[tid] = ri;
+    }
+    __syncthreads();
+
+    const int chunk = tid & 7;
+    const int r0 = tid >> 3;  // 0..31
+    int a_off[AJ], a_ih[AJ], a_iw[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const RowInfo ri = rows[r0 + 32 * j];
+        a_off[j] = ri.in_off + chunk * 4;
+        a_ih[j] = ri.ih0;
+        a_iw[j] = ri.iw0;
+    }
+    const int n0 = nt * BN;
+    int b_off[BJ];
+    bool b_ok[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int co = n0 + r0 + 32 * j;
+        b_ok[j] = co < p.Cout;
+        b_off[j] = (b_ok[j] ? co : 0) * p.wrow + chunk * 4;
+    }
+
+    const int cpt = (Cin + BK - 1) / BK;  // K-slices per tap (last one zero-filled past Cin)
+    const int nkt = p.ntaps * cpt;
+
+    float4 ra[AJ], rb[BJ];
+    int tap = 0, cc = 0;
+
+    auto load_global = [&]() {
+        const int dyt = p.dy[tap], dxt = p.dx[tap];
+        const int kb = p.wk[tap] + cc * BK;
+        const int cb = cc * BK;
+        const bool cok = cb + chunk * 4 < Cin;   // Cin % 4 == 0: a 16-B chunk is all-in or all-out
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int ih = a_ih[j] + dyt, iw = a_iw[j] + dxt;
+            const bool ok = cok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) ra[j] = *reinterpret_cast<const float4*>(in + (a_off[j] + (ih * IW + iw) * Cin + cb));
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_ok[j] && cok) rb[j] = *reinterpret_cast<const float4*>(w + (b_off[j] + kb));
+        }
+        if (++cc == cpt) { cc = 0; ++tap; }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int row = r0 + 32 * j;
+            As[buf * BM * 8 + row * 8 + swz(row, chunk)] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = r0 + 32 * j;
+            Bs[buf * BN * 8 + row * 8 + swz(row, chunk)] = rb[j];
+        }
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, h = lane >> 5;
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_global();
+    store_lds(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_global();
+        const float4* Ab = As + buf * BM * 8;
+        const float4* Bb = Bs + buf * BN * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = 2 * kk + h;
+            float4 fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = (wm * FM + i) * 32 + li;
+                fa[i] = Ab[row * 8 + swz(row, c)];
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = (wn * FN + j) * 32 + li;
+                fb[j] = Bb[row * 8 + swz(row, c)];
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    float* __restrict__ out = sg.out;
+    const float* res = sg.res;
+    const float alpha = sg.alpha ? *sg.alpha : 1.f;
+    const bool has_alpha = sg.alpha != nullptr;
+    const int res_delta_n = 0;
+    (void)res_delta_n;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int co = n0 + (wn * FN + j) * 32 + li;
+        const bool cok = co < p.Cout;
+        const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
+        const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int oo = rows[row].out_off;
+                if (oo >= 0 && cok) {
+                    float v = acc[i][j][r];
+                    if (p.scale) v *= sc;
+                    v += sh;
+                    if (has_alpha) v *= alpha;
+                    if (res) v += res[oo + co];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    out[oo + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight gradient: G[co][t][ci] = sum_p dz[p][co] * x[p+tap t][ci]; K = pixels (split over gridDim.z)
+// LDS tiles are k-major ([32 px][128 ch], exactly the global layout); fragments by ds_read_b32.
+// -------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad_desc p) {
+    constexpr int FM = BM / 64, FN = BN / 64;  // 2x2 waves
+    constexpr int AC = BM / 4, BC = BN / 4;    // float4 chunks per row
+    constexpr int AJ = (BK * AC) / NTHREADS, BJ = (BK * BC) / NTHREADS;
+    constexpr int AR = NTHREADS / AC, BR = NTHREADS / BC;  // rows covered per pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);   // [2][BK][BM]
+    float* Bs = As + 2 * BK * BM;                 // [2][BK][BN]
+
+    const int tid = threadIdx.x;
+    const int nci = (p.Cin + BN - 1) / BN;
+    const int tap = blockIdx.x / nci;
+    const int ci0 = (blockIdx.x % nci) * BN;
+    const int co0 = blockIdx.y * BM;
+    const int GHW = p.GH * p.GW;
+    const int P = p.N * GHW;
+    const int nkt_total = (P + BK - 1) / BK;
+    const int per = (nkt_total + gridDim.z - 1) / gridDim.z;
+    const int kt_begin = blockIdx.z * per;
+    const int kt_end = min(nkt_total, kt_begin + per);
+    const int dyt = p.dy[tap], dxt = p.dx[tap];
+    const float* __restrict__ x = p.x;
+    const float* __restrict__ dz = p.dz;
+
+    // A rows (pixels) handled by this thread: ar0 + AR*j ; B rows: br0 + BR*j
+    const int achunk = tid % AC, ar0 = tid / AC;
+    const int bchunk = tid % BC, br0 = tid / BC;
+    const bool a_cok = co0 + achunk * 4 < p.Cout;
+    const bool b_cok = ci0 + bchunk * 4 < p.Cin;
+
+    float4 ra[AJ], rb[BJ];
+    auto load_global = [&](int kt) {
+        const int pbase = kt * BK;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int pp = pbase + ar0 + AR * j;
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pp < P && a_cok) {
+                const int n = pp / GHW;
+                const int rem = pp - n * GHW;
+                const int a = rem / p.GW;
+                const int b = rem - a * p.GW;
+                const int64_t off = n * p.dz_nstride +
+                                    (int64_t)((a * p.out_stride + p.oy) * p.OW + (b * p.out_stride + p.ox)) * p.Cout +
+                                    co0 + achunk * 4;
+                ra[j] = *reinterpret_cast<const float4*>(dz + off);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int pp = pbase + br0 + BR * j;
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pp < P && b_cok) {
+                const int n = pp / GHW;
+                const int rem = pp - n * GHW;
+                const int a = rem / p.GW;
+                const int b = rem - a * p.GW;
+                const int ih = a * p.in_stride + dyt, iw = b * p.in_stride + dxt;
+                if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+                    const int64_t off = n * p.x_nstride + (int64_t)(ih * p.IW + iw) * p.Cin + ci0 + bchunk * 4;
+                    rb[j] = *reinterpret_cast<const float4*>(x + off);
+                }
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            *reinterpret_cast<float4*>(As + (buf * BK + ar0 + AR * j) * BM + achunk * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            *reinterpret_cast<float4*>(Bs + (buf * BK + br0 + BR * j) * BN + bchunk * 4) = rb[j];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_global(kt_begin);
+        store_lds(0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            const bool more = kt + 1 < kt_end;
+            if (more) load_global(kt + 1);
+            const float* Ab = As + buf * BK * BM;
+            const float* Bb = Bs + buf * BK * BN;
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int k = 2 * ks + h;
+                float fa[FM], fb[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) fa[i] = Ab[k * BM + (wm * FM + i) * 32 + li];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[j] = Bb[k * BN + (wn * FN + j) * 32 + li];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial slab [z][Cout][ntaps][Cin]
+    float* __restrict__ part = p.part + (int64_t)blockIdx.z * p.Cout * p.ntaps * p.Cin;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int ci = ci0 + (wn * FN + j) * 32 + li;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout) part[((int64_t)co * p.ntaps + tap) * p.Cin + ci] = acc[i][j][r];
+            }
+    }
+}
+
+// dW[co][k] (+)= rowscale[co] * sum_s part[s][co][k];  rowdot[co] = sum_k w[co][k] * G[co][k]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int Cout,
+                                                            int K, const float* __restrict__ w,
+                                                            const float* __restrict__ rowscale,
+                                                            float* __restrict__ dW, int accumulate,
+                                                            float* __restrict__ rowdot) {
+    const int co = blockIdx.x;
+    const int64_t slab = (int64_t)Cout * K;
+    const float rs = rowscale ? rowscale[co] : 1.f;
+    float dot = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 256 * 4) {
+        const int64_t o = (int64_t)co * K + k;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < nsplit; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(part + s * slab + o);
+            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+        }
+        if (rowdot) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + o);
+            dot += ww.x * g.x + ww.y * g.y + ww.z * g.z + ww.w * g.w;
+        }
+        float4 o4 = make_float4(rs * g.x, rs * g.y, rs * g.z, rs * g.w);
+        if (accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(dW + o);
+            o4.x += old.x; o4.y += old.y; o4.z += old.z; o4.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dW + o) = o4;
+    }
+    if (rowdot) {
+        __shared__ float red[4];
+        dot = erd::wave_sum(dot);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) rowdot[co] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// dst[ci][t'][co] = rowscale[co] * w[co][t][ci]
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w,
+                                                                const float* __restrict__ rowscale,
+                                                                float* __restrict__ dst, int Cout, int ntaps, int Cin,
+                                                                int flip) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int td = flip ? ntaps - 1 - t : t;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((int64_t)co * ntaps + t) * Cin + ci] * (rowscale ? rowscale[co] : 1.f);
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (co < Cout && ci < Cin) dst[((int64_t)ci * ntaps + td) * Cout + co] = tile[tx][r];
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
+    int tiles = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const int64_t M = (int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW;
+        tiles += (int)((M + BM - 1) / BM);
+    }
+    const int ntn = (d->Cout + BN - 1) / BN;
+    if (tiles == 0) return 0;
+    const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(float4) + BM * sizeof(RowInfo);
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
+    static bool attr_done = false;  // idempotent, value never changes: benign race
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * ntn), dim3(NTHREADS), lds, st, *d);
+    return erd::check_launch("conv_igemm");
+}
+
+}  // namespace
+
+extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
+    ERD_REQUIRE(d != nullptr, "conv: null desc");
+    ERD_REQUIRE(d->nseg >= 1 && d->nseg <= ERD_MAX_SEG, "conv: nseg=%d", d->nseg);
+    ERD_REQUIRE(d->ntaps >= 1 && d->ntaps <= ERD_MAX_TAPS, "conv: ntaps=%d", d->ntaps);
+    ERD_REQUIRE(d->Cin > 0 && d->Cin % 4 == 0, "conv: Cin=%d must be a multiple of 4", d->Cin);
+    ERD_REQUIRE(d->Cout > 0 && d->wrow % 4 == 0, "conv: Cout=%d wrow=%d", d->Cout, d->wrow);
+    for (int s = 0; s < d->nseg; ++s) {
+        const erd_conv_seg& g = d->seg[s];
+        ERD_REQUIRE(g.in && g.out, "conv: null tensor in segment %d", s);
+        ERD_REQUIRE((int64_t)g.N * g.in_nstride < (1ll << 31) && (int64_t)g.N * g.out_nstride < (1ll << 31),
+                    "conv: segment %d exceeds 2^31 elements", s);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2>(d, st);
+    return launch_igemm<128, 128, 2, 2>(d, st);
+}
+
+extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
+    ERD_REQUIRE(d != nullptr && d->x && d->dz && d->part, "wgrad: null pointer");
+    ERD_REQUIRE(d->ntaps >= 1 && d->ntaps <= ERD_MAX_TAPS, "wgrad: ntaps=%d", d->ntaps);
+    ERD_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "wgrad: Cin=%d Cout=%d must be multiples of 4", d->Cin, d->Cout);
+    ERD_REQUIRE(d->nsplit >= 1 && d->nsplit <= 65535, "wgrad: nsplit=%d", d->nsplit);
+    ERD_REQUIRE((int64_t)d->N * d->GH * d->GW < (1ll << 31), "wgrad: too many pixels");
+    constexpr int BM = 128, BN = 128;
+    const int nci = (d->Cin + BN - 1) / BN, nco = (d->Cout + BM - 1) / BM;
+    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
+    auto kern = conv_wgrad_kernel<BM, BN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nci * d->ntaps, nco, d->nsplit), dim3(NTHREADS), lds, (hipStream_t)stream, *d);
+    return erd::check_launch("conv_wgrad");
+}
+
+extern "C" int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, const float* w,
+                                const float* rowscale, float* dW, int accumulate, float* rowdot,
+                                erd_stream_t stream) {
+    ERD_REQUIRE(part && dW && nsplit >= 1 && K % 4 == 0, "wgrad_reduce: bad args");
+    ERD_REQUIRE(!rowdot || w, "wgrad_reduce: rowdot needs w");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, part, nsplit, Cout, K, w,
+                       rowscale, dW, accumulate, rowdot);
+    return erd::check_launch("wgrad_reduce");
+}
+
+extern "C" int erd_weight_transpose(const float* w, const float* rowscale, float* dst, int Cout, int ntaps,
+                                    int Cin, int flip, erd_stream_t stream) {
+    ERD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && ntaps > 0, "weight_transpose: bad args");
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, ntaps), dim3(256), 0,
+                       (hipStream_t)stream, w, rowscale, dst, Cout, ntaps, Cin, flip);
+    return erd::check_launch("weight_transpose");
+}

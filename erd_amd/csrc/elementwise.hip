@@ -1,0 +1,646 @@
+// HBM-bound kernels around the convolutions: stem, max-pool, frozen-BN helpers, GroupNorm(32)+ReLU
+// forward/backward over level-concatenated [N][A][C] maps, FPN top-down add, bias/scale helpers, SGD.
+// All activations NHWC fp32; 16-byte (float4) accesses, channels fastest => fully coalesced rows.
+#include "erd_common.h"
+
+namespace erd {
+thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace erd
+
+extern "C" int erd_abi_version(void) { return ERD_ABI_VERSION; }
+extern "C" const char* erd_last_error(void) { return erd::g_err; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// stem: conv 7x7 stride 2 pad 3, 3->64, input NCHW (the detector's public input layout), output NHWC,
+// frozen BN + ReLU fused (resnet.py:636-638).  Direct convolution: Cin=3 does not feed an MFMA K-slice.
+// Block = 256 threads = 8x32 output pixels; each thread accumulates all 64 output channels of one
+// pixel; weights (147x64) and the 21x69x3 input patch live in LDS (weights are read as broadcasts).
+// ------------------------------------------------------------------------------------------------
+constexpr int ST_TH = 8, ST_TW = 32;
+constexpr int ST_PH = ST_TH * 2 + 5, ST_PW = ST_TW * 2 + 5;  // 21 x 69
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   float* __restrict__ out, int N, int H, int W, int OH, int OW) {
+    __shared__ float4 wl[147 * 16];           // [kh][kw][c][64] as float4 over couts
+    __shared__ float patch[3][ST_PH][ST_PW + 1];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;
+    const int oh0 = blockIdx.y * ST_TH, ow0 = blockIdx.x * ST_TW;
+    // weights arrive as [co][kh][kw][c] (OHWI); LDS wants [(kh,kw,c)][co]
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int co = i / 147, k = i - co * 147;
+        reinterpret_cast<float*>(wl)[k * 64 + co] = w[i];
+    }
+    const int ih0 = oh0 * 2 - 3, iw0 = ow0 * 2 - 3;
+    for (int i = tid; i < 3 * ST_PH * ST_PW; i += 256) {
+        const int c = i / (ST_PH * ST_PW);
+        const int r = (i / ST_PW) % ST_PH;
+        const int col = i % ST_PW;
+        const int ih = ih0 + r, iw = iw0 + col;
+        float v = 0.f;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((int64_t)(n * 3 + c) * H + ih) * W + iw];
+        patch[c][r][col] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 5, tx = tid & 31;
+    float4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < 7; ++kh)
+        for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = patch[c][ty * 2 + kh][tx * 2 + kw];
+                const float4* wr = wl + ((kh * 7 + kw) * 3 + c) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 ww = wr[i];
+                    acc[i].x = fmaf(v, ww.x, acc[i].x);
+                    acc[i].y = fmaf(v, ww.y, acc[i].y);
+                    acc[i].z = fmaf(v, ww.z, acc[i].z);
+                    acc[i].w = fmaf(v, ww.w, acc[i].w);
+                }
+            }
+    const int oh = oh0 + ty, ow = ow0 + tx;
+    if (oh < OH && ow < OW) {
+        float4* o = reinterpret_cast<float4*>(out + ((int64_t)(n * OH + oh) * OW + ow) * 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 sc = reinterpret_cast<const float4*>(scale)[i];
+            const float4 sh = reinterpret_cast<const float4*>(shift)[i];
+            float4 v;
+            v.x = fmaxf(acc[i].x * sc.x + sh.x, 0.f);
+            v.y = fmaxf(acc[i].y * sc.y + sh.y, 0.f);
+            v.z = fmaxf(acc[i].z * sc.z + sh.z, 0.f);
+            v.w = fmaxf(acc[i].w * sc.w + sh.w, 0.f);
+            o[i] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int N,
+                                                      int H, int W, int C4, int OH, int OW) {
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = i % C4;
+        int64_t r = i / C4;
+        const int ow = r % OW; r /= OW;
+        const int oh = r % OH;
+        const int n = r / OH;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh * 2 - 1 + dy;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iw = ow * 2 - 1 + dx;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float4 v = in[((int64_t)(n * H + ih) * W + iw) * C4 + c];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        out[i] = m;
+    }
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ m,
+                               const float* __restrict__ v, float eps, float* __restrict__ scale,
+                               float* __restrict__ shift, int64_t n) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i < n) {
+        const float s = g[i] * (1.0f / sqrtf(v[i] + eps));
+        scale[i] = s;
+        shift[i] = b[i] - m[i] * s;
+    }
+}
+
+// dz = dy * (y>0) (dz may alias dy); colsum[c] += sum over rows of dz.  rows are [npix][C] with an image
+// stride (level views of [N][A][C] buffers): row r -> img r / rows_per_img.
+__global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __restrict__ y, const float* dy, float* dz,
+                                                               int64_t npix, int C, int64_t nstride,
+                                                               int64_t rows_per_img, float* __restrict__ colsum,
+                                                               int use_relu, int rows_per_block) {
+    // thread layout: C/4 float4 columns x (256/(C/4)) row lanes ; C in {64..2048}: C4 may exceed 256
+    const int C4 = C >> 2;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = min(npix, r_begin + rows_per_block);
+    for (int c4 = threadIdx.x % min(C4, 256); c4 < C4; c4 += 256) {
+        const int lanes = C4 >= 256 ? 1 : 256 / C4;
+        const int rl = C4 >= 256 ? 0 : threadIdx.x / C4;
+        if (rl >= lanes) break;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t r = r_begin + rl; r < r_end; r += lanes) {
+            const int64_t img = r / rows_per_img;
+            const int64_t off = img * nstride + (r - img * rows_per_img) * C + c4 * 4;
+            float4 g = *reinterpret_cast<const float4*>(dy + off);
+            if (use_relu) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + off);
+                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+                *reinterpret_cast<float4*>(dz + off) = g;
+            }
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        }
+        if (colsum) {
+            atomicAdd(colsum + c4 * 4 + 0, s.x);
+            atomicAdd(colsum + c4 * 4 + 1, s.y);
+            atomicAdd(colsum + c4 * 4 + 2, s.z);
+            atomicAdd(colsum + c4 * 4 + 3, s.w);
+        }
+    }
+}
+
+__global__ void bn_dgamma_kernel(const float* __restrict__ rowdot, const float* __restrict__ dbeta,
+                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                 float* __restrict__ dgamma, int accumulate, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < C) {
+        const float v = (1.0f / sqrtf(var[i] + eps)) * (rowdot[i] - mean[i] * dbeta[i]);
+        dgamma[i] = accumulate ? dgamma[i] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(G groups) + ReLU over [N][A][C] with per-(image, level, group) statistics.
+// stats_ws: double [N][nseg][G][2] (sum, sumsq) accumulated with f64 atomics, then folded to
+// mean_rstd float [N][nseg][G][2].
+// ------------------------------------------------------------------------------------------------
+constexpr int GN_ROWS = 128;  // rows per block
+
+__device__ __forceinline__ int find_level(const erd_levels& lv, int64_t a) {
+    int s = 0;
+#pragma unroll 1
+    for (; s < lv.nseg - 1; ++s)
+        if (a < lv.off[s] + lv.cnt[s]) break;
+    return s;
+}
+
+// grid: (chunks over A rows, N).  Each chunk of GN_ROWS rows lies inside one level (host pads the
+// chunk table per level: blockIdx.x -> (level, first row) through cumulative chunk counts).
+struct GnChunks {
+    int nseg;
+    int start[ERD_MAX_SEG + 1];
+};
+__device__ __forceinline__ void gn_chunk(const erd_levels& lv, const GnChunks& ch, int bx, int& s, int64_t& r0,
+                                         int64_t& r1) {
+    s = 0;
+#pragma unroll 1
+    for (; s < ch.nseg - 1; ++s)
+        if (bx < ch.start[s + 1]) break;
+    r0 = lv.off[s] + (int64_t)(bx - ch.start[s]) * GN_ROWS;
+    r1 = min(lv.off[s] + lv.cnt[s], r0 + GN_ROWS);
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ c, double* __restrict__ stats,
+                                                       int64_t A, erd_levels lv, GnChunks ch) {
+    constexpr int C4 = C / 4;          // 64 float4 columns
+    constexpr int CPG = C / G;         // channels per group (8)
+    static_assert(CPG == 8 && C4 == 64, "tuned for C=256, G=32");
+    const int n = blockIdx.y;
+    int s; int64_t r0, r1;
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 4 row lanes
+    float sum = 0.f, sq = 0.f;
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(c + ((int64_t)n * A + r) * C + c4 * 4);
+        sum += v.x + v.y + v.z + v.w;
+        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    // a group = 2 adjacent float4 columns -> combine lane pairs
+    sum += __shfl_xor(sum, 1, 64);
+    sq += __shfl_xor(sq, 1, 64);
+    __shared__ float red[4][32][2];
+    if ((c4 & 1) == 0) { red[rl][c4 >> 1][0] = sum; red[rl][c4 >> 1][1] = sq; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int g = threadIdx.x >> 1, k = threadIdx.x & 1;
+        const double t = (double)red[0][g][k] + (double)red[1][g][k] + (double)red[2][g][k] + (double)red[3][g][k];
+        atomicAdd(stats + (((int64_t)n * lv.nseg + s) * G + g) * 2 + k, t);
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mean_rstd, int N, int G,
+                                   erd_levels lv, int cpg, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = N * lv.nseg * G;
+    if (i < total) {
+        const int s = (i / G) % lv.nseg;
+        const double m = (double)lv.cnt[s] * cpg;
+        const double mean = stats[i * 2] / m;
+        double var = stats[i * 2 + 1] / m - mean * mean;
+        if (var < 0) var = 0;
+        mean_rstd[i * 2] = (float)mean;
+        mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ c, float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean_rstd, int64_t A, erd_levels lv,
+                                                       GnChunks ch) {
+    const int n = blockIdx.y;
+    int s; int64_t r0, r1;
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int g = c4 >> 1;
+    const float2 mr = *reinterpret_cast<const float2*>(mean_rstd + (((int64_t)n * lv.nseg + s) * G + g) * 2);
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
+    const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
+        const float4 v = *reinterpret_cast<const float4*>(c + off);
+        float4 o;
+        o.x = fmaxf((v.x - mr.x) * mr.y * ga.x + be.x, 0.f);
+        o.y = fmaxf((v.y - mr.x) * mr.y * ga.y + be.y, 0.f);
+        o.z = fmaxf((v.z - mr.x) * mr.y * ga.z + be.z, 0.f);
+        o.w = fmaxf((v.w - mr.x) * mr.y * ga.w + be.w, 0.f);
+        *reinterpret_cast<float4*>(y + off) = o;
+    }
+}
+
+// backward pass 1: per (n,level,group) s1 = sum dyh, s2 = sum dyh*xhat (dyh = dy*mask*gamma);
+// per channel dgamma += sum dy*mask*xhat, dbeta += sum dy*mask
+template <int C, int G>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ c, const float* __restrict__ dy,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ mean_rstd,
+                                                           double* __restrict__ stats, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int64_t A, erd_levels lv,
+                                                           GnChunks ch) {
+    const int n = blockIdx.y;
+    int s; int64_t r0, r1;
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int g = c4 >> 1;
+    const float2 mr = *reinterpret_cast<const float2*>(mean_rstd + (((int64_t)n * lv.nseg + s) * G + g) * 2);
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
+    const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+    float s1 = 0.f, s2 = 0.f;
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
+        const float4 v = *reinterpret_cast<const float4*>(c + off);
+        const float4 d = *reinterpret_cast<const float4*>(dy + off);
+#define GN_ONE(F)                                                          \
+        {                                                                  \
+            const float xh = (v.F - mr.x) * mr.y;                          \
+            const float dm = (xh * ga.F + be.F > 0.f) ? d.F : 0.f;         \
+            dg.F += dm * xh;                                               \
+            db.F += dm;                                                    \
+            const float dh = dm * ga.F;                                    \
+            s1 += dh;                                                      \
+            s2 += dh * xh;                                                 \
+        }
+        GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w)
+#undef GN_ONE
+    }
+    s1 += __shfl_xor(s1, 1, 64);
+    s2 += __shfl_xor(s2, 1, 64);
+    __shared__ float red[4][32][2];
+    __shared__ float4 redc[4][64][2];
+    if ((c4 & 1) == 0) { red[rl][g][0] = s1; red[rl][g][1] = s2; }
+    redc[rl][c4][0] = dg;
+    redc[rl][c4][1] = db;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int gg = threadIdx.x >> 1, k = threadIdx.x & 1;
+        const double t = (double)red[0][gg][k] + (double)red[1][gg][k] + (double)red[2][gg][k] + (double)red[3][gg][k];
+        atomicAdd(stats + (((int64_t)n * lv.nseg + s) * G + gg) * 2 + k, t);
+    } else if (threadIdx.x < 128) {
+        const int cc = threadIdx.x - 64;
+        float4 a = redc[0][cc][0], b = redc[0][cc][1];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            a.x += redc[q][cc][0].x; a.y += redc[q][cc][0].y; a.z += redc[q][cc][0].z; a.w += redc[q][cc][0].w;
+            b.x += redc[q][cc][1].x; b.y += redc[q][cc][1].y; b.z += redc[q][cc][1].z; b.w += redc[q][cc][1].w;
+        }
+        atomicAdd(dgamma + cc * 4 + 0, a.x); atomicAdd(dgamma + cc * 4 + 1, a.y);
+        atomicAdd(dgamma + cc * 4 + 2, a.z); atomicAdd(dgamma + cc * 4 + 3, a.w);
+        atomicAdd(dbeta + cc * 4 + 0, b.x); atomicAdd(dbeta + cc * 4 + 1, b.y);
+        atomicAdd(dbeta + cc * 4 + 2, b.z); atomicAdd(dbeta + cc * 4 + 3, b.w);
+    }
+}
+
+// backward pass 2: dc = rstd * (dyh - (s1 + xhat*s2)/m)
+template <int C, int G>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ c, const float* __restrict__ dy,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ mean_rstd,
+                                                           const double* __restrict__ stats, float* __restrict__ dc,
+                                                           int64_t A, erd_levels lv, GnChunks ch) {
+    const int n = blockIdx.y;
+    int s; int64_t r0, r1;
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int g = c4 >> 1;
+    const int64_t si = ((int64_t)n * lv.nseg + s) * G + g;
+    const float2 mr = *reinterpret_cast<const float2*>(mean_rstd + si * 2);
+    const float inv_m = (float)(1.0 / ((double)lv.cnt[s] * (C / G)));
+    const float m1 = (float)stats[si * 2] * inv_m, m2 = (float)stats[si * 2 + 1] * inv_m;
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
+    const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
+        const float4 v = *reinterpret_cast<const float4*>(c + off);
+        const float4 d = *reinterpret_cast<const float4*>(dy + off);
+        float4 o;
+#define GN_ONE(F)                                                          \
+        {                                                                  \
+            const float xh = (v.F - mr.x) * mr.y;                          \
+            const float dh = (xh * ga.F + be.F > 0.f) ? d.F * ga.F : 0.f;  \
+            o.F = mr.y * (dh - m1 - xh * m2);                              \
+        }
+        GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w)
+#undef GN_ONE
+        *reinterpret_cast<float4*>(dc + off) = o;
+    }
+}
+
+GnChunks make_chunks(const erd_levels* lv) {
+    GnChunks ch;
+    ch.nseg = lv->nseg;
+    int acc = 0;
+    for (int s = 0; s < lv->nseg; ++s) {
+        ch.start[s] = acc;
+        acc += (int)((lv->cnt[s] + GN_ROWS - 1) / GN_ROWS);
+    }
+    ch.start[lv->nseg] = acc;
+    for (int s = lv->nseg + 1; s <= ERD_MAX_SEG; ++s) ch.start[s] = acc;
+    return ch;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_add_kernel(float4* __restrict__ fine, const float4* __restrict__ coarse,
+                                                           int N, int H, int W, int C4, int h, int w, int64_t fns,
+                                                           int64_t cns) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = i % C4;
+        int64_t r = i / C4;
+        const int x = r % W; r /= W;
+        const int y = r % H;
+        const int n = r / H;
+        // F.interpolate(mode='nearest', size=(H,W)): src = floor(dst * (h/H)); exact 2x => dst>>1
+        const int sy = min((int)((int64_t)y * h / H), h - 1), sx = min((int)((int64_t)x * w / W), w - 1);
+        float4* f = fine + (n * fns + ((int64_t)y * W + x) * C4 * 4) / 4 + c;
+        const float4 cv = coarse[(n * cns + ((int64_t)sy * w + sx) * C4 * 4) / 4 + c];
+        float4 v = *f;
+        v.x += cv.x; v.y += cv.y; v.z += cv.z; v.w += cv.w;
+        *f = v;
+    }
+}
+
+// adjoint: dcoarse[sy,sx] += sum of dfine over the pixels that map to it
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float4* __restrict__ dfine,
+                                                               float4* __restrict__ dcoarse, int N, int H, int W,
+                                                               int C4, int h, int w, int64_t fns, int64_t cns) {
+    const int64_t total = (int64_t)N * h * w * C4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = i % C4;
+        int64_t r = i / C4;
+        const int sx = r % w; r /= w;
+        const int sy = r % h;
+        const int n = r / h;
+        // fine rows y with floor(y*h/H) == sy
+        const int y0 = (int)(((int64_t)sy * H + h - 1) / h), y1 = (int)((((int64_t)sy + 1) * H + h - 1) / h);
+        const int x0 = (int)(((int64_t)sx * W + w - 1) / w), x1 = (int)((((int64_t)sx + 1) * W + w - 1) / w);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int y = y0; y < min(y1, H); ++y)
+            for (int x = x0; x < min(x1, W); ++x) {
+                const float4 v = dfine[(n * fns + ((int64_t)y * W + x) * C4 * 4) / 4 + c];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        float4* d = dcoarse + (n * cns + ((int64_t)sy * w + sx) * C4 * 4) / 4 + c;
+        float4 o = *d;
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        *d = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                     float* __restrict__ out, int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += x[r * C + c];
+        atomicAdd(out + c, s);
+    }
+}
+
+// y = x * alpha[level]  over [N][A][C] (gfl_head.py:229 `scale(self.gfl_reg(reg_feat))`, one Scale per level)
+__global__ __launch_bounds__(256) void level_scale_kernel(const float* __restrict__ x, const float* __restrict__ alphas,
+                                                          float* __restrict__ y, int64_t A, int C, erd_levels lv,
+                                                          GnChunks ch) {
+    const int n = blockIdx.y;
+    int s; int64_t r0, r1;
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    const float a = alphas[s];
+    const int64_t base = ((int64_t)n * A + r0) * C, cnt = (r1 - r0) * C;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) y[base + i] = x[base + i] * a;
+}
+
+__global__ __launch_bounds__(256) void level_scale_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ alphas, float* __restrict__ dx,
+                                                              float* __restrict__ dalphas, int64_t A, int C,
+                                                              erd_levels lv, GnChunks ch) {
+    const int n = blockIdx.y;
+    int s; int64_t r0, r1;
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    const float a = alphas[s];
+    const int64_t base = ((int64_t)n * A + r0) * C, cnt = (r1 - r0) * C;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+        const float g = dy[base + i];
+        acc += g * x[base + i];
+        dx[base + i] = g * a;
+    }
+    acc = erd::wave_sum(acc);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dalphas + s, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                  float4* __restrict__ buf, int64_t n4, float lr, float mom, float wd,
+                                                  float gs, int first) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = p[i];
+        const float4 gg = g[i];
+        float4 d;
+        d.x = gg.x * gs + wd * pp.x; d.y = gg.y * gs + wd * pp.y;
+        d.z = gg.z * gs + wd * pp.z; d.w = gg.w * gs + wd * pp.w;
+        float4 b;
+        if (first) {
+            b = d;
+        } else {
+            b = buf[i];
+            b.x = mom * b.x + d.x; b.y = mom * b.y + d.y; b.z = mom * b.z + d.z; b.w = mom * b.w + d.w;
+        }
+        buf[i] = b;
+        pp.x -= lr * b.x; pp.y -= lr * b.y; pp.z -= lr * b.z; pp.w -= lr * b.w;
+        p[i] = pp;
+    }
+}
+
+inline int grid_for(int64_t n, int cap = 2048) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int erd_stem_conv7x7_bn_relu(const float* x, const float* w, const float* scale, const float* shift,
+                                        float* out, int N, int H, int W, erd_stream_t stream) {
+    ERD_REQUIRE(x && w && scale && shift && out && N > 0, "stem: bad args");
+    const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+    hipLaunchKernelGGL(stem_kernel, dim3((OW + ST_TW - 1) / ST_TW, (OH + ST_TH - 1) / ST_TH, N), dim3(256), 0,
+                       (hipStream_t)stream, x, w, scale, shift, out, N, H, W, OH, OW);
+    return erd::check_launch("stem");
+}
+
+extern "C" int erd_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, erd_stream_t stream) {
+    ERD_REQUIRE(in && out && C % 4 == 0, "maxpool: bad args");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), N, H, W, C / 4, OH, OW);
+    return erd::check_launch("maxpool");
+}
+
+extern "C" int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                           float* scale, float* shift, int64_t n, erd_stream_t stream) {
+    ERD_REQUIRE(gamma && beta && mean && var && scale && shift, "bn_fold: null");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gamma,
+                       beta, mean, var, eps, scale, shift, n);
+    return erd::check_launch("bn_fold");
+}
+
+extern "C" int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, int64_t npix, int C,
+                                   int64_t nstride_rows, int64_t rows_per_img, float* colsum, int use_relu,
+                                   erd_stream_t stream) {
+    ERD_REQUIRE(dy && C % 4 == 0 && (!use_relu || (y && dz)), "relu_bwd: bad args");
+    if (npix == 0) return 0;
+    int rpb = 64;
+    while ((npix + rpb - 1) / rpb > 4096) rpb *= 2;
+    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((unsigned)((npix + rpb - 1) / rpb)), dim3(256), 0,
+                       (hipStream_t)stream, y, dy, dz, npix, C, nstride_rows, rows_per_img, colsum, use_relu, rpb);
+    return erd::check_launch("relu_bwd_colsum");
+}
+
+extern "C" int erd_bn_dgamma(const float* rowdot, const float* dbeta, const float* mean, const float* var, float eps,
+                             float* dgamma, int accumulate, int C, erd_stream_t stream) {
+    ERD_REQUIRE(rowdot && dbeta && mean && var && dgamma, "bn_dgamma: null");
+    hipLaunchKernelGGL(bn_dgamma_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowdot, dbeta, mean,
+                       var, eps, dgamma, accumulate, C);
+    return erd::check_launch("bn_dgamma");
+}
+
+extern "C" int erd_gn_relu_fwd(const float* c, float* y, const float* gamma, const float* beta, double* stats_ws,
+                               float* mean_rstd, int N, int64_t A, int C, int G, const erd_levels* lv, float eps,
+                               erd_stream_t stream) {
+    ERD_REQUIRE(c && y && gamma && beta && stats_ws && mean_rstd && lv, "gn_fwd: null");
+    ERD_REQUIRE(C == 256 && G == 32, "gn_fwd: only C=256,G=32 (gfl_head.py:109-110) is built");
+    hipStream_t st = (hipStream_t)stream;
+    const GnChunks ch = make_chunks(lv);
+    const int nst = N * lv->nseg * G;
+    hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
+    hipLaunchKernelGGL((gn_stats_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, stats_ws, A, *lv, ch);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nst + 255) / 256), dim3(256), 0, st, stats_ws, mean_rstd, N, G, *lv,
+                       C / G, eps);
+    hipLaunchKernelGGL((gn_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, y, gamma, beta,
+                       mean_rstd, A, *lv, ch);
+    return erd::check_launch("gn_relu_fwd");
+}
+
+extern "C" int erd_gn_relu_bwd(const float* c, const float* dy, const float* gamma, const float* beta,
+                               const float* mean_rstd, double* stats_ws, float* dc, float* dgamma, float* dbeta, int N,
+                               int64_t A, int C, int G, const erd_levels* lv, erd_stream_t stream) {
+    ERD_REQUIRE(c && dy && gamma && beta && mean_rstd && stats_ws && dc && dgamma && dbeta && lv, "gn_bwd: null");
+    ERD_REQUIRE(C == 256 && G == 32, "gn_bwd: only C=256,G=32 is built");
+    hipStream_t st = (hipStream_t)stream;
+    const GnChunks ch = make_chunks(lv);
+    const int nst = N * lv->nseg * G;
+    hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
+                       beta, mean_rstd, stats_ws, dgamma, dbeta, A, *lv, ch);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
+                       beta, mean_rstd, stats_ws, dc, A, *lv, ch);
+    return erd::check_launch("gn_relu_bwd");
+}
+
+extern "C" int erd_upsample2x_add(float* fine, const float* coarse, int N, int H, int W, int C, int h, int w,
+                                  int64_t fns, int64_t cns, erd_stream_t stream) {
+    ERD_REQUIRE(fine && coarse && C % 4 == 0 && fns % 4 == 0 && cns % 4 == 0, "upsample_add: bad args");
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(fine), reinterpret_cast<const float4*>(coarse), N, H, W, C / 4, h, w,
+                       fns, cns);
+    return erd::check_launch("upsample_add");
+}
+
+extern "C" int erd_upsample2x_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int C, int h, int w,
+                                      int64_t fns, int64_t cns, erd_stream_t stream) {
+    ERD_REQUIRE(dfine && dcoarse && C % 4 == 0 && fns % 4 == 0 && cns % 4 == 0, "upsample_add_bwd: bad args");
+    const int64_t total = (int64_t)N * h * w * (C / 4);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for(total, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(dfine), reinterpret_cast<float4*>(dcoarse), N, H, W, C / 4, h, w,
+                       fns, cns);
+    return erd::check_launch("upsample_add_bwd");
+}
+
+extern "C" int erd_colsum(const float* x, int64_t rows, int C, float* out, int accumulate, erd_stream_t stream) {
+    ERD_REQUIRE(x && out && C > 0, "colsum: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * C, st);
+    if (rows == 0) return 0;
+    int rpb = 64;
+    while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x, rows, C, out, rpb);
+    return erd::check_launch("colsum");
+}
+
+extern "C" int erd_level_scale(const float* x, const float* alphas, float* y, int N, int64_t A, int C,
+                               const erd_levels* lv, erd_stream_t stream) {
+    ERD_REQUIRE(x && alphas && y && lv, "level_scale: null");
+    const GnChunks ch = make_chunks(lv);
+    hipLaunchKernelGGL(level_scale_kernel, dim3(ch.start[lv->nseg], N), dim3(256), 0, (hipStream_t)stream, x, alphas, y,
+                       A, C, *lv, ch);
+    return erd::check_launch("level_scale");
+}
+
+extern "C" int erd_level_scale_bwd(const float* x, const float* dy, const float* alphas, float* dx, float* dalphas,
+                                   int N, int64_t A, int C, const erd_levels* lv, erd_stream_t stream) {
+    ERD_REQUIRE(x && dy && alphas && dx && dalphas && lv, "level_scale_bwd: null");
+    hipStream_t st = (hipStream_t)stream;
+    const GnChunks ch = make_chunks(lv);
+    hipMemsetAsync(dalphas, 0, sizeof(float) * lv->nseg, st);
+    hipLaunchKernelGGL(level_scale_bwd_kernel, dim3(ch.start[lv->nseg], N), dim3(256), 0, st, x, dy, alphas, dx,
+                       dalphas, A, C, *lv, ch);
+    return erd::check_launch("level_scale_bwd");
+}
+
+extern "C" int erd_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                                float weight_decay, float grad_scale, int first_step, erd_stream_t stream) {
+    ERD_REQUIRE(p && g && buf && n % 4 == 0, "sgd: bad args (n must be a multiple of 4)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(buf),
+                       n / 4, lr, momentum, weight_decay, grad_scale, first_step);
+    return erd::check_launch("sgd");
+}

@@ -1,0 +1,480 @@
+"""Thin Python wrappers over the C ABI (``include/erd_hip.h``): they only translate torch
+tensors (device memory + current HIP stream = plumbing) into raw pointers / sizes and pick
+launch geometry.  No arithmetic happens here and there is no non-HIP fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, Levels, WgradDesc, call
+
+Tensor = torch.Tensor
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_gpu(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.ErdHipError("erd_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+# ---------------------------------------------------------------------------------------------
+# workspace cache: one growing buffer per (name, device, stream) -- stream-ordered reuse is safe
+# ---------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def workspace(name: str, nbytes: int, device) -> Tensor:
+    key = (name, str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def ws_float(name: str, n: int, device) -> Tensor:
+    return workspace(name, n * 4, device)[: n * 4].view(torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# NHWC map helpers.  A "map" is a float32 tensor of shape [N,H,W,C] whose (H,W,C) dims are dense;
+# the image stride may be larger (level views of a [N,A,C] buffer).
+# ---------------------------------------------------------------------------------------------
+def _check_map(t: Tensor) -> None:
+    assert t.dtype == torch.float32 and t.dim() == 4, (t.dtype, t.shape)
+    N, H, W, Cc = t.shape
+    st = t.stride()
+    assert st[3] == 1 and st[2] == Cc and st[1] == W * Cc, f"map is not NHWC-dense: {t.shape} {st}"
+
+
+def level_views(cat: Tensor, sizes: Sequence[Tuple[int, int]]) -> List[Tensor]:
+    """[N,A,C] level-concatenated buffer -> per-level [N,h,w,C] views (no copy)."""
+    N, A, Cc = cat.shape
+    out, off = [], 0
+    for (h, w) in sizes:
+        out.append(cat[:, off:off + h * w, :].unflatten(1, (h, w)))
+        off += h * w
+    assert off == A
+    return out
+
+
+def make_levels(sizes: Sequence[Tuple[int, int]]) -> Levels:
+    lv = Levels()
+    lv.nseg = len(sizes)
+    off = 0
+    for i, (h, w) in enumerate(sizes):
+        lv.off[i] = off
+        lv.cnt[i] = h * w
+        off += h * w
+    return lv
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution (forward form, input-gradient form, weight gradient)
+# ---------------------------------------------------------------------------------------------
+def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor], alpha: Optional[Tensor]):
+    _check_map(x)
+    _check_map(out)
+    sg.inp = x.data_ptr()
+    sg.out = out.data_ptr()
+    sg.res = 0 if res is None else res.data_ptr()
+    sg.alpha = 0 if alpha is None else alpha.data_ptr()
+    sg.N, sg.IH, sg.IW = x.shape[0], x.shape[1], x.shape[2]
+    sg.GH, sg.GW = GH, GW
+    sg.OH, sg.OW = out.shape[1], out.shape[2]
+    sg.in_nstride = x.stride(0)
+    sg.out_nstride = out.stride(0)
+    if res is not None:
+        _check_map(res)
+        assert res.shape == out.shape and res.stride(0) == out.stride(0), "residual must share the output geometry"
+        sg.res_nstride = res.stride(0)
+
+
+def conv_out_size(h: int, k: int, s: int, p: int) -> int:
+    return (h + 2 * p - k) // s + 1
+
+
+def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int, stride: int, pad: int,
+                 scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+                 res: Optional[Sequence[Optional[Tensor]]] = None, alphas: Optional[Sequence[Tensor]] = None,
+                 relu: bool = False) -> None:
+    """outs[i] = epi(conv(xs[i], w)); w is [Cout,k,k,Cin] contiguous (OHWI).  All segments share w."""
+    _require_gpu(w, *xs, *outs)
+    Cout, Cin = w.shape[0], w.shape[3]
+    assert w.is_contiguous() and w.shape[1] == k and w.shape[2] == k
+    d = ConvDesc()
+    d.nseg = len(xs)
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        assert x.shape[3] == Cin and o.shape[3] == Cout
+        assert o.shape[1] == conv_out_size(x.shape[1], k, stride, pad) and o.shape[2] == conv_out_size(x.shape[2], k, stride, pad)
+        _fill_seg(d.seg[i], x, o, o.shape[1], o.shape[2], None if res is None else res[i],
+                  None if alphas is None else alphas[i])
+    d.w = w.data_ptr()
+    d.Cin, d.Cout, d.wrow = Cin, Cout, k * k * Cin
+    d.ntaps = k * k
+    for kh in range(k):
+        for kw in range(k):
+            t = kh * k + kw
+            d.dy[t], d.dx[t], d.wk[t] = kh - pad, kw - pad, t * Cin
+    d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
+    d.scale = 0 if scale is None else scale.data_ptr()
+    d.shift = 0 if shift is None else shift.data_ptr()
+    d.relu = 1 if relu else 0
+    call("erd_conv_igemm", C.byref(d), _stream())
+
+
+def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
+    """[Cout,k,k,Cin] -> [Cin,k,k,Cout] (* rowscale[co]): weights of the input-gradient convolution."""
+    Cout, k, _, Cin = w.shape
+    wt = torch.empty((Cin, k, k, Cout), dtype=torch.float32, device=w.device)
+    call("erd_weight_transpose", _p(w), _p(rowscale), _p(wt), Cout, k * k, Cin, 0, _stream())
+    return wt
+
+
+def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int, stride: int, pad: int,
+               accumulate: bool = False) -> None:
+    """dxs[i] (+)= conv_transpose(dzs[i]); wt = weight_transpose(w) is [Cin,k,k,Cout].
+    stride 1: one launch; stride 2: one launch per output-parity class (no zero-multiplies).
+    Pixels of dx that no tap reaches (k=1, stride 2) are NOT written: pass accumulate=True on a
+    buffer that already holds the other branch's gradient, or zero it first."""
+    _require_gpu(wt, *dzs, *dxs)
+    Cin, Cout = wt.shape[0], wt.shape[3]       # of the forward conv
+    classes = [(0, 0)] if stride == 1 else [(py, px) for py in range(stride) for px in range(stride)]
+    for (py, px) in classes:
+        taps = []
+        for kh in range(k):
+            if (py + pad - kh) % stride:
+                continue
+            for kw in range(k):
+                if (px + pad - kw) % stride:
+                    continue
+                taps.append(((py + pad - kh) // stride, (px + pad - kw) // stride, (kh * k + kw) * Cout))
+        if not taps:
+            continue
+        d = ConvDesc()
+        d.nseg = len(dzs)
+        skip = False
+        for i, (dz, dx) in enumerate(zip(dzs, dxs)):
+            assert dz.shape[3] == Cout and dx.shape[3] == Cin
+            GH = (dx.shape[1] - py + stride - 1) // stride
+            GW = (dx.shape[2] - px + stride - 1) // stride
+            if GH <= 0 or GW <= 0:
+                skip = True
+            _fill_seg(d.seg[i], dz, dx, max(GH, 0), max(GW, 0), dx if accumulate else None, None)
+        if skip and len(dzs) == 1:
+            continue
+        d.w = wt.data_ptr()
+        d.Cin, d.Cout, d.wrow = Cout, Cin, k * k * Cout     # roles swap: contraction over Cout
+        d.ntaps = len(taps)
+        for t, (dy, dx_, wk) in enumerate(taps):
+            d.dy[t], d.dx[t], d.wk[t] = dy, dx_, wk
+        d.in_stride, d.out_stride, d.oy, d.ox = 1, stride, py, px
+        d.scale = 0
+        d.shift = 0
+        d.relu = 0
+        call("erd_conv_igemm", C.byref(d), _stream())
+
+
+def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
+    tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * ntaps
+    kt = (npix + 31) // 32
+    want = max(1, (1024 + tiles - 1) // tiles)          # ~4 blocks per CU
+    return int(max(1, min(want, kt // 8 if kt >= 8 else 1, 512)))
+
+
+def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, stride: int, pad: int):
+    """returns (part [S_total, Cout, k*k, Cin], S_total): split-K partial slabs over all segments."""
+    _require_gpu(*xs, *dzs)
+    Cin, Cout = xs[0].shape[3], dzs[0].shape[3]
+    splits = [_pick_nsplit(dz.shape[0] * dz.shape[1] * dz.shape[2], Cout, Cin, k * k) for dz in dzs]
+    S = sum(splits)
+    slab = Cout * k * k * Cin
+    part = ws_float("wgrad_part", S * slab, xs[0].device)
+    off = 0
+    for x, dz, ns in zip(xs, dzs, splits):
+        _check_map(x)
+        _check_map(dz)
+        d = WgradDesc()
+        d.x, d.dz = x.data_ptr(), dz.data_ptr()
+        d.N, d.IH, d.IW = x.shape[0], x.shape[1], x.shape[2]
+        d.GH, d.GW, d.OH, d.OW = dz.shape[1], dz.shape[2], dz.shape[1], dz.shape[2]
+        d.x_nstride, d.dz_nstride = x.stride(0), dz.stride(0)
+        d.Cin, d.Cout, d.ntaps = Cin, Cout, k * k
+        for kh in range(k):
+            for kw in range(k):
+                d.dy[kh * k + kw], d.dx[kh * k + kw] = kh - pad, kw - pad
+        d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
+        d.part = part.data_ptr() + off * slab * 4
+        d.nsplit = ns
+        call("erd_conv_wgrad", C.byref(d), _stream())
+        off += ns
+    return part, S
+
+
+def wgrad_reduce(part: Tensor, S: int, w: Tensor, rowscale: Optional[Tensor], dW: Tensor, accumulate: bool,
+                 rowdot: Optional[Tensor]) -> None:
+    Cout = w.shape[0]
+    K = w.numel() // Cout
+    call("erd_wgrad_reduce", _p(part), S, Cout, K, _p(w), _p(rowscale), _p(dW), 1 if accumulate else 0,
+         _p(rowdot), _stream())
+
+
+# ---------------------------------------------------------------------------------------------
+# stem / pooling / norm helpers
+# ---------------------------------------------------------------------------------------------
+def stem(x_nchw: Tensor, w_ohwi: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
+    _require_gpu(x_nchw, w_ohwi)
+    assert x_nchw.is_contiguous() and x_nchw.shape[1] == 3 and w_ohwi.shape == (64, 7, 7, 3) and w_ohwi.is_contiguous()
+    N, _, H, W = x_nchw.shape
+    OH, OW = conv_out_size(H, 7, 2, 3), conv_out_size(W, 7, 2, 3)
+    y = torch.empty((N, OH, OW, 64), dtype=torch.float32, device=x_nchw.device)
+    call("erd_stem_conv7x7_bn_relu", _p(x_nchw), _p(w_ohwi), _p(scale), _p(shift), _p(y), N, H, W, _stream())
+    PH, PW = conv_out_size(OH, 3, 2, 1), conv_out_size(OW, 3, 2, 1)
+    z = torch.empty((N, PH, PW, 64), dtype=torch.float32, device=x_nchw.device)
+    call("erd_maxpool3x3s2", _p(y), _p(z), N, OH, OW, 64, _stream())
+    return z
+
+
+def bn_fold(gamma: Tensor, beta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5):
+    _require_gpu(gamma)
+    scale = torch.empty_like(gamma)
+    shift = torch.empty_like(gamma)
+    call("erd_bn_fold", _p(gamma), _p(beta), _p(mean), _p(var), eps, _p(scale), _p(shift), gamma.numel(), _stream())
+    return scale, shift
+
+
+def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum: bool = True):
+    """(dz, colsum): dz = dy*(y>0) (new buffer) or dy itself; colsum[c] = sum over pixels of dz."""
+    _check_map(dy)
+    N, H, W, Cc = dy.shape
+    colsum = torch.zeros(Cc, dtype=torch.float32, device=dy.device) if want_colsum else None
+    dz = dy
+    if use_relu:
+        _check_map(y)
+        assert y.is_contiguous() and dy.is_contiguous(), "relu backward runs on dense maps"
+        dz = torch.empty_like(dy)
+    call("erd_relu_bwd_colsum", _p(y), _p(dy), _p(dz), N * H * W, Cc, dy.stride(0), H * W, _p(colsum),
+         1 if use_relu else 0, _stream())
+    return dz, colsum
+
+
+def bn_dgamma(rowdot: Tensor, dbeta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5) -> Tensor:
+    dg = torch.empty_like(dbeta)
+    call("erd_bn_dgamma", _p(rowdot), _p(dbeta), _p(mean), _p(var), eps, _p(dg), 0, dbeta.numel(), _stream())
+    return dg
+
+
+def colsum(x2d: Tensor) -> Tensor:
+    """x2d: contiguous [rows, C] -> [C]"""
+    assert x2d.is_contiguous()
+    rows, Cc = x2d.shape[:-1].numel(), x2d.shape[-1]
+    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    call("erd_colsum", _p(x2d), rows, Cc, _p(out), 0, _stream())
+    return out
+
+
+def gn_relu_forward(c: Tensor, gamma: Tensor, beta: Tensor, sizes, G: int = 32, eps: float = 1e-5):
+    """c: [N,A,C] contiguous conv output -> (y, mean_rstd)"""
+    _require_gpu(c)
+    assert c.is_contiguous()
+    N, A, Cc = c.shape
+    lv = make_levels(sizes)
+    y = torch.empty_like(c)
+    nst = N * lv.nseg * G
+    stats = workspace("gn_stats", nst * 16, c.device)
+    mr = torch.empty((N, lv.nseg, G, 2), dtype=torch.float32, device=c.device)
+    call("erd_gn_relu_fwd", _p(c), _p(y), _p(gamma), _p(beta), _p(stats), _p(mr), N, A, Cc, G, C.byref(lv), eps,
+         _stream())
+    return y, mr
+
+
+def gn_relu_backward(c: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mr: Tensor, sizes, G: int = 32):
+    assert c.is_contiguous() and dy.is_contiguous()
+    N, A, Cc = c.shape
+    lv = make_levels(sizes)
+    stats = workspace("gn_stats", N * lv.nseg * G * 16, c.device)
+    dc = torch.empty_like(c)
+    dgamma = torch.zeros_like(gamma)
+    dbeta = torch.zeros_like(beta)
+    call("erd_gn_relu_bwd", _p(c), _p(dy), _p(gamma), _p(beta), _p(mr), _p(stats), _p(dc), _p(dgamma), _p(dbeta), N, A,
+         Cc, G, C.byref(lv), _stream())
+    return dc, dgamma, dbeta
+
+
+def upsample_add_(fine: Tensor, coarse: Tensor) -> None:
+    _check_map(fine)
+    _check_map(coarse)
+    N, H, W, Cc = fine.shape
+    call("erd_upsample2x_add", _p(fine), _p(coarse), N, H, W, Cc, coarse.shape[1], coarse.shape[2], fine.stride(0),
+         coarse.stride(0), _stream())
+
+
+def upsample_add_bwd_(dfine: Tensor, dcoarse: Tensor) -> None:
+    """dcoarse += adjoint(nearest-upsample)(dfine)"""
+    _check_map(dfine)
+    _check_map(dcoarse)
+    N, H, W, Cc = dfine.shape
+    call("erd_upsample2x_add_bwd", _p(dfine), _p(dcoarse), N, H, W, Cc, dcoarse.shape[1], dcoarse.shape[2],
+         dfine.stride(0), dcoarse.stride(0), _stream())
+
+
+def level_scale(x: Tensor, alphas: Tensor, sizes) -> Tensor:
+    assert x.is_contiguous() and alphas.is_contiguous()
+    N, A, Cc = x.shape
+    lv = make_levels(sizes)
+    y = torch.empty_like(x)
+    call("erd_level_scale", _p(x), _p(alphas), _p(y), N, A, Cc, C.byref(lv), _stream())
+    return y
+
+
+def level_scale_bwd(x: Tensor, dy: Tensor, alphas: Tensor, sizes):
+    assert x.is_contiguous() and dy.is_contiguous()
+    N, A, Cc = x.shape
+    lv = make_levels(sizes)
+    dx = torch.empty_like(x)
+    dal = torch.empty_like(alphas)
+    call("erd_level_scale_bwd", _p(x), _p(dy), _p(alphas), _p(dx), _p(dal), N, A, Cc, C.byref(lv), _stream())
+    return dx, dal
+
+
+def sgd_momentum_(p: Tensor, g: Tensor, buf: Tensor, lr: float, momentum: float, weight_decay: float,
+                  grad_scale: float, first_step: bool) -> None:
+    assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous() and p.numel() % 4 == 0
+    call("erd_sgd_momentum", _p(p), _p(g), _p(buf), p.numel(), lr, momentum, weight_decay, grad_scale,
+         1 if first_step else 0, _stream())
+
+
+# ---------------------------------------------------------------------------------------------
+# ERS / anchors / ATSS / losses
+# ---------------------------------------------------------------------------------------------
+def ers_select(t_cls: Tensor, t_bbox: Tensor):
+    """[N,A,Ccls], [N,A,68] -> dict(mask_cls, mask_bbox [N,A] u8; idx_cls, idx_bbox [N,A] i64 (first counts valid);
+    counts [N,2] i32; thr [N,2] f32).  No host sync."""
+    _require_gpu(t_cls, t_bbox)
+    assert t_cls.is_contiguous() and t_bbox.is_contiguous()
+    N, A, Cc = t_cls.shape
+    dev = t_cls.device
+    out = dict(mask_cls=torch.empty((N, A), dtype=torch.uint8, device=dev),
+               mask_bbox=torch.empty((N, A), dtype=torch.uint8, device=dev),
+               idx_cls=torch.empty((N, A), dtype=torch.int64, device=dev),
+               idx_bbox=torch.empty((N, A), dtype=torch.int64, device=dev),
+               counts=torch.empty((N, 2), dtype=torch.int32, device=dev),
+               thr=torch.empty((N, 2), dtype=torch.float32, device=dev))
+    ws = workspace("ers", N * 32 + 2 * N * A * 4, dev)
+    call("erd_ers_select", _p(t_cls), _p(t_bbox), N, A, Cc, t_bbox.shape[2], _p(out["mask_cls"]), _p(out["mask_bbox"]),
+         _p(out["idx_cls"]), _p(out["idx_bbox"]), _p(out["counts"]), _p(out["thr"]), _p(ws), _stream())
+    return out
+
+
+def _iarr(vals, ctype=C.c_int):
+    return (ctype * len(vals))(*[int(v) for v in vals])
+
+
+def grid_anchors(sizes, strides, device, octave_scale: int = 8) -> Tensor:
+    A = sum(h * w for h, w in sizes)
+    anchors = torch.empty((A, 4), dtype=torch.float32, device=device)
+    call("erd_grid_anchors", _p(anchors), _iarr([h for h, _ in sizes]), _iarr([w for _, w in sizes]), _iarr(strides),
+         len(sizes), octave_scale, _stream())
+    return anchors
+
+
+def _lvl_off(sizes):
+    off = [0]
+    for h, w in sizes:
+        off.append(off[-1] + h * w)
+    return _iarr(off, C.c_int64)
+
+
+def atss_assign(anchors: Tensor, valid: Optional[Tensor], sizes, gt_boxes: Tensor, gt_labels: Tensor, gt_off: Tensor,
+                N: int, max_gt: int, num_classes: int, topk: int = 9):
+    A = anchors.shape[0]
+    dev = anchors.device
+    labels = torch.empty((N, A), dtype=torch.int64, device=dev)
+    lw = torch.empty((N, A), dtype=torch.float32, device=dev)
+    bt = torch.empty((N, A, 4), dtype=torch.float32, device=dev)
+    npos = torch.empty((N,), dtype=torch.int32, device=dev)
+    ws = workspace("atss", N * A * 8, dev)
+    call("erd_atss_assign", _p(anchors), _p(valid), _lvl_off(sizes), len(sizes), A, _p(gt_boxes), _p(gt_labels),
+         _p(gt_off), N, max_gt, topk, num_classes, _p(labels), _p(lw), _p(bt), _p(npos), _p(ws), _stream())
+    return labels, lw, bt, npos
+
+
+def gfl_losses_fwd(cls, bbox, anchors, labels, lw, bt, sizes, strides, c_old, c_all):
+    N, A, _ = cls.shape
+    dev = cls.device
+    score = torch.empty((N, A), dtype=torch.float32, device=dev)
+    wt = torch.empty((N, A), dtype=torch.float32, device=dev)
+    sums = torch.empty((len(sizes), 4), dtype=torch.float64, device=dev)
+    call("erd_gfl_losses_fwd", _p(cls), _p(bbox), _p(anchors), _p(labels), _p(lw), _p(bt), _lvl_off(sizes),
+         _iarr(strides), len(sizes), N, A, c_old, c_all, _p(score), _p(wt), _p(sums), _stream())
+    return score, wt, sums
+
+
+def gfl_losses_bwd(cls, bbox, anchors, labels, lw, bt, sizes, strides, c_old, c_all, score, wt, coef):
+    N, A, _ = cls.shape
+    dcls = torch.empty_like(cls)
+    dbbox = torch.empty_like(bbox)
+    call("erd_gfl_losses_bwd", _p(cls), _p(bbox), _p(anchors), _p(labels), _p(lw), _p(bt), _lvl_off(sizes),
+         _iarr(strides), len(sizes), N, A, c_old, c_all, _p(score), _p(wt), _p(coef), _p(dcls), _p(dbbox), _stream())
+    return dcls, dbbox
+
+
+def l2_distill(s_cls, t_cls, idx_cls, counts, c_old):
+    N, A, c_s = s_cls.shape
+    sums = torch.empty((N,), dtype=torch.float64, device=s_cls.device)
+    call("erd_l2_distill", _p(s_cls), _p(t_cls), _p(idx_cls), _p(counts), N, A, c_s, t_cls.shape[2], c_old, _p(sums),
+         _stream())
+    return sums
+
+
+def l2_distill_bwd_(s_cls, t_cls, idx_cls, counts, coef, c_old, dcls):
+    N, A, c_s = s_cls.shape
+    call("erd_l2_distill_bwd", _p(s_cls), _p(t_cls), _p(idx_cls), _p(counts), _p(coef), N, A, c_s, t_cls.shape[2],
+         c_old, _p(dcls), _stream())
+
+
+def distill_nms(t_cls, t_bbox, anchors, idx_bbox, counts, iou_thr: float = 0.005):
+    N, A, c_t = t_cls.shape
+    dev = t_cls.device
+    keep = torch.empty((N, A), dtype=torch.uint8, device=dev)
+    kcnt = torch.empty((N,), dtype=torch.int32, device=dev)
+    nbytes = N * A * 32
+    ws = workspace("nms", nbytes, dev)
+    call("erd_distill_nms", _p(t_cls), _p(t_bbox), _p(anchors), _p(idx_bbox), _p(counts), N, A, c_t, iou_thr, _p(keep),
+         _p(kcnt), _p(ws), C.c_size_t(nbytes), _stream())
+    return keep, kcnt
+
+
+def kd_kl(s_bbox, t_bbox, s_cls, keep, c_old, T):
+    N, A, c_s = s_cls.shape
+    sums = torch.empty((N,), dtype=torch.float64, device=s_cls.device)
+    call("erd_kd_kl", _p(s_bbox), _p(t_bbox), _p(s_cls), _p(keep), N, A, c_s, c_old, float(T), _p(sums), _stream())
+    return sums
+
+
+def kd_kl_bwd_(s_bbox, t_bbox, s_cls, keep, coef, c_old, T, dbbox):
+    N, A, c_s = s_cls.shape
+    call("erd_kd_kl_bwd", _p(s_bbox), _p(t_bbox), _p(s_cls), _p(keep), _p(coef), N, A, c_s, c_old, float(T), _p(dbbox),
+         _stream())
+
+
+def loss_finalize(lvl_sums, avg, l2_sums, kd_sums, counts, nlvl, N, c_old, w_dist, lw_cls, lw_bbox, lw_dfl, lw_ld,
+                  upstream: Optional[Tensor], want_losses: bool, want_coef: bool):
+    dev = lvl_sums.device
+    losses = torch.empty((3 * nlvl + 2 * N,), dtype=torch.float32, device=dev) if want_losses else None
+    coef = torch.empty((4 * nlvl + 2 * N,), dtype=torch.float32, device=dev) if want_coef else None
+    call("erd_loss_finalize", _p(lvl_sums), _p(avg), _p(l2_sums), _p(kd_sums), _p(counts), nlvl, N, c_old,
+         float(w_dist), float(lw_cls), float(lw_bbox), float(lw_dfl), float(lw_ld), _p(upstream), _p(losses), _p(coef),
+         _stream())
+    return losses, coef

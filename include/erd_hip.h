@@ -1,0 +1,218 @@
+/*
+ * erd_hip.h -- C ABI of liberd_hip.so: the MI355X (gfx950) kernels of the ERD
+ * incremental-detection training step.
+ *
+ * The reference (Hi-FT/ERD, a pure-Python fork of MMDetection 3.0.0) has no C
+ * ABI of its own: every native kernel its hot path executes is reached through
+ * a torch ATen / mmcv operator dispatch.  Each
+ * entry point below therefore names the reference *call site* (file:line under
+ * /root/reference) whose operator dispatch it replaces.
+ *
+ * Conventions:
+ *   - plain device pointers + explicit sizes; fp32 activations are NHWC, weights
+ *     are [Cout][kh][kw][Cin] (= OIHW tensors in channels_last memory format);
+ *   - no allocation inside: the caller passes workspaces;
+ *   - every call takes the hipStream_t it is enqueued on (as void*);
+ *   - returns 0 on success, a negative ERD_E* argument error, or a positive
+ *     hipError_t; never throws; message via erd_last_error() (thread-local);
+ *   - no global mutable state; re-entrant.
+ */
+#ifndef ERD_HIP_H_
+#define ERD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ERD_ABI_VERSION 1
+#define ERD_MAX_SEG 5   /* FPN levels batched in one launch */
+#define ERD_MAX_TAPS 9
+
+#define ERD_EINVAL (-1)
+#define ERD_EUNSUPPORTED (-2)
+
+typedef void* erd_stream_t; /* hipStream_t */
+
+int erd_abi_version(void);
+const char* erd_last_error(void);
+
+/* ---- convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) --------------------
+ * One "segment" = one feature map (level); a launch may batch up to ERD_MAX_SEG
+ * segments that share weights (the GFL head, gfl_head.py:156-177 "weights shared
+ * across the 5 levels").  The iteration grid of a segment is N x GH x GW points
+ * (a,b); tap t reads in[n, a*in_stride+dy[t], b*in_stride+dx[t], :] (zero outside
+ * [0,IH)x[0,IW)) and the result goes to out[n, a*out_stride+oy, b*out_stride+ox, :].
+ * Forward conv, stride-1 dgrad and the four parity classes of a stride-2 dgrad are
+ * all instances of this one form. */
+typedef struct {
+    const float* in;     /* [N][IH][IW][Cin], image stride in_nstride (elements) */
+    float* out;          /* [N][OH][OW][Cout], image stride out_nstride */
+    const float* res;    /* optional residual, same geometry as out (may alias out) */
+    const float* alpha;  /* optional device scalar multiplied in the epilogue */
+    int N, IH, IW, GH, GW, OH, OW;
+    int64_t in_nstride, out_nstride, res_nstride;
+} erd_conv_seg;
+
+typedef struct {
+    int nseg;
+    erd_conv_seg seg[ERD_MAX_SEG];
+    const float* w;      /* [Cout][wrow] ; tap t uses columns [wk[t], wk[t]+Cin) */
+    int Cin, Cout, wrow;
+    int ntaps;
+    int dy[ERD_MAX_TAPS], dx[ERD_MAX_TAPS], wk[ERD_MAX_TAPS];
+    int in_stride, out_stride, oy, ox;
+    const float* scale;  /* optional [Cout]: v = acc*scale[co]            */
+    const float* shift;  /* optional [Cout]: v += shift[co]  (bias / folded BN) */
+    int relu;            /* v = max(v,0) last */
+} erd_conv_desc;
+
+/* replaces: F.conv2d dispatches at resnet.py:268-283, res_layer.py:57-63, fpn.py:196,215-220,
+ * gfl_head.py:224-229 (+ fused frozen-stat BN resnet.py:268-300 / bias / ReLU / residual add);
+ * and, run on dz with transformed weights, their convolution_backward (input grad). */
+int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream);
+
+/* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
+ * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
+ * replaces: convolution_backward (weight grad) of the same call sites. */
+typedef struct {
+    const float* x;      /* [N][IH][IW][Cin] */
+    const float* dz;     /* [N][OH][OW][Cout], read at (a*out_stride+oy, b*out_stride+ox) */
+    int N, IH, IW, GH, GW, OH, OW;
+    int64_t x_nstride, dz_nstride;
+    int Cin, Cout, ntaps;
+    int dy[ERD_MAX_TAPS], dx[ERD_MAX_TAPS];
+    int in_stride, out_stride, oy, ox;
+    float* part;         /* [nsplit][Cout][ntaps][Cin] */
+    int nsplit;
+} erd_wgrad_desc;
+int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream);
+
+/* dW (+)= rowscale[co] * sum_s part[s]; optional rowdot[co] = <W[co,:], sum_s part[s][co,:]>
+ * (used for d gamma of a frozen-statistics BN: resnet.py:648-657 keeps BN in eval while
+ * gamma/beta train). */
+int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, const float* w,
+                     const float* rowscale, float* dW, int accumulate, float* rowdot,
+                     erd_stream_t stream);
+
+/* dst[ci][t'][co] = rowscale[co] * w[co][t][ci]  (t' = flip ? ntaps-1-t : t): weights of the
+ * input-gradient convolution. */
+int erd_weight_transpose(const float* w, const float* rowscale, float* dst, int Cout, int ntaps,
+                         int Cin, int flip, erd_stream_t stream);
+
+/* ---- stem (resnet.py:636-639): conv7x7/2 (3->64) + frozen BN + ReLU, then maxpool 3x3/2 ---- */
+int erd_stem_conv7x7_bn_relu(const float* x_nchw, const float* w_ohwi, const float* scale,
+                             const float* shift, float* out_nhwc, int N, int H, int W,
+                             erd_stream_t stream);
+int erd_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, erd_stream_t stream);
+
+/* ---- frozen-statistics BN helpers ---------------------------------------------------------- */
+/* scale = gamma*rsqrt(var+eps), shift = beta-mean*scale over n channels (resnet.py:268-300, eval BN) */
+int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                float eps, float* scale, float* shift, int64_t n, erd_stream_t stream);
+/* use_relu: dz = dy * (y > 0) (dz may alias dy); else dz is not written (dz == dy semantically);
+ * colsum[c] += sum_p dz[p,c].  Rows are [npix][C] with an image stride (level views). */
+int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, int64_t npix, int C,
+                        int64_t nstride_rows, int64_t rows_per_img, float* colsum, int use_relu,
+                        erd_stream_t stream);
+/* dgamma = rsqrt(var+eps) * (rowdot - mean*dbeta) */
+int erd_bn_dgamma(const float* rowdot, const float* dbeta, const float* mean, const float* var,
+                  float eps, float* dgamma, int accumulate, int C, erd_stream_t stream);
+
+/* ---- GroupNorm(32)+ReLU over level-concatenated [N][A][C] maps (gfl_head.py:158-177) -------- */
+typedef struct {
+    int nseg;
+    int64_t off[ERD_MAX_SEG]; /* first row of the level inside an image's A rows */
+    int64_t cnt[ERD_MAX_SEG]; /* rows (pixels) of the level per image */
+} erd_levels;
+int erd_gn_relu_fwd(const float* c, float* y, const float* gamma, const float* beta, double* stats_ws,
+                    float* mean_rstd, int N, int64_t A, int C, int G, const erd_levels* lv, float eps,
+                    erd_stream_t stream);
+int erd_gn_relu_bwd(const float* c, const float* dy, const float* gamma, const float* beta,
+                    const float* mean_rstd, double* stats_ws, float* dc, float* dgamma, float* dbeta,
+                    int N, int64_t A, int C, int G, const erd_levels* lv, erd_stream_t stream);
+
+/* ---- FPN top-down (fpn.py:181-191): lat[l-1] += nearest2x(lat[l]) and its adjoint -------------- */
+int erd_upsample2x_add(float* fine, const float* coarse, int N, int H, int W, int C, int h, int w,
+                       int64_t fine_nstride, int64_t coarse_nstride, erd_stream_t stream);
+int erd_upsample2x_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int C, int h, int w,
+                           int64_t fine_nstride, int64_t coarse_nstride, erd_stream_t stream);
+
+/* ---- small dense helpers -------------------------------------------------------------------- */
+int erd_colsum(const float* x, int64_t rows, int C, float* out, int accumulate, erd_stream_t stream);
+/* y[n][a][:] = x[n][a][:] * alphas[level(a)] (gfl_head.py:229, one learnable Scale per level) and adjoint */
+int erd_level_scale(const float* x, const float* alphas, float* y, int N, int64_t A, int C,
+                    const erd_levels* lv, erd_stream_t stream);
+int erd_level_scale_bwd(const float* x, const float* dy, const float* alphas, float* dx, float* dalphas,
+                        int N, int64_t A, int C, const erd_levels* lv, erd_stream_t stream);
+/* SGD(momentum, weight decay) over one flat buffer (torch.optim.SGD; config :112-114) */
+int erd_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                     float weight_decay, float grad_scale, int first_step, erd_stream_t stream);
+
+/* ---- ERS (gfl_increment_erd.py:143-163) -------------------------------------------------------- */
+/* per image: m_c = max_k sigmoid(cls[a,k]), keep iff m_c > mean + 2*std (unbiased); m_b = max_j
+ * bbox[a,j] likewise.  Writes masks [N][A] (uint8), ascending index lists idx_*[N][A] (int64) and
+ * counts[N][2] (int32), thresholds thr[N][2]. */
+int erd_ers_select(const float* cls, const float* bbox, int N, int64_t A, int Ccls, int Cbox,
+                   uint8_t* mask_cls, uint8_t* mask_bbox, int64_t* idx_cls, int64_t* idx_bbox,
+                   int32_t* counts, float* thr, double* ws, erd_stream_t stream);
+
+/* ---- anchors / ATSS (anchor_generator.py:259-301; atss_assigner.py:74-254) ---------------------- */
+int erd_grid_anchors(float* anchors, const int* hs, const int* ws, const int* strides, int nlvl,
+                     int octave_scale, erd_stream_t stream);
+/* labels[N][A] int64 (bg = num_classes), label_weights[N][A], bbox_targets[N][A][4], num_pos[N].
+ * gt boxes of all images concatenated, gt_off[N+1] (device); max_gt = max boxes per image (host);
+ * valid = optional [N][A] flags (anchor_generator.py:415-476); ws = N*A*8 bytes. */
+int erd_atss_assign(const float* anchors, const uint8_t* valid, const int64_t* lvl_off, int nlvl,
+                    int64_t A, const float* gt_boxes, const int64_t* gt_labels, const int32_t* gt_off,
+                    int N, int max_gt, int topk, int num_classes, int64_t* labels, float* label_weights,
+                    float* bbox_targets, int32_t* num_pos, void* ws, erd_stream_t stream);
+
+/* ---- supervised losses on the new classes (gfl_head_increment_erd.py:225-322) ------------------- */
+/* One launch over all N*A anchors (level-concatenated).  Produces per-level sums
+ * out[nlvl][4] = {qfl_sum, giou_sum(w-weighted), dfl_sum(w-weighted), sum w} and, in the same pass,
+ * the gradients d/d cls[:, c_old:] and d/d bbox of (qfl_sum*gq + giou_sum*gb[l] + dfl_sum*gd[l]). */
+int erd_gfl_losses_fwd(const float* cls, const float* bbox, const float* anchors, const int64_t* labels,
+                       const float* label_weights, const float* bbox_targets, const int64_t* lvl_off,
+                       const int* strides, int nlvl, int N, int64_t A, int c_old, int c_all,
+                       float* score_ws, float* wt_ws, double* out_sums, erd_stream_t stream);
+int erd_gfl_losses_bwd(const float* cls, const float* bbox, const float* anchors, const int64_t* labels,
+                       const float* label_weights, const float* bbox_targets, const int64_t* lvl_off,
+                       const int* strides, int nlvl, int N, int64_t A, int c_old, int c_all,
+                       const float* score_ws, const float* wt_ws, const float* coef /* erd_loss_finalize layout */,
+                       float* dcls, float* dbbox, erd_stream_t stream);
+
+/* ---- response distillation (gfl_head_increment_erd.py:142-223) ------------------------------------ */
+/* L2 over ERS-selected rows: sums[n] = sum_{a in idx_cls[n], k<c_old} (s-t)^2 ; bwd adds coef[n]*2(s-t) */
+int erd_l2_distill(const float* s_cls, const float* t_cls, const int64_t* idx_cls, const int32_t* counts,
+                   int N, int64_t A, int c_s, int c_t, int c_old, double* sums, erd_stream_t stream);
+int erd_l2_distill_bwd(const float* s_cls, const float* t_cls, const int64_t* idx_cls,
+                       const int32_t* counts, const float* coef, int N, int64_t A, int c_s, int c_t,
+                       int c_old, float* dcls, erd_stream_t stream);
+/* teacher boxes (D8 unit mix) + class-offset NMS (mmcv.ops.batched_nms restated, UNPINNED) */
+int erd_distill_nms(const float* t_cls, const float* t_bbox, const float* anchors,
+                    const int64_t* idx_bbox, const int32_t* counts, int N, int64_t A, int c_t,
+                    float iou_thr, uint8_t* keep_mask, int32_t* keep_count, float* ws, size_t ws_bytes,
+                    erd_stream_t stream);
+/* KD-KL(T) over kept rows (kd_loss.py:12-37): sums[n] = sum_r w_r * T^2 * mean_j KL ; bwd adds grads */
+int erd_kd_kl(const float* s_bbox, const float* t_bbox, const float* s_cls, const uint8_t* keep_mask,
+              int N, int64_t A, int c_s, int c_old, float T, double* sums, erd_stream_t stream);
+int erd_kd_kl_bwd(const float* s_bbox, const float* t_bbox, const float* s_cls, const uint8_t* keep_mask,
+                  const float* coef, int N, int64_t A, int c_s, int c_old, float T, float* dbbox,
+                  erd_stream_t stream);
+
+/* loss vector [3*nlvl + 2N] = loss_cls[l] | loss_bbox[l] | loss_dfl[l] | loss_dist_cls[n] | loss_dist_bbox[n]
+ * from the kernel sums (gfl_head_increment_erd.py:390-409,436-454; losses/utils.py:30-65) and/or the
+ * backward coefficients coef[4*nlvl + 2N] given the upstream gradient of the loss vector.
+ * avg[2] = {reduce_mean(sum num_pos), reduce_mean(sum weight_targets)} (device). */
+int erd_loss_finalize(const double* lvl_sums, const float* avg, const double* l2_sums, const double* kd_sums,
+                      const int32_t* counts, int nlvl, int N, int c_old, float dist_loss_weight,
+                      float lw_cls, float lw_bbox, float lw_dfl, float lw_ld, const float* upstream,
+                      float* losses, float* coef, erd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ERD_HIP_H_ */

@@ -1,0 +1,218 @@
+"""GPU: every C-ABI kernel group against a plain PyTorch-CPU fp32 reference of the same op
+(conv / norm / pooling) -- the per-anchor ERD kernels are checked against the oracle and the
+golden fixtures in test_gpu_losses.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import golden_inputs as G
+
+
+@pytest.fixture(scope="module")
+def K():
+    from erd_amd import kernels
+    assert torch.cuda.is_available()
+    return kernels
+
+
+def dev(t):
+    return t.cuda()
+
+
+def nhwc(t):      # NCHW cpu -> NHWC gpu contiguous
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def to_nchw(t):   # NHWC gpu -> NCHW cpu
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W, k, s, p
+    (2, 64, 64, 20, 28, 1, 1, 0),
+    (2, 64, 256, 20, 28, 1, 1, 0),
+    (1, 256, 128, 25, 42, 1, 1, 0),
+    (2, 128, 128, 26, 30, 3, 1, 1),
+    (2, 128, 128, 26, 30, 3, 2, 1),
+    (1, 256, 256, 13, 21, 3, 2, 1),     # odd sizes (P6-like 25x42 -> 13x21 is below)
+    (1, 256, 256, 25, 42, 3, 2, 1),
+    (2, 256, 512, 20, 28, 1, 2, 0),     # downsample
+    (1, 256, 80, 13, 21, 3, 1, 1),      # gfl_cls
+    (1, 256, 68, 7, 11, 3, 1, 1),       # gfl_reg
+    (1, 2048, 512, 7, 11, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p", CONV_CASES)
+def test_conv_forward_epilogues(K, N, Cin, Cout, H, W, k, s, p):
+    x = G.randn(1, N, Cin, H, W)
+    w = G.randn(2, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    scale = 0.5 + G.rand(3, Cout)
+    shift = G.randn(4, Cout, scale=0.1)
+    ref = F.conv2d(x, w, None, s, p)
+    OH, OW = ref.shape[2:]
+    res = G.randn(5, N, Cout, OH, OW)
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xg = nhwc(x)
+    # plain
+    out = torch.empty((N, OH, OW, Cout), device="cuda")
+    K.conv_forward([xg], wg, [out], k, s, p)
+    assert relerr(to_nchw(out), ref) < 2e-5
+    # folded BN + residual + relu
+    out2 = torch.empty_like(out)
+    K.conv_forward([xg], wg, [out2], k, s, p, scale=scale.cuda(), shift=shift.cuda(), res=[nhwc(res)], relu=True)
+    ref2 = F.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    assert relerr(to_nchw(out2), ref2) < 2e-5
+    # bias + per-level scalar
+    alpha = torch.tensor(1.37)
+    out3 = torch.empty_like(out)
+    K.conv_forward([xg], wg, [out3], k, s, p, shift=shift.cuda(), alphas=[alpha.cuda()])
+    assert relerr(to_nchw(out3), (ref + shift.view(1, -1, 1, 1)) * alpha) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p", CONV_CASES)
+def test_conv_dgrad_wgrad(K, N, Cin, Cout, H, W, k, s, p):
+    x = G.randn(11, N, Cin, H, W).requires_grad_(True)
+    w = G.randn(12, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = G.randn(13, *y.shape)
+    y.backward(dy)
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    rowscale = 0.5 + G.rand(14, Cout)
+    # dgrad (with rowscale folded into the transposed weights == dy*scale)
+    wt = K.weight_transpose(wg, rowscale.cuda())
+    dx = torch.zeros((N, H, W, Cin), device="cuda")
+    K.conv_dgrad([nhwc(dy)], wt, [dx], k, s, p)
+    xr = torch.autograd.grad(F.conv2d(x, w, None, s, p), x, dy * rowscale.view(1, -1, 1, 1))[0]
+    assert relerr(to_nchw(dx), xr) < 2e-5
+    # accumulate form
+    base = G.randn(15, N, Cin, H, W)
+    dx2 = nhwc(base)
+    wt1 = K.weight_transpose(wg, None)
+    K.conv_dgrad([nhwc(dy)], wt1, [dx2], k, s, p, accumulate=True)
+    assert relerr(to_nchw(dx2), x.grad + base) < 2e-5
+    # wgrad + reduce (+ rowdot)
+    part, S = K.conv_wgrad_partials([nhwc(x.detach())], [nhwc(dy)], k, s, p)
+    dW = torch.empty_like(wg)
+    rowdot = torch.empty(Cout, device="cuda")
+    K.wgrad_reduce(part, S, wg, rowscale.cuda(), dW, False, rowdot)
+    gw = w.grad.permute(0, 2, 3, 1)
+    assert relerr(dW.cpu(), gw * rowscale.view(-1, 1, 1, 1)) < 5e-5
+    assert relerr(rowdot.cpu(), (gw * w.detach().permute(0, 2, 3, 1)).sum((1, 2, 3))) < 5e-4
+
+
+def test_conv_multilevel_shared_weights(K):
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    N, Cc = 2, 256
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(21, N, A, Cc)
+    w = G.randn(22, Cc, Cc, 3, 3, scale=(2.0 / (Cc * 9)) ** 0.5)
+    xg = x.cuda()
+    out = torch.empty((N, A, Cc), device="cuda")
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    K.conv_forward(K.level_views(xg, sizes), wg, K.level_views(out, sizes), 3, 1, 1)
+    off = 0
+    for (h, wd) in sizes:
+        xl = x[:, off:off + h * wd].reshape(N, h, wd, Cc).permute(0, 3, 1, 2)
+        ref = F.conv2d(xl, w, None, 1, 1).permute(0, 2, 3, 1).reshape(N, h * wd, Cc)
+        assert relerr(out[:, off:off + h * wd].cpu(), ref) < 2e-5
+        off += h * wd
+
+
+def test_stem_and_maxpool(K):
+    x = G.randn(31, 2, 3, 67, 93)
+    w = G.randn(32, 64, 3, 7, 7, scale=0.1)
+    scale, shift = 0.5 + G.rand(33, 64), G.randn(34, 64, scale=0.1)
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1)
+    out = K.stem(x.cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), scale.cuda(), shift.cuda())
+    assert relerr(to_nchw(out), ref) < 2e-5
+
+
+def test_bn_fold_and_backward_pieces(K):
+    Cc = 128
+    g, b, m, v = 0.5 + G.rand(41, Cc), G.randn(42, Cc), G.randn(43, Cc), 0.5 + G.rand(44, Cc)
+    sc, sh = K.bn_fold(g.cuda(), b.cuda(), m.cuda(), v.cuda())
+    s_ref = g / torch.sqrt(v + 1e-5)
+    assert relerr(sc.cpu(), s_ref) < 1e-6 and relerr(sh.cpu(), b - m * s_ref) < 1e-6
+    y = G.randn(45, 2, 9, 11, Cc)
+    dy = G.randn(46, 2, 9, 11, Cc)
+    dz, cs = K.relu_bwd_colsum(y.cuda(), dy.cuda(), True)
+    ref = dy * (y > 0)
+    assert torch.equal(dz.cpu(), ref)
+    assert relerr(cs.cpu(), ref.sum((0, 1, 2))) < 1e-5
+    rd, db = G.randn(47, Cc), G.randn(48, Cc)
+    dg = K.bn_dgamma(rd.cuda(), db.cuda(), m.cuda(), v.cuda())
+    assert relerr(dg.cpu(), (rd - m * db) / torch.sqrt(v + 1e-5)) < 1e-5
+
+
+def test_groupnorm_relu_fwd_bwd(K):
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    N, Cc = 2, 256
+    A = sum(h * w for h, w in sizes)
+    c = G.randn(51, N, A, Cc, scale=2.0, shift=0.3)
+    gamma, beta = 0.5 + G.rand(52, Cc), G.randn(53, Cc, scale=0.3)
+    dy = G.randn(54, N, A, Cc)
+    y, mr = K.gn_relu_forward(c.cuda(), gamma.cuda(), beta.cuda(), sizes)
+    dc, dg, db = K.gn_relu_backward(c.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), mr, sizes)
+    off = 0
+    dg_ref, db_ref = torch.zeros(Cc), torch.zeros(Cc)
+    for (h, w) in sizes:
+        cl = c[:, off:off + h * w].reshape(N, h, w, Cc).permute(0, 3, 1, 2).clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        yl = F.relu(F.group_norm(cl, 32, gr, br, 1e-5))
+        yl.backward(dy[:, off:off + h * w].reshape(N, h, w, Cc).permute(0, 3, 1, 2))
+        flat = lambda t: t.permute(0, 2, 3, 1).reshape(N, h * w, Cc)
+        assert relerr(y[:, off:off + h * w].cpu(), flat(yl.detach())) < 1e-5
+        assert relerr(dc[:, off:off + h * w].cpu(), flat(cl.grad)) < 1e-4
+        dg_ref += gr.grad
+        db_ref += br.grad
+        off += h * w
+    assert relerr(dg.cpu(), dg_ref) < 1e-4 and relerr(db.cpu(), db_ref) < 1e-4
+
+
+def test_upsample_add_and_adjoint(K):
+    N, Cc = 2, 256
+    fine, coarse = G.randn(61, N, 10, 14, Cc), G.randn(62, N, 5, 7, Cc)
+    f = fine.cuda()
+    K.upsample_add_(f, coarse.cuda())
+    ref = fine.permute(0, 3, 1, 2) + F.interpolate(coarse.permute(0, 3, 1, 2), size=(10, 14), mode="nearest")
+    assert torch.allclose(to_nchw(f), ref)
+    dc = torch.zeros((N, 5, 7, Cc), device="cuda")
+    K.upsample_add_bwd_(fine.cuda(), dc)
+    cr = coarse.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.interpolate(cr, size=(10, 14), mode="nearest").backward(fine.permute(0, 3, 1, 2))
+    assert relerr(to_nchw(dc), cr.grad) < 1e-6
+
+
+def test_level_scale_colsum_sgd(K):
+    sizes = [(6, 7), (3, 4), (2, 2)]
+    A = sum(h * w for h, w in sizes)
+    x, dy = G.randn(71, 2, A, 68), G.randn(72, 2, A, 68)
+    al = torch.tensor([0.9, 1.1, 1.3])
+    y = K.level_scale(x.cuda(), al.cuda(), sizes)
+    dx, dal = K.level_scale_bwd(x.cuda(), dy.cuda(), al.cuda(), sizes)
+    off = 0
+    for i, (h, w) in enumerate(sizes):
+        sl = slice(off, off + h * w)
+        assert torch.allclose(y[:, sl].cpu(), x[:, sl] * al[i])
+        assert torch.allclose(dx[:, sl].cpu(), dy[:, sl] * al[i])
+        assert float(dal[i]) == pytest.approx(float((dy[:, sl] * x[:, sl]).sum()), rel=1e-4)
+        off += h * w
+    assert relerr(K.colsum(x.cuda()).cpu(), x.sum((0, 1))) < 1e-5
+    n = 4096 + 8
+    p, g = G.randn(73, n), G.randn(74, n)
+    pg, buf = p.cuda(), torch.zeros(n, device="cuda")
+    ref_p = [p.clone()]
+    opt = torch.optim.SGD(ref_p, lr=0.02, momentum=0.9, weight_decay=1e-4)
+    for it in range(3):
+        ref_p[0].grad = g.clone()
+        opt.step()
+        K.sgd_momentum_(pg, g.cuda(), buf, 0.02, 0.9, 1e-4, 1.0, it == 0)
+    assert relerr(pg.cpu(), ref_p[0]) < 1e-6
