@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the GFL-R50 40+40 ERD incremental training step at 1333x800 on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = teacher fwd + ERS + NMS + student fwd + the five loss groups + student backward + gradient mean over
+ranks (RCCL) + SGD update, on one synthetic batch already resident in HBM (BASELINE.json configs[1]: bs=4 per GPU,
+fp32, procedural weights).  Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured with HIP events
+on the launch stream over the timed region) and, at N=1, `cpu_baseline` (the oracle restatement timed on the host).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+H, W = 800, 1333
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = f32 vector rate
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_gpu_batch(bs: int, seed: int, device, num_new: int = 40):
+    """post-preprocess batch of the reference's demo_mm_inputs shape (mmdet/testing/_utils.py:89-202):
+    uint8 pixels -> (x-mean)/std -> zero pad to /32, 1..9 random boxes, labels in [0, C_new)."""
+    from oracle import erd_oracle as O
+    from erd_amd import DetDataSample, InstanceData
+    rng = np.random.RandomState(seed)
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    mean = torch.tensor(O.PIXEL_MEAN, device=device).view(1, 3, 1, 1)
+    std = torch.tensor(O.PIXEL_STD, device=device).view(1, 3, 1, 1)
+    x = torch.zeros((bs, 3, Hp, Wp), device=device)
+    samples = []
+    for i in range(bs):
+        img = torch.from_numpy(rng.randint(0, 255, size=(3, H, W), dtype=np.uint8)).to(device)
+        x[i, :, :H, :W] = (img[[2, 1, 0]].float() - mean[0]) / std[0]
+        nb = rng.randint(1, 10)
+        boxes = torch.from_numpy(O.rand_bboxes(rng, nb, W, H).astype(np.float32)).to(device)
+        labels = torch.from_numpy(rng.randint(0, num_new, size=nb).astype(np.int64)).to(device)
+        ds = DetDataSample(metainfo=dict(img_shape=(H, W), pad_shape=(Hp, Wp), batch_input_shape=(Hp, Wp)))
+        ds.gt_instances = InstanceData(bboxes=boxes, labels=labels)
+        samples.append(ds)
+    return x, samples
+
+
+def build_model(device, rank: int):
+    """through the reference's own boundary: config files + MODELS.build + teacher checkpoint on disk
+    (gfl_increment_erd.py:95-122).  Weights are procedural (no network for checkpoints)."""
+    from oracle import erd_oracle as O          # synthetic-weight spec only
+    from erd_amd import Config, MODELS
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "gfl_increment",
+                                       "gfl_r50_fpn_1x_coco_first_40_incre_last_40_cats.py"))
+    tsd = O.procedural_state_dict(40, seed=0)
+    ckpt = os.path.join(tempfile.gettempdir(), f"erd_teacher_first40_rank{rank}.pth")
+    torch.save(dict(state_dict=tsd), ckpt)
+    cfg.model.ori_setting.ori_checkpoint_file = ckpt
+    cfg.model.ori_setting.ori_config_file = os.path.join(ROOT, "configs", "gfl_increment",
+                                                         "gfl_r50_fpn_1x_coco_first_40_cats.py")
+    torch.manual_seed(1234)                      # the student's fresh new-class rows: same on every rank
+    model = MODELS.build(cfg.model)
+    os.remove(ckpt)
+    return model.to(device).train(), cfg
+
+
+def cpu_baseline(seconds_budget: float = 30.0):
+    """the oracle restatement (kind 'port') on the host cores: ONE image, one full ERD step at 800x1344."""
+    from oracle import erd_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    tsd = O.procedural_state_dict(40, seed=0)
+    ssd = O.student_state_from_teacher(tsd, 80, seed=1)
+    sd = {k: (v.clone().requires_grad_(True) if O.trainable(k) and v.dtype == torch.float32 else v)
+          for k, v in ssd.items()}
+    imgs, boxes, labels = O.synthetic_batch(1, H, W, 40, seed=0)
+    x, metas = O.preprocess(imgs)
+    t0 = time.time()
+    losses = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80)
+    O.parse_losses(losses).backward()
+    dt = time.time() - t0
+    return dict(value=round(1.0 / dt, 4), unit="images/sec", cores=ncores, kind="port",
+                sample="1 image 800x1344, 1 ERD step (teacher fwd+ERS+NMS+student fwd+losses+backward), "
+                       "oracle/erd_oracle.py on torch-CPU fp32, %.1f s" % dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[1]: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # 'nccl' == RCCL on ROCm
+
+    from erd_amd import kernels as K
+    from erd_amd.engine import ERDTrainer
+    model, cfg = build_model(device, rank)
+    opt = cfg.optim_wrapper.optimizer
+    trainer = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
+                         base_batch_size=cfg.auto_scale_lr.base_batch_size, batch_size_per_gpu=args.batch,
+                         auto_scale_lr=cfg.auto_scale_lr.enable)
+    batches = [synthetic_gpu_batch(args.batch, seed=rank * 1000 + i, device=device) for i in range(2)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log = None
+    for i in range(args.warmup):
+        log = trainer.train_step(*batches[i % len(batches)])
+    trainer.flush()
+    barrier()
+    if not args.no_kernel_timing:
+        K.timing_begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        log = trainer.train_step(*batches[i % len(batches)])
+    trainer.flush()                   # the deferred SGD of the last step belongs to the timed region
+    barrier()
+    dt = time.perf_counter() - t0
+    ktime = None if args.no_kernel_timing else K.timing_end()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss = float(log["loss"]) if log is not None else float("nan")
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec GFL-R50 40+40 incre step @1333x800",
+            "value": round(images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "gfl_r50_fpn first_40_incre_last_40 ERD (BASELINE configs[1]), 1333x800 padded to "
+                                   "800x1344, fp32, procedural weights", "batch_per_gpu": args.batch,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "loss": round(loss, 6),
+        }
+        if ktime:
+            dom = max(ktime.values(), key=lambda r: r["ms"])
+            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"],
+                               "achieved": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "traffic": None, "launches_per_step": dom["launches"] // args.steps,
+                               "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
+                               "gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3)}
+            out["kernels"] = {k: {"ms_per_step": round(r["ms"] / args.steps, 3),
+                                  "tflops": round(r["flop"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flop"] else None,
+                                  "launches_per_step": r["launches"] // args.steps} for k, r in ktime.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

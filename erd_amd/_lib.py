@@ -79,6 +79,7 @@ _SIGNATURES = {
     "erd_distill_nms": [P, P, P, P, P, i32, i64, i32, f32, P, P, P, C.c_size_t, P],
     "erd_kd_kl": [P, P, P, P, i32, i64, i32, i32, f32, P, P],
     "erd_kd_kl_bwd": [P, P, P, P, P, i32, i64, i32, i32, f32, P, P],
+    "erd_loss_avg": [P, i32, P, i32, P, P],
     "erd_loss_finalize": [P, P, P, P, P, i32, i32, i32, f32, f32, f32, f32, f32, P, P, P, P],
 }
 

@@ -874,8 +874,30 @@ extern "C" int erd_loss_finalize(const double* lvl_sums, const float* avg, const
                                  const int32_t* counts, int nlvl, int N, int c_old, float dist_loss_weight,
                                  float lw_cls, float lw_bbox, float lw_dfl, float lw_ld, const float* upstream,
                                  float* losses, float* coef, erd_stream_t stream) {
-    ERD_REQUIRE(lvl_sums && avg && l2_sums && kd_sums && counts && (losses || coef), "finalize: null");
+    ERD_REQUIRE(lvl_sums && avg && (N == 0 || (l2_sums && kd_sums && counts)) && (losses || coef), "finalize: null");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lvl_sums, avg, l2_sums, kd_sums,
                        counts, nlvl, N, c_old, dist_loss_weight, lw_cls, lw_bbox, lw_dfl, lw_ld, upstream, losses, coef);
     return erd::check_launch("loss_finalize");
+}
+
+namespace {
+// avg[0] = sum_n max(num_pos_n, 1) (sampling_result.py:96-100 summed, gfl_head.py:545-546);
+// avg[1] = sum_l sum weight_targets (gfl_head_increment_erd.py:405)
+__global__ void loss_avg_kernel(const int32_t* __restrict__ num_pos, int N, const double* __restrict__ lvl_sums,
+                                int nlvl, float* __restrict__ avg) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int t = 0;
+    for (int n = 0; n < N; ++n) t += num_pos[n] > 1 ? num_pos[n] : 1;
+    double w = 0;
+    for (int l = 0; l < nlvl; ++l) w += lvl_sums[l * 4 + 3];
+    avg[0] = (float)t;
+    avg[1] = (float)w;
+}
+}  // namespace
+
+extern "C" int erd_loss_avg(const int32_t* num_pos, int N, const double* lvl_sums, int nlvl, float* avg,
+                            erd_stream_t stream) {
+    ERD_REQUIRE(num_pos && lvl_sums && avg, "loss_avg: null");
+    hipLaunchKernelGGL(loss_avg_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, num_pos, N, lvl_sums, nlvl, avg);
+    return erd::check_launch("loss_avg");
 }

@@ -1,0 +1,170 @@
+"""Training-step engine for the ERD path: what mmengine's ``model.train_step`` / ``OptimWrapper`` /
+``MMDistributedDataParallel`` do around ``model(inputs, data_samples, mode='loss')``,
+re-designed for one process per MI355X:
+
+  * trainable parameters live in ONE flat fp32 buffer (and their gradients in another) so that the
+    SGD(momentum, weight-decay) update is a single HIP launch and the data-parallel gradient mean is a
+    handful of large RCCL all-reduces on contiguous bucket slices -- no flatten/unflatten copies;
+  * buckets are laid out in *backward* order (head -> neck -> layer4 -> layer2) and each bucket's
+    all-reduce is issued from a post-accumulate hook as soon as its last gradient lands, i.e. it rides
+    over xGMI while the rest of the backward is still computing;
+  * the optimizer step of iteration t is deferred to the start of iteration t+1, behind the (frozen)
+    teacher's forward of batch t+1 which runs on a side HIP stream -- the teacher never depends on the
+    update, so the tail of the all-reduce and the SGD launch hide under it (north_star).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import kernels as K
+from .modules import GFLIncrementERD, parse_losses
+
+Tensor = torch.Tensor
+ALIGN = 64  # floats: every parameter starts on a 256-B boundary (kernels read weights as float4)
+
+
+def _storage_view(flat: Tensor, off: int, p: Tensor) -> Tensor:
+    """a view of flat[off:off+numel] with p's logical shape AND p's physical (dense) layout."""
+    n = p.numel()
+    if p.dim() == 4:
+        O, I, kh, kw = p.shape
+        v = p.detach().permute(0, 2, 3, 1)
+        if v.is_contiguous():      # channels_last parameter: keep [O][kh][kw][I]
+            return flat[off:off + n].view(O, kh, kw, I).permute(0, 3, 1, 2)
+    return flat[off:off + n].view(p.shape)
+
+
+class FlatParams:
+    def __init__(self, named_params: Sequence, device, bucket_bytes: int = 32 << 20):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.offsets, self.total = offs, total
+        self.data = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.momentum = torch.zeros(total, dtype=torch.float32, device=device)
+        for p, off in zip(self.params, offs):
+            v = _storage_view(self.data, off, p)
+            v.copy_(p.detach())
+            p.data = v
+            p.grad = _storage_view(self.grad, off, p)
+        # buckets over the flat range, in layout order (= backward order)
+        self.buckets: List[tuple] = []
+        start, members = 0, []
+        for i, (p, off) in enumerate(zip(self.params, offs)):
+            members.append(i)
+            end = off + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            if (end - start) * 4 >= bucket_bytes or i == len(self.params) - 1:
+                self.buckets.append((start, end, members))
+                start, members = end, []
+        self.bucket_of = {}
+        for b, (_, _, mem) in enumerate(self.buckets):
+            for i in mem:
+                self.bucket_of[i] = b
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+
+class ERDTrainer:
+    """One optimisation step of the ERD incremental detector per call (teacher fwd -> ERS -> student fwd ->
+    losses -> backward -> gradient mean over ranks -> SGD)."""
+
+    def __init__(self, model: nn.Module, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 1e-4,
+                 base_batch_size: int = 16, batch_size_per_gpu: Optional[int] = None, auto_scale_lr: bool = True,
+                 warmup_iters: int = 500, warmup_start_factor: float = 0.001, bucket_mb: int = 32,
+                 overlap_teacher: bool = True):
+        self.model = model
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.distributed else 1
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("ERDTrainer needs the model on the GPU (erd_amd has no CPU path)")
+        self.device = dev
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith("ori_model.")]
+        named.reverse()                      # backward order: head first, layer2 last
+        self.flat = FlatParams(named, dev, bucket_mb << 20)
+        self.base_lr = lr * (self.world * batch_size_per_gpu / base_batch_size
+                             if (auto_scale_lr and batch_size_per_gpu) else 1.0)   # auto_scale_lr (config :116)
+        self.momentum, self.weight_decay = momentum, weight_decay
+        self.warmup_iters, self.warmup_start = warmup_iters, warmup_start_factor
+        self.iter = 0
+        self._first = True
+        self._pending = False                # an un-applied gradient sits in flat.grad
+        self._works: List = []
+        self._remaining: List[int] = []
+        self.is_erd = isinstance(model, GFLIncrementERD)
+        self.overlap_teacher = overlap_teacher and self.is_erd
+        self.side = torch.cuda.Stream(device=dev) if self.overlap_teacher else None
+        if self.distributed:
+            for i, p in enumerate(self.flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    # -- schedule (schedule_1x.py:7-17: LinearLR warm-up; MultiStep handled by the caller per epoch) ------------
+    def lr_at(self, it: int, epoch_factor: float = 1.0) -> float:
+        f = 1.0
+        if it < self.warmup_iters:
+            f = self.warmup_start + (1.0 - self.warmup_start) * it / max(self.warmup_iters - 1, 1)
+        return self.base_lr * f * epoch_factor
+
+    # -- gradient buckets --------------------------------------------------------------------------------------------
+    def _make_hook(self, i: int):
+        def hook(_p):
+            b = self.flat.bucket_of[i]
+            self._remaining[b] -= 1
+            if self._remaining[b] == 0:
+                s, e, _ = self.flat.buckets[b]
+                self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    def _apply_pending(self) -> None:
+        """wait for the bucket all-reduces of the previous backward, then ONE fused SGD launch."""
+        if not self._pending:
+            return
+        for w in self._works:
+            w.wait()
+        self._works = []
+        K.sgd_momentum_(self.flat.data, self.flat.grad, self.flat.momentum, self.lr_at(self.iter - 1), self.momentum,
+                        self.weight_decay, 1.0 / self.world, self._first)
+        self._first = False
+        self._pending = False
+
+    def flush(self) -> None:
+        self._apply_pending()
+
+    # -- the step ------------------------------------------------------------------------------------------------------
+    def train_step(self, inputs: Tensor, data_samples) -> Dict[str, Tensor]:
+        model = self.model
+        cur = torch.cuda.current_stream(self.device)
+        teacher_out = None
+        if self.overlap_teacher:
+            # teacher forward of THIS batch on the side stream, concurrent with the tail of the previous
+            # step's all-reduce + SGD on the main stream
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side), torch.no_grad():
+                teacher_out = model.teacher_pass(inputs)
+        self._apply_pending()
+        self.flat.zero_grad()
+        if self.overlap_teacher:
+            cur.wait_stream(self.side)
+            for t in teacher_out.tensors():
+                t.record_stream(cur)
+            losses = model.loss(inputs, data_samples, teacher_out=teacher_out)
+        else:
+            losses = model(inputs, data_samples, mode="loss")
+        total, log_vars = parse_losses(losses)
+        self._remaining = [len(m) for (_, _, m) in self.flat.buckets]
+        total.backward()
+        self._pending = True
+        self.iter += 1
+        if not self.overlap_teacher:
+            self._apply_pending()
+        return log_vars

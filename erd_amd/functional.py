@@ -1,0 +1,321 @@
+"""Differentiable building blocks of the ERD step.  Each ``torch.autograd.Function`` is a fused group of
+HIP launches (through ``erd_amd.kernels`` -> C ABI) and implements its own backward with the hand-written
+dgrad / wgrad / norm-backward kernels; torch autograd only sequences them (plumbing).
+
+Maps are NHWC fp32 ``[N,H,W,C]``; the head works on level-concatenated ``[N,A,C]`` buffers whose per-level
+views are maps.  Weights are ``nn.Parameter``s of logical shape OIHW in channels_last memory, i.e.
+``[Cout][kh][kw][Cin]`` as the kernels want them (checkpoint ABI = the reference's OIHW keys/shapes)."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+Tensor = torch.Tensor
+
+
+def ohwi(w: Tensor) -> Tensor:
+    """OIHW parameter -> [O,H,W,I] contiguous view (copy only if the parameter is not channels_last)."""
+    v = w.detach().permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _to_oihw(dw_ohwi: Tensor) -> Tensor:
+    return dw_ohwi.permute(0, 3, 1, 2)
+
+
+class ConvBNAct(Function):
+    """y = [relu]( conv(x, w) * scale + shift [+ res] ) with scale/shift folded from a frozen-statistics BN
+    (resnet.py:263-302 Bottleneck; norm_eval=True resnet.py:648-657).  gamma/beta still receive gradients
+    (d gamma through the <W, G> identity, see erd_hip.h erd_wgrad_reduce)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, mean, var, res, k: int, stride: int, pad: int, relu: bool, eps: float):
+        wk = ohwi(w)
+        scale, shift = K.bn_fold(gamma.detach(), beta.detach(), mean, var, eps)
+        N, H, W_, _ = x.shape
+        OH, OW = K.conv_out_size(H, k, stride, pad), K.conv_out_size(W_, k, stride, pad)
+        out = torch.empty((N, OH, OW, wk.shape[0]), dtype=torch.float32, device=x.device)
+        K.conv_forward([x], wk, [out], k, stride, pad, scale=scale, shift=shift,
+                       res=None if res is None else [res], relu=relu)
+        ctx.cfg = (k, stride, pad, relu, eps, res is not None)
+        ctx.save_for_backward(x, w, mean, var, scale, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, var, scale, out = ctx.saved_tensors
+        k, stride, pad, relu, eps, has_res = ctx.cfg
+        need_x, need_w, need_g, need_b = ctx.needs_input_grad[0:4]
+        dy = dy.contiguous()
+        dz, dbeta = K.relu_bwd_colsum(out if relu else None, dy, relu, want_colsum=need_g or need_b)
+        wk = ohwi(w)
+        dW = dgamma = None
+        if need_w or need_g:
+            part, S = K.conv_wgrad_partials([x], [dz], k, stride, pad)
+            dWk = torch.empty_like(wk)
+            rowdot = torch.empty_like(scale) if need_g else None
+            K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
+            dW = _to_oihw(dWk)
+            if need_g:
+                dgamma = K.bn_dgamma(rowdot, dbeta, mean, var, eps)
+        dx = None
+        if need_x:
+            wt = K.weight_transpose(wk, scale)
+            # a strided 1x1 (projection shortcut) reaches only the even pixels: the rest of dx is zero
+            dx = torch.zeros_like(x) if k < stride else torch.empty_like(x)
+            K.conv_dgrad([dz], wt, [dx], k, stride, pad)
+        dres = dz if (has_res and ctx.needs_input_grad[6]) else None
+        return dx, dW, dgamma, (dbeta if need_b else None), None, None, dres, None, None, None, None, None
+
+
+class ConvBias(Function):
+    """y = conv(x, w) + b on one map (FPN laterals, fpn.py:177-179)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k: int, stride: int, pad: int):
+        wk = ohwi(w)
+        N, H, W_, _ = x.shape
+        OH, OW = K.conv_out_size(H, k, stride, pad), K.conv_out_size(W_, k, stride, pad)
+        out = torch.empty((N, OH, OW, wk.shape[0]), dtype=torch.float32, device=x.device)
+        K.conv_forward([x], wk, [out], k, stride, pad, shift=b.detach())
+        ctx.cfg = (k, stride, pad)
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k, stride, pad = ctx.cfg
+        dy = dy.contiguous()
+        wk = ohwi(w)
+        dW = db = dx = None
+        if ctx.needs_input_grad[1]:
+            part, S = K.conv_wgrad_partials([x], [dy], k, stride, pad)
+            dWk = torch.empty_like(wk)
+            K.wgrad_reduce(part, S, wk, None, dWk, False, None)
+            dW = _to_oihw(dWk)
+        if ctx.needs_input_grad[2]:
+            db = K.colsum(dy)
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x) if k < stride else torch.empty_like(x)
+            K.conv_dgrad([dy], K.weight_transpose(wk), [dx], k, stride, pad)
+        return dx, dW, db, None, None, None
+
+
+class UpsampleAdd(Function):
+    """fine += nearest_upsample(coarse) in place (fpn.py:181-191)."""
+
+    @staticmethod
+    def forward(ctx, fine, coarse):
+        ctx.mark_dirty(fine)
+        K.upsample_add_(fine, coarse)
+        ctx.cshape = coarse.shape
+        return fine
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dcoarse = None
+        if ctx.needs_input_grad[1]:
+            dcoarse = torch.zeros(ctx.cshape, dtype=torch.float32, device=dout.device)
+            K.upsample_add_bwd_(dout, dcoarse)
+        return dout, dcoarse
+
+
+class FPNOutputs(Function):
+    """The five FPN output convs (3x3 on the three merged laterals, then P6 = 3x3/2 on P5's OUTPUT and
+    P7 = 3x3/2 on P6, no activation: fpn.py:195-220) writing straight into one level-concatenated
+    [N,A,256] buffer -- the layout the head, ERS and the losses consume (K10 "free" permute+cat)."""
+
+    @staticmethod
+    def forward(ctx, l3, l4, l5, w0, w1, w2, w3, w4, b0, b1, b2, b3, b4):
+        lats = [l3, l4, l5]
+        ws = [w0, w1, w2, w3, w4]
+        bs = [b0, b1, b2, b3, b4]
+        N = l3.shape[0]
+        sizes = [(l.shape[1], l.shape[2]) for l in lats]
+        h, w_ = sizes[-1]
+        for _ in range(2):
+            h, w_ = K.conv_out_size(h, 3, 2, 1), K.conv_out_size(w_, 3, 2, 1)
+            sizes.append((h, w_))
+        A = sum(a * b for a, b in sizes)
+        Cc = w0.shape[0]
+        cat = torch.empty((N, A, Cc), dtype=torch.float32, device=l3.device)
+        views = K.level_views(cat, sizes)
+        for i in range(3):
+            K.conv_forward([lats[i]], ohwi(ws[i]), [views[i]], 3, 1, 1, shift=bs[i].detach())
+        K.conv_forward([views[2]], ohwi(ws[3]), [views[3]], 3, 2, 1, shift=bs[3].detach())
+        K.conv_forward([views[3]], ohwi(ws[4]), [views[4]], 3, 2, 1, shift=bs[4].detach())
+        ctx.sizes = sizes
+        ctx.save_for_backward(l3, l4, l5, cat, *ws)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        l3, l4, l5, cat, *ws = ctx.saved_tensors
+        sizes = ctx.sizes
+        lats = [l3, l4, l5]
+        dcat = dcat.contiguous().clone()      # P5/P6 slices accumulate the extra-level input gradients
+        dv = K.level_views(dcat, sizes)
+        pv = K.level_views(cat, sizes)
+        grads_w: List[Optional[Tensor]] = [None] * 5
+        grads_b: List[Optional[Tensor]] = [None] * 5
+
+        def wgrad(i, xin, dz, stride):
+            wk = ohwi(ws[i])
+            if ctx.needs_input_grad[3 + i]:
+                part, S = K.conv_wgrad_partials([xin], [dz], 3, stride, 1)
+                dWk = torch.empty_like(wk)
+                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
+                grads_w[i] = _to_oihw(dWk)
+            if ctx.needs_input_grad[8 + i]:
+                grads_b[i] = K.relu_bwd_colsum(None, dz, False)[1]
+            return wk
+
+        # P7 <- P6 output ; P6 <- P5 output (input grads accumulate into the producer's slice)
+        wk = wgrad(4, pv[3], dv[4], 2)
+        K.conv_dgrad([dv[4]], K.weight_transpose(wk), [dv[3]], 3, 2, 1, accumulate=True)
+        wk = wgrad(3, pv[2], dv[3], 2)
+        K.conv_dgrad([dv[3]], K.weight_transpose(wk), [dv[2]], 3, 2, 1, accumulate=True)
+        dl: List[Optional[Tensor]] = [None, None, None]
+        for i in range(3):
+            wk = wgrad(i, lats[i], dv[i], 1)
+            if ctx.needs_input_grad[i]:
+                dl[i] = torch.empty_like(lats[i])
+                K.conv_dgrad([dv[i]], K.weight_transpose(wk), [dl[i]], 3, 1, 1)
+        return (dl[0], dl[1], dl[2], *grads_w, *grads_b)
+
+
+class HeadConvGN(Function):
+    """One tower layer of the GFL head on all five levels at once (weights shared across levels,
+    gfl_head.py:156-177,219-223): conv3x3 (no bias) -> GroupNorm(32) -> ReLU."""
+
+    @staticmethod
+    def forward(ctx, x_cat, w, gamma, beta, sizes, eps: float):
+        wk = ohwi(w)
+        c = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=torch.float32, device=x_cat.device)
+        K.conv_forward(K.level_views(x_cat, sizes), wk, K.level_views(c, sizes), 3, 1, 1)
+        y, mr = K.gn_relu_forward(c, gamma.detach(), beta.detach(), sizes, 32, eps)
+        ctx.sizes = sizes
+        ctx.save_for_backward(x_cat, w, gamma, beta, c, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cat, w, gamma, beta, c, mr = ctx.saved_tensors
+        sizes = ctx.sizes
+        dc, dgamma, dbeta = K.gn_relu_backward(c, dy.contiguous(), gamma.detach(), beta.detach(), mr, sizes, 32)
+        wk = ohwi(w)
+        dW = dx = None
+        xv, dv = K.level_views(x_cat, sizes), K.level_views(dc, sizes)
+        if ctx.needs_input_grad[1]:
+            part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
+            dWk = torch.empty_like(wk)
+            K.wgrad_reduce(part, S, wk, None, dWk, False, None)
+            dW = _to_oihw(dWk)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x_cat)
+            K.conv_dgrad(dv, K.weight_transpose(wk), K.level_views(dx, sizes), 3, 1, 1)
+        return dx, dW, dgamma, dbeta, None, None
+
+
+class HeadConvBias(Function):
+    """gfl_cls / gfl_reg: conv3x3 + bias on all levels into a [N,A,Cout] buffer (gfl_head.py:224-229)."""
+
+    @staticmethod
+    def forward(ctx, x_cat, w, b, sizes):
+        wk = ohwi(w)
+        out = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=torch.float32, device=x_cat.device)
+        K.conv_forward(K.level_views(x_cat, sizes), wk, K.level_views(out, sizes), 3, 1, 1, shift=b.detach())
+        ctx.sizes = sizes
+        ctx.save_for_backward(x_cat, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cat, w = ctx.saved_tensors
+        sizes = ctx.sizes
+        dy = dy.contiguous()
+        wk = ohwi(w)
+        dW = db = dx = None
+        xv, dv = K.level_views(x_cat, sizes), K.level_views(dy, sizes)
+        if ctx.needs_input_grad[1]:
+            part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
+            dWk = torch.empty_like(wk)
+            K.wgrad_reduce(part, S, wk, None, dWk, False, None)
+            dW = _to_oihw(dWk)
+        if ctx.needs_input_grad[2]:
+            db = K.colsum(dy)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x_cat)
+            K.conv_dgrad(dv, K.weight_transpose(wk), K.level_views(dx, sizes), 3, 1, 1)
+        return dx, dW, db, None
+
+
+class LevelScale(Function):
+    """bbox_pred_l = Scale_l(gfl_reg(.)) -- one learnable scalar per level (gfl_head.py:184,229)."""
+
+    @staticmethod
+    def forward(ctx, x_cat, alphas, sizes):
+        y = K.level_scale(x_cat, alphas.detach().contiguous(), sizes)
+        ctx.sizes = sizes
+        ctx.save_for_backward(x_cat, alphas)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cat, alphas = ctx.saved_tensors
+        dx, dal = K.level_scale_bwd(x_cat, dy.contiguous(), alphas.detach().contiguous(), ctx.sizes)
+        return dx, dal, None
+
+
+class ERDLossFn(Function):
+    """All loss entries of the step as ONE vector
+        [loss_cls(L) | loss_bbox(L) | loss_dfl(L) | loss_dist_cls(N) | loss_dist_bbox(N)]
+    (gfl_head_increment_erd.py:334-454).  `t` carries the no-grad side: targets, teacher outputs, ERS lists,
+    NMS keep mask (None for the plain GFL head loss)."""
+
+    @staticmethod
+    def forward(ctx, s_cls, s_bbox, t):
+        N, A, c_all = s_cls.shape
+        L = len(t.sizes)
+        score, wt, sums = K.gfl_losses_fwd(s_cls, s_bbox, t.anchors, t.labels, t.label_weights, t.bbox_targets,
+                                           t.sizes, t.strides, t.c_old, c_all)
+        avg = K.loss_avg(t.num_pos, sums)
+        if t.world_size > 1:       # reduce_mean x2 (dist_utils.py:59-65) fused into one 2-float all-reduce
+            import torch.distributed as dist
+            avg.div_(t.world_size)
+            dist.all_reduce(avg, op=dist.ReduceOp.SUM)
+        l2s = kds = None
+        nd = 0
+        if t.distill:
+            nd = N
+            l2s = K.l2_distill(s_cls, t.t_cls, t.ers["idx_cls"], t.ers["counts"], t.c_old)
+            kds = K.kd_kl(s_bbox, t.t_bbox, s_cls, t.keep, t.c_old, t.T)
+        losses, _ = K.loss_finalize(sums, avg, l2s, kds, t.ers["counts"] if t.distill else None, L, nd, t.c_old,
+                                    t.dist_loss_weight, t.lw_cls, t.lw_bbox, t.lw_dfl, t.lw_ld, None, True, False)
+        ctx.t = t
+        ctx.nd = nd
+        ctx.save_for_backward(s_cls, s_bbox, score, wt, sums, avg, l2s if l2s is not None else sums,
+                              kds if kds is not None else sums)
+        return losses
+
+    @staticmethod
+    def backward(ctx, dlosses):
+        s_cls, s_bbox, score, wt, sums, avg, l2s, kds = ctx.saved_tensors
+        t, nd = ctx.t, ctx.nd
+        N, A, c_all = s_cls.shape
+        L = len(t.sizes)
+        _, coef = K.loss_finalize(sums, avg, l2s if nd else None, kds if nd else None,
+                                  t.ers["counts"] if nd else None, L, nd, t.c_old, t.dist_loss_weight, t.lw_cls,
+                                  t.lw_bbox, t.lw_dfl, t.lw_ld, dlosses.contiguous(), False, True)
+        dcls, dbbox = K.gfl_losses_bwd(s_cls, s_bbox, t.anchors, t.labels, t.label_weights, t.bbox_targets, t.sizes,
+                                       t.strides, t.c_old, c_all, score, wt, coef)
+        if nd:
+            K.l2_distill_bwd_(s_cls, t.t_cls, t.ers["idx_cls"], t.ers["counts"], coef[4 * L:], t.c_old, dcls)
+            K.kd_kl_bwd_(s_bbox, t.t_bbox, s_cls, t.keep, coef[4 * L + N:], t.c_old, t.T, dbbox)
+        return dcls, dbbox, None

@@ -29,6 +29,41 @@ def _require_gpu(*ts: Tensor) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
+# optional per-launch timing of the GEMM-shaped kernels with HIP events recorded on the launch stream
+# (bench.py roofline leg).  Off by default: zero overhead in normal runs.
+# ---------------------------------------------------------------------------------------------
+_TIMING = None
+
+
+def timing_begin() -> None:
+    global _TIMING
+    _TIMING = {}
+
+
+def timing_end():
+    """-> {kernel: dict(kernel, ms, flop, launches)} summed over every launch since timing_begin()."""
+    global _TIMING
+    rec, _TIMING = _TIMING, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in (rec or {}).items():
+        ms = sum(s.elapsed_time(e) for s, e, _ in evs)
+        out[name] = dict(kernel=name, ms=ms, flop=float(sum(f for _, _, f in evs)), launches=len(evs))
+    return out
+
+
+def _timed_call(kname: str, flop: float, cname: str, *args) -> None:
+    if _TIMING is None:
+        call(cname, *args)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    call(cname, *args)
+    e.record()
+    _TIMING.setdefault(kname, []).append((s, e, flop))
+
+
+# ---------------------------------------------------------------------------------------------
 # workspace cache: one growing buffer per (name, device, stream) -- stream-ordered reuse is safe
 # ---------------------------------------------------------------------------------------------
 _WS = {}
@@ -131,7 +166,8 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     d.scale = 0 if scale is None else scale.data_ptr()
     d.shift = 0 if shift is None else shift.data_ptr()
     d.relu = 1 if relu else 0
-    call("erd_conv_igemm", C.byref(d), _stream())
+    flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
+    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream())
 
 
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
@@ -183,7 +219,8 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.scale = 0
         d.shift = 0
         d.relu = 0
-        call("erd_conv_igemm", C.byref(d), _stream())
+        flop = 2.0 * sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg)) * Cin * len(taps) * Cout
+        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream())
 
 
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
@@ -217,7 +254,8 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
         d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
         d.part = part.data_ptr() + off * slab * 4
         d.nsplit = ns
-        call("erd_conv_wgrad", C.byref(d), _stream())
+        flop = 2.0 * dz.shape[0] * dz.shape[1] * dz.shape[2] * Cout * Cin * k * k
+        _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream())
         off += ns
     return part, S
 
@@ -478,3 +516,9 @@ def loss_finalize(lvl_sums, avg, l2_sums, kd_sums, counts, nlvl, N, c_old, w_dis
          float(w_dist), float(lw_cls), float(lw_bbox), float(lw_dfl), float(lw_ld), _p(upstream), _p(losses), _p(coef),
          _stream())
     return losses, coef
+
+
+def loss_avg(num_pos: Tensor, lvl_sums: Tensor) -> Tensor:
+    avg = torch.empty((2,), dtype=torch.float32, device=lvl_sums.device)
+    call("erd_loss_avg", _p(num_pos), num_pos.numel(), _p(lvl_sums), lvl_sums.shape[0], _p(avg), _stream())
+    return avg

@@ -212,6 +212,11 @@ int erd_loss_finalize(const double* lvl_sums, const float* avg, const double* l2
                       float lw_cls, float lw_bbox, float lw_dfl, float lw_ld, const float* upstream,
                       float* losses, float* coef, erd_stream_t stream);
 
+/* avg[0] = sum_n max(num_pos[n],1), avg[1] = sum_l lvl_sums[l][3]  (the two normalisers that
+ * reduce_mean all-reduces: gfl_head_increment_erd.py:390-391,405-407) */
+int erd_loss_avg(const int32_t* num_pos, int N, const double* lvl_sums, int nlvl, float* avg,
+                 erd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

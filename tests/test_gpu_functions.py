@@ -1,0 +1,139 @@
+"""GPU: each autograd.Function of erd_amd.functional (a fused group of HIP launches with a hand-written
+backward) against torch-CPU autograd of the same composite op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import golden_inputs as G
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def cl_weight(w):     # OIHW cpu -> channels_last parameter on the GPU
+    return w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+
+CBA = [
+    # N,H,W,Cin,Cout,k,s,res,relu
+    (2, 8, 10, 1024, 256, 1, 1, False, True),
+    (2, 8, 10, 256, 256, 3, 1, False, True),
+    (2, 8, 10, 256, 1024, 1, 1, True, True),
+    (2, 8, 10, 1024, 2048, 1, 2, False, False),
+    (2, 16, 20, 128, 128, 3, 2, False, True),
+    (2, 7, 9, 512, 512, 3, 2, False, True),
+    (2, 16, 20, 512, 128, 1, 1, False, True),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,res,relu", CBA)
+def test_conv_bn_act(N, H, W, Cin, Cout, k, s, res, relu):
+    from erd_amd import functional as Fn
+    p = k // 2
+    x = G.randn(1, N, Cin, H, W).requires_grad_(True)
+    w = G.randn(2, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5).requires_grad_(True)
+    gamma = (0.5 + G.rand(3, Cout)).requires_grad_(True)
+    beta = G.randn(4, Cout, scale=0.2).requires_grad_(True)
+    mean, var = G.randn(5, Cout, scale=0.2), 0.5 + G.rand(6, Cout)
+    y = F.batch_norm(F.conv2d(x, w, None, s, p), mean, var, gamma, beta, False, 0.0, 1e-5)
+    r = None
+    if res:
+        r = G.randn(7, *y.shape).requires_grad_(True)
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    dy = G.randn(8, *y.shape)
+    y.backward(dy)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    wg = cl_weight(w.detach())
+    gg, bg = gamma.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
+    rg = r.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True) if res else None
+    out = Fn.ConvBNAct.apply(xg, wg, gg, bg, mean.cuda(), var.cuda(), rg, k, s, p, relu, 1e-5)
+    assert relerr(out.detach().permute(0, 3, 1, 2).cpu(), y.detach()) < 2e-5
+    out.backward(dy.permute(0, 2, 3, 1).contiguous().cuda())
+    assert relerr(xg.grad.permute(0, 3, 1, 2).cpu(), x.grad) < 5e-5
+    assert relerr(wg.grad.cpu(), w.grad) < 5e-5
+    assert relerr(gg.grad.cpu(), gamma.grad) < 2e-4
+    assert relerr(bg.grad.cpu(), beta.grad) < 5e-5
+    if res:
+        assert relerr(rg.grad.permute(0, 3, 1, 2).cpu(), r.grad) < 1e-6
+
+
+def test_fpn_functions():
+    from erd_amd import functional as Fn
+    N = 2
+    shapes = [(16, 20), (8, 10), (4, 5)]
+    chans = [512, 1024, 2048]
+    cs = [G.randn(10 + i, N, c, h, w).requires_grad_(True) for i, (c, (h, w)) in enumerate(zip(chans, shapes))]
+    lw = [G.randn(20 + i, 256, c, 1, 1, scale=(1.0 / c) ** 0.5).requires_grad_(True) for i, c in enumerate(chans)]
+    lb = [G.randn(30 + i, 256, scale=0.1).requires_grad_(True) for i in range(3)]
+    fw = [G.randn(40 + i, 256, 256, 3, 3, scale=(1.0 / 2304) ** 0.5).requires_grad_(True) for i in range(5)]
+    fb = [G.randn(50 + i, 256, scale=0.1).requires_grad_(True) for i in range(5)]
+    lats = [F.conv2d(cs[i], lw[i], lb[i]) for i in range(3)]
+    for i in range(2, 0, -1):
+        lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode="nearest")
+    outs = [F.conv2d(lats[i], fw[i], fb[i], 1, 1) for i in range(3)]
+    outs.append(F.conv2d(outs[-1], fw[3], fb[3], 2, 1))
+    outs.append(F.conv2d(outs[-1], fw[4], fb[4], 2, 1))
+    ref_cat = torch.cat([o.permute(0, 2, 3, 1).reshape(N, -1, 256) for o in outs], 1)
+    dcat = G.randn(60, *ref_cat.shape)
+    ref_cat.backward(dcat)
+    csg = [c.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True) for c in cs]
+    lwg = [cl_weight(w.detach()) for w in lw]
+    lbg = [b.detach().cuda().requires_grad_(True) for b in lb]
+    fwg = [cl_weight(w.detach()) for w in fw]
+    fbg = [b.detach().cuda().requires_grad_(True) for b in fb]
+    l = [Fn.ConvBias.apply(csg[i], lwg[i], lbg[i], 1, 1, 0) for i in range(3)]
+    for i in range(2, 0, -1):
+        l[i - 1] = Fn.UpsampleAdd.apply(l[i - 1], l[i])
+    cat = Fn.FPNOutputs.apply(l[0], l[1], l[2], *fwg, *fbg)
+    assert relerr(cat.detach().cpu(), ref_cat.detach()) < 2e-5
+    cat.backward(dcat.cuda())
+    for i in range(3):
+        assert relerr(csg[i].grad.permute(0, 3, 1, 2).cpu(), cs[i].grad) < 5e-5, i
+        assert relerr(lwg[i].grad.cpu(), lw[i].grad) < 5e-5, i
+        assert relerr(lbg[i].grad.cpu(), lb[i].grad) < 5e-5, i
+    for i in range(5):
+        assert relerr(fwg[i].grad.cpu(), fw[i].grad) < 5e-5, i
+        assert relerr(fbg[i].grad.cpu(), fb[i].grad) < 5e-5, i
+
+
+def test_head_functions():
+    from erd_amd import functional as Fn
+    N = 2
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(70, N, A, 256).requires_grad_(True)
+    w1 = G.randn(71, 256, 256, 3, 3, scale=(2.0 / 2304) ** 0.5).requires_grad_(True)
+    g1, b1 = (0.5 + G.rand(72, 256)).requires_grad_(True), G.randn(73, 256, scale=0.2).requires_grad_(True)
+    w2 = G.randn(74, 80, 256, 3, 3, scale=(1.0 / 2304) ** 0.5).requires_grad_(True)
+    b2 = G.randn(75, 80, scale=0.1).requires_grad_(True)
+    al = torch.tensor([0.9, 1.0, 1.1, 1.2, 1.3]).requires_grad_(True)
+    outs = []
+    off = 0
+    for l, (h, w) in enumerate(sizes):
+        xl = x[:, off:off + h * w].reshape(N, h, w, 256).permute(0, 3, 1, 2)
+        y = F.relu(F.group_norm(F.conv2d(xl, w1, None, 1, 1), 32, g1, b1, 1e-5))
+        o = F.conv2d(y, w2, b2, 1, 1) * al[l]
+        outs.append(o.permute(0, 2, 3, 1).reshape(N, h * w, 80))
+        off += h * w
+    ref = torch.cat(outs, 1)
+    dy = G.randn(76, *ref.shape)
+    ref.backward(dy)
+    xg = x.detach().cuda().requires_grad_(True)
+    w1g, w2g = cl_weight(w1.detach()), cl_weight(w2.detach())
+    g1g, b1g = g1.detach().cuda().requires_grad_(True), b1.detach().cuda().requires_grad_(True)
+    b2g, alg = b2.detach().cuda().requires_grad_(True), al.detach().cuda().requires_grad_(True)
+    y = Fn.HeadConvGN.apply(xg, w1g, g1g, b1g, sizes, 1e-5)
+    pre = Fn.HeadConvBias.apply(y, w2g, b2g, sizes)
+    out = Fn.LevelScale.apply(pre, alg, sizes)
+    assert relerr(out.detach().cpu(), ref.detach()) < 2e-5
+    out.backward(dy.cuda())
+    assert relerr(xg.grad.cpu(), x.grad) < 1e-4
+    assert relerr(w1g.grad.cpu(), w1.grad) < 1e-4
+    assert relerr(g1g.grad.cpu(), g1.grad) < 2e-4 and relerr(b1g.grad.cpu(), b1.grad) < 2e-4
+    assert relerr(w2g.grad.cpu(), w2.grad) < 1e-4 and relerr(b2g.grad.cpu(), b2.grad) < 1e-4
+    assert relerr(alg.grad.cpu(), al.grad) < 1e-4
