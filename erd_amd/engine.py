@@ -74,6 +74,41 @@ class FlatParams:
         self.grad.zero_()
 
 
+class BucketedGradSync:
+    """Data-parallel gradient SUM over ranks on the flat gradient buffer: one async all-reduce per bucket, issued
+    from a post-accumulate-grad hook when the bucket's last gradient has landed (so it overlaps the rest of the
+    backward).  Device-agnostic (RCCL on GPUs, gloo in the CPU tests); the 1/world scaling is folded into the SGD
+    kernel's `grad_scale`."""
+
+    def __init__(self, flat: FlatParams):
+        self.flat = flat
+        self._works: List = []
+        self._remaining: List[int] = []
+        for i, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def arm(self) -> None:
+        self._remaining = [len(m) for (_, _, m) in self.flat.buckets]
+        self._works = []
+
+    def _make_hook(self, i: int):
+        def hook(_p):
+            if not self._remaining:
+                return
+            b = self.flat.bucket_of[i]
+            self._remaining[b] -= 1
+            if self._remaining[b] == 0:
+                s, e, _ = self.flat.buckets[b]
+                self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    def wait(self) -> None:
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._remaining = []
+
+
 class ERDTrainer:
     """One optimisation step of the ERD incremental detector per call (teacher fwd -> ERS -> student fwd ->
     losses -> backward -> gradient mean over ranks -> SGD)."""
@@ -99,14 +134,10 @@ class ERDTrainer:
         self.iter = 0
         self._first = True
         self._pending = False                # an un-applied gradient sits in flat.grad
-        self._works: List = []
-        self._remaining: List[int] = []
+        self.sync = BucketedGradSync(self.flat) if self.distributed else None
         self.is_erd = isinstance(model, GFLIncrementERD)
         self.overlap_teacher = overlap_teacher and self.is_erd
         self.side = torch.cuda.Stream(device=dev) if self.overlap_teacher else None
-        if self.distributed:
-            for i, p in enumerate(self.flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     # -- schedule (schedule_1x.py:7-17: LinearLR warm-up; MultiStep handled by the caller per epoch) ------------
     def lr_at(self, it: int, epoch_factor: float = 1.0) -> float:
@@ -115,23 +146,12 @@ class ERDTrainer:
             f = self.warmup_start + (1.0 - self.warmup_start) * it / max(self.warmup_iters - 1, 1)
         return self.base_lr * f * epoch_factor
 
-    # -- gradient buckets --------------------------------------------------------------------------------------------
-    def _make_hook(self, i: int):
-        def hook(_p):
-            b = self.flat.bucket_of[i]
-            self._remaining[b] -= 1
-            if self._remaining[b] == 0:
-                s, e, _ = self.flat.buckets[b]
-                self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
-        return hook
-
     def _apply_pending(self) -> None:
         """wait for the bucket all-reduces of the previous backward, then ONE fused SGD launch."""
         if not self._pending:
             return
-        for w in self._works:
-            w.wait()
-        self._works = []
+        if self.sync is not None:
+            self.sync.wait()
         K.sgd_momentum_(self.flat.data, self.flat.grad, self.flat.momentum, self.lr_at(self.iter - 1), self.momentum,
                         self.weight_decay, 1.0 / self.world, self._first)
         self._first = False
@@ -161,7 +181,8 @@ class ERDTrainer:
         else:
             losses = model(inputs, data_samples, mode="loss")
         total, log_vars = parse_losses(losses)
-        self._remaining = [len(m) for (_, _, m) in self.flat.buckets]
+        if self.sync is not None:
+            self.sync.arm()
         total.backward()
         self._pending = True
         self.iter += 1

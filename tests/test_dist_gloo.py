@@ -1,0 +1,63 @@
+"""CPU, world_size 2 over gloo: the data-parallel pieces that do not need a GPU -- bucket layout in backward
+order, hook-driven per-bucket all-reduce on the flat gradient buffer, and the reduce_mean convention of the
+two loss normalisers (dist_utils.py:59-65)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from erd_amd.engine import BucketedGradSync, FlatParams
+        torch.manual_seed(0)                                   # same init on every rank
+        net = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                                  torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 1))
+        named = list(net.named_parameters()); named.reverse()
+        flat = FlatParams(named, "cpu", bucket_bytes=1024)     # tiny buckets -> several all-reduces
+        assert len(flat.buckets) >= 2 and flat.buckets[0][0] == 0 and flat.buckets[-1][1] == flat.total
+        assert all(p.data_ptr() >= flat.data.data_ptr() for p in flat.params)           # params live in the flat buffer
+        sync = BucketedGradSync(flat)
+        g = torch.Generator().manual_seed(100 + rank)          # different data per rank
+        x = torch.randn(2, 4, 6, 6, generator=g)
+        flat.zero_grad(); sync.arm()
+        net(x).square().mean().backward()
+        sync.wait()
+        mine = flat.grad.clone() / world
+        # reference: gather every rank's local gradient and average
+        flat.zero_grad()
+        net(x).square().mean().backward()
+        loc = [torch.zeros_like(flat.grad) for _ in range(world)]
+        dist.all_gather(loc, flat.grad.clone())
+        ref = sum(loc) / world
+        ok = torch.allclose(mine, ref, rtol=1e-6, atol=1e-8)
+        # reduce_mean of the two loss normalisers: div by world, then SUM
+        avg = torch.tensor([3.0 + rank, 10.0 * (rank + 1)])
+        avg.div_(world); dist.all_reduce(avg)
+        ok = ok and torch.allclose(avg, torch.tensor([3.5, 15.0]))
+        q.put((rank, bool(ok), len(flat.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_grad_sync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

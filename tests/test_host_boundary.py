@@ -1,0 +1,122 @@
+"""CPU: the drop-in boundary -- config files, registry, state-dict ABI, teacher load /
+student warm start, C-ABI exports.  No compute: erd_amd has no CPU path (and says so)."""
+import os
+import re
+import tempfile
+
+import pytest
+import torch
+
+import erd_amd
+from erd_amd import Config, MODELS, TASK_UTILS
+from e2e_util import CFG_FIRST, CFG_INCRE, ROOT
+from oracle import erd_oracle as O
+
+REF_CFG = "/root/reference/configs/gfl_increment"
+
+
+def test_configs_load_and_inherit_bases():
+    cfg = Config.fromfile(CFG_INCRE)
+    assert cfg.model.type == "GFLIncrementERD" and cfg.model.bbox_head.type == "GFLHeadIncrementERD"
+    assert cfg.model.ori_setting.ori_num_classes == 40            # attribute access on nested dicts
+    assert cfg.optim_wrapper.optimizer == dict(type="SGD", lr=0.01, momentum=0.9, weight_decay=0.0001)
+    assert cfg.param_scheduler[0].type == "LinearLR" and cfg.param_scheduler[1].milestones == [8, 11]   # from _base_
+    assert cfg.env_cfg.dist_cfg.backend == "nccl" and cfg.auto_scale_lr == dict(enable=True, base_batch_size=16)
+    assert cfg.train_dataloader.batch_size == 2                    # base value survives the child's partial override
+    assert cfg.train_dataloader.dataset.ann_file.endswith("sel_last_40_cats.json")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("name", ["gfl_r50_fpn_1x_coco_first_40_cats.py",
+                                  "gfl_r50_fpn_1x_coco_first_40_incre_last_40_cats.py"])
+def test_reference_config_files_load_unchanged_and_equal_ours(name):
+    ref = Config.fromfile(os.path.join(REF_CFG, name)).to_dict()
+    ours = Config.fromfile(os.path.join(ROOT, "configs", "gfl_increment", name)).to_dict()
+    ref.pop("filename"); ours.pop("filename")
+    assert ref == ours
+    MODELS.build(dict(ref["model"], latest_model_flag=False) if "ori_setting" in ref["model"] else ref["model"])
+
+
+def test_registry_surface():
+    for t in ["GFLIncrementERD", "GFL", "ResNet", "FPN", "GFLHead", "GFLHeadIncrementERD", "QualityFocalLoss",
+              "DistributionFocalLoss", "GIoULoss", "KnowledgeDistillationKLDivLoss", "DetDataPreprocessor"]:
+        assert t in MODELS, t
+    for t in ["AnchorGenerator", "ATSSAssigner", "DistancePointBBoxCoder", "BboxOverlaps2D"]:
+        assert t in TASK_UTILS, t
+    with pytest.raises(KeyError):
+        MODELS.build(dict(type="FasterRCNN"))
+    with pytest.raises(NotImplementedError):      # out-of-path variants fail loudly instead of silently differing
+        MODELS.build(dict(type="ResNet", depth=50, norm_eval=False))
+
+
+def test_state_dict_abi_matches_reference_keys():
+    teacher = MODELS.build(Config.fromfile(CFG_FIRST).model)
+    spec = O.gfl_param_shapes(40)
+    sd = teacher.state_dict()
+    assert list(sorted(sd)) == list(sorted(spec))
+    assert all(tuple(sd[k].shape) == spec[k] for k in spec)
+    assert sum(p.numel() for p in teacher.parameters()) == 32348337                  # SURVEY 8(b) [probe]
+    cfg = Config.fromfile(CFG_INCRE)
+    cfg.model.latest_model_flag = False
+    student = MODELS.build(cfg.model)
+    assert sum(p.numel() for p in student.parameters() if p.requires_grad) == 32215193
+    assert sum(p.numel() for p in student.parameters() if not p.requires_grad) == 225344
+    # D11: stacked_convs / reg_max given to the ERD head are ignored, exactly like the reference
+    cfg.model.bbox_head.stacked_convs = 1
+    s2 = MODELS.build(cfg.model)
+    assert len(s2.bbox_head.cls_convs) == 4 and s2.bbox_head.gfl_reg.weight.shape[0] == 68
+    # conv weights are stored [O][kh][kw][I] while exposing the OIHW checkpoint shape
+    w = student.backbone.layer2[0].conv2.weight
+    assert tuple(w.shape) == (128, 128, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_teacher_load_and_student_warm_start_through_checkpoint_file():
+    """gfl_increment_erd.py:67-122 with a real file on disk (latest_model_flag=True path)."""
+    tsd = O.procedural_state_dict(40, seed=0)
+    with tempfile.TemporaryDirectory() as d:
+        ck = os.path.join(d, "epoch_12.pth")
+        torch.save(dict(state_dict={"module." + k: v for k, v in tsd.items()}, meta=dict(epoch=12)), ck)
+        cfg = Config.fromfile(CFG_INCRE)
+        cfg.model.ori_setting.ori_checkpoint_file = ck
+        cfg.model.ori_setting.ori_config_file = CFG_FIRST
+        torch.manual_seed(0)
+        model = MODELS.build(cfg.model)
+        missing = dict(cfg.model.ori_setting, ori_checkpoint_file=os.path.join(d, "nope.pth"))
+        with pytest.raises(AssertionError):
+            MODELS.build(dict(cfg.model, ori_setting=missing))
+    sd = model.state_dict()
+    assert any(k.startswith("ori_model.") for k in sd)                  # D7: teacher is a registered submodule
+    assert all(not p.requires_grad for p in model.ori_model.parameters()) and not model.ori_model.training
+    assert torch.equal(sd["ori_model.bbox_head.gfl_cls.weight"], tsd["bbox_head.gfl_cls.weight"])
+    assert torch.equal(sd["bbox_head.gfl_cls.weight"][:40], tsd["bbox_head.gfl_cls.weight"])     # old rows copied
+    assert float(sd["bbox_head.gfl_cls.weight"][40:].std()) == pytest.approx(0.01, rel=0.1)        # new rows fresh
+    assert torch.allclose(sd["bbox_head.gfl_cls.bias"][40:], torch.full((40,), -4.59512))
+    assert torch.equal(sd["backbone.layer3.2.conv2.weight"], tsd["backbone.layer3.2.conv2.weight"])
+    assert model.ori_num_classes == 40 and model._is_init
+
+
+def test_product_has_no_cpu_path_and_never_imports_the_oracle():
+    model = MODELS.build(Config.fromfile(CFG_FIRST).model)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(1, 3, 64, 64), mode="tensor")
+    with pytest.raises(RuntimeError, match="Invalid mode"):
+        model(torch.zeros(1, 3, 64, 64), mode="bogus")
+    for root, _, files in os.walk(os.path.join(ROOT, "erd_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from erd_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "erd_hip.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int|const char\*)\s+(erd_\w+)\s*\(", header, re.M)))
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.erd_abi_version() == 1
+    # argument errors come back as codes + message, never as exceptions across the ABI
+    assert lib.erd_conv_igemm(None, None) == -1 and b"null" in lib.erd_last_error()
