@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("Cin", i32), ("Cout", i32), ("wrow", i32), ("ntaps", i32),
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS), ("wk", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
-                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32)]
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32),
+                ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t)]
 
 
 class WgradDesc(C.Structure):
@@ -52,6 +53,7 @@ P = C.c_void_p
 _SIGNATURES = {
     # name: argtypes (restype is always int unless noted)
     "erd_conv_igemm": [C.POINTER(ConvDesc), P],
+    "erd_conv_igemm_ws_bytes": [i32],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
     "erd_weight_transpose": [P, P, P, i32, i32, i32, i32, P],
@@ -107,7 +109,7 @@ def load():
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = C.c_size_t if name.endswith("_ws_bytes") else C.c_int
     if lib.erd_abi_version() != 1:
         raise ErdHipError("liberd_hip.so ABI version mismatch")
     _lib = lib

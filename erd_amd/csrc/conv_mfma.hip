@@ -34,198 +34,269 @@ struct RowInfo {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Work decomposition ("stream-K"): the launch is a PERSISTENT grid of G workgroups.  All output tiles have
+// the same number of K-slices nkt, so the work is U = tiles*nkt equal units, and workgroup b takes the
+// contiguous unit range [b*U/G, (b+1)*U/G): whole tiles in the middle, at most one partial tile at each end.
+// A partial tile's accumulators go to a per-(workgroup, slot) fp32 slab; the LAST contributor to arrive (a
+// relaxed agent-scope ticket behind an agent-scope release; acquire on the reducer -- cdna_hip_programming
+// Guideline 16 counter form, no spinning, no co-residency assumption) sums all slabs of the tile in
+// contributor order (deterministic) and runs the epilogue.  With G == tiles this is plain data-parallel.
+// Why: at bs=4 most ERD layers have 0.5..4 "CU-rounds" of 128x128 tiles; tile-granular dispatch wastes
+// 10-48 % of the matrix pipes in the last round, unit-granular dispatch wastes < 1/nkt.
+struct SkWs {
+    int* cnt;        // [tiles] arrival tickets (zeroed before the launch)
+    float* slabs;    // [2*G][BM*BN]
+};
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_desc p) {
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
+                                                                  const SkWs ws) {
     constexpr int FM = BM / (WAVES_M * 32);
     constexpr int FN = BN / (WAVES_N * 32);
     constexpr int AJ = BM / 32;  // float4 loads per thread for A
     constexpr int BJ = BN / 32;
+    constexpr int NACC = FM * FN * 16;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*8]
     float4* Bs = As + 2 * BM * 8;                                  // [2][BN*8]
     RowInfo* rows = reinterpret_cast<RowInfo*>(Bs + 2 * BN * 8);   // [BM]
+    int* bcast = reinterpret_cast<int*>(rows + BM);                // [4]
 
     const int tid = threadIdx.x;
     const int ntn = (p.Cout + BN - 1) / BN;
-    const int nt = blockIdx.x % ntn;
-    int mt = blockIdx.x / ntn;
-
-    // ---- which segment (level) does this M-tile belong to -----------------------------------
-    int s = 0;
-#pragma unroll 1
-    for (; s < p.nseg - 1; ++s) {
-        const int M = p.seg[s].N * p.seg[s].GH * p.seg[s].GW;
-        const int tiles = (M + BM - 1) / BM;
-        if (mt < tiles) break;
-        mt -= tiles;
-    }
-    const erd_conv_seg& sg = p.seg[s];
-    const int IH = sg.IH, IW = sg.IW, Cin = p.Cin;
-    const float* __restrict__ in = sg.in;
+    const int Cin = p.Cin;
+    const int cpt = (Cin + BK - 1) / BK;  // K-slices per tap (last one zero-filled past Cin)
+    const int nkt = p.ntaps * cpt;
     const float* __restrict__ w = p.w;
 
-    if (tid < BM) {
-        const int GHW = sg.GH * sg.GW;
-        const int M = sg.N * GHW;
-        const int m = mt * BM + tid;
-        RowInfo ri;
-        if (m < M) {
-            const int n = m / GHW;
-            const int rem = m - n * GHW;
-            const int a = rem / sg.GW;
-            const int b = rem - a * sg.GW;
-            ri.in_off = (int)(n * sg.in_nstride);
-            ri.ih0 = a * p.in_stride;
-            ri.iw0 = b * p.in_stride;
-            ri.out_off = (int)(n * sg.out_nstride) +
-                         ((a * p.out_stride + p.oy) * sg.OW + (b * p.out_stride + p.ox)) * p.Cout;
-        } else {
-            ri.in_off = 0;
-            ri.ih0 = -(1 << 28);
-            ri.iw0 = -(1 << 28);
-            ri.out_off = -1;
-        }
-        rows[tid] = ri;
-    }
-    __syncthreads();
+    const long long U = (long long)total_tiles * nkt;
+    const int G = gridDim.x;
+    const long long u_begin = (U * blockIdx.x) / G, u_end = (U * (blockIdx.x + 1)) / G;
 
     const int chunk = tid & 7;
     const int r0 = tid >> 3;  // 0..31
-    int a_off[AJ], a_ih[AJ], a_iw[AJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        const RowInfo ri = rows[r0 + 32 * j];
-        a_off[j] = ri.in_off + chunk * 4;
-        a_ih[j] = ri.ih0;
-        a_iw[j] = ri.iw0;
-    }
-    const int n0 = nt * BN;
-    int b_off[BJ];
-    bool b_ok[BJ];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-        const int co = n0 + r0 + 32 * j;
-        b_ok[j] = co < p.Cout;
-        b_off[j] = (b_ok[j] ? co : 0) * p.wrow + chunk * 4;
-    }
-
-    const int cpt = (Cin + BK - 1) / BK;  // K-slices per tap (last one zero-filled past Cin)
-    const int nkt = p.ntaps * cpt;
-
-    float4 ra[AJ], rb[BJ];
-    int tap = 0, cc = 0;
-
-    auto load_global = [&]() {
-        const int dyt = p.dy[tap], dxt = p.dx[tap];
-        const int kb = p.wk[tap] + cc * BK;
-        const int cb = cc * BK;
-        const bool cok = cb + chunk * 4 < Cin;   // Cin % 4 == 0: a 16-B chunk is all-in or all-out
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const int ih = a_ih[j] + dyt, iw = a_iw[j] + dxt;
-            const bool ok = cok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
-            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) ra[j] = *reinterpret_cast<const float4*>(in + (a_off[j] + (ih * IW + iw) * Cin + cb));
-        }
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b_ok[j] && cok) rb[j] = *reinterpret_cast<const float4*>(w + (b_off[j] + kb));
-        }
-        if (++cc == cpt) { cc = 0; ++tap; }
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const int row = r0 + 32 * j;
-            As[buf * BM * 8 + row * 8 + swz(row, chunk)] = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int row = r0 + 32 * j;
-            Bs[buf * BN * 8 + row * 8 + swz(row, chunk)] = rb[j];
-        }
-    };
-
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
 
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (long long u = u_begin; u < u_end;) {
+        const int tt = (int)(u / nkt);
+        const int ks = (int)(u - (long long)tt * nkt);
+        const int ke = (int)min((long long)nkt, ks + (u_end - u));
+        u += ke - ks;
+        const int nt = tt % ntn;
+        int mt = tt / ntn;
 
-    load_global();
-    store_lds(0);
-    __syncthreads();
+        // ---- which segment (level) does this M-tile belong to -------------------------------------
+        int s = 0;
+#pragma unroll 1
+        for (; s < p.nseg - 1; ++s) {
+            const int M = p.seg[s].N * p.seg[s].GH * p.seg[s].GW;
+            const int tiles = (M + BM - 1) / BM;
+            if (mt < tiles) break;
+            mt -= tiles;
+        }
+        const erd_conv_seg& sg = p.seg[s];
+        const int IH = sg.IH, IW = sg.IW;
+        const float* __restrict__ in = sg.in;
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) load_global();
-        const float4* Ab = As + buf * BM * 8;
-        const float4* Bb = Bs + buf * BN * 8;
+        __syncthreads();   // previous tile's epilogue / fragment reads are done with LDS
+        if (tid < BM) {
+            const int GHW = sg.GH * sg.GW;
+            const int M = sg.N * GHW;
+            const int m = mt * BM + tid;
+            RowInfo ri;
+            if (m < M) {
+                const int n = m / GHW;
+                const int rem = m - n * GHW;
+                const int a = rem / sg.GW;
+                const int b = rem - a * sg.GW;
+                ri.in_off = (int)(n * sg.in_nstride);
+                ri.ih0 = a * p.in_stride;
+                ri.iw0 = b * p.in_stride;
+                ri.out_off = (int)(n * sg.out_nstride) +
+                             ((a * p.out_stride + p.oy) * sg.OW + (b * p.out_stride + p.ox)) * p.Cout;
+            } else {
+                ri.in_off = 0;
+                ri.ih0 = -(1 << 28);
+                ri.iw0 = -(1 << 28);
+                ri.out_off = -1;
+            }
+            rows[tid] = ri;
+        }
+        __syncthreads();
+
+        int a_off[AJ], a_ih[AJ], a_iw[AJ];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int c = 2 * kk + h;
-            float4 fa[FM], fb[FN];
+        for (int j = 0; j < AJ; ++j) {
+            const RowInfo ri = rows[r0 + 32 * j];
+            a_off[j] = ri.in_off + chunk * 4;
+            a_ih[j] = ri.ih0;
+            a_iw[j] = ri.iw0;
+        }
+        const int n0 = nt * BN;
+        int b_off[BJ];
+        bool b_ok[BJ];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int row = (wm * FM + i) * 32 + li;
-                fa[i] = Ab[row * 8 + swz(row, c)];
+        for (int j = 0; j < BJ; ++j) {
+            const int co = n0 + r0 + 32 * j;
+            b_ok[j] = co < p.Cout;
+            b_off[j] = (b_ok[j] ? co : 0) * p.wrow + chunk * 4;
+        }
+
+        float4 ra[AJ], rb[BJ];
+        int tap = ks / cpt, cc = ks - tap * cpt;
+
+        auto load_global = [&]() {
+            const int dyt = p.dy[tap], dxt = p.dx[tap];
+            const int kb = p.wk[tap] + cc * BK;
+            const int cb = cc * BK;
+            const bool cok = cb + chunk * 4 < Cin;   // Cin % 4 == 0: a 16-B chunk is all-in or all-out
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int ih = a_ih[j] + dyt, iw = a_iw[j] + dxt;
+                const bool ok = cok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+                ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) ra[j] = *reinterpret_cast<const float4*>(in + (a_off[j] + (ih * IW + iw) * Cin + cb));
             }
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int row = (wn * FN + j) * 32 + li;
-                fb[j] = Bb[row * 8 + swz(row, c)];
+            for (int j = 0; j < BJ; ++j) {
+                rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b_ok[j] && cok) rb[j] = *reinterpret_cast<const float4*>(w + (b_off[j] + kb));
             }
+            if (++cc == cpt) { cc = 0; ++tap; }
+        };
+        auto store_lds = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int row = r0 + 32 * j;
+                As[buf * BM * 8 + row * 8 + swz(row, chunk)] = ra[j];
+            }
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int row = r0 + 32 * j;
+                Bs[buf * BN * 8 + row * 8 + swz(row, chunk)] = rb[j];
+            }
+        };
+
+        f32x16 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        load_global();
+        store_lds(0);
+        __syncthreads();
+
+        for (int kt = ks; kt < ke; ++kt) {
+            const int buf = (kt - ks) & 1;
+            const bool more = kt + 1 < ke;
+            if (more) load_global();
+            const float4* Ab = As + buf * BM * 8;
+            const float4* Bb = Bs + buf * BN * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int c = 2 * kk + h;
+                float4 fa[FM], fb[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = (wm * FM + i) * 32 + li;
+                    fa[i] = Ab[row * 8 + swz(row, c)];
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = (wn * FN + j) * 32 + li;
+                    fb[j] = Bb[row * 8 + swz(row, c)];
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---- partial tile: hand the accumulators over; the last contributor to arrive reduces ----------
+        if (ks != 0 || ke != nkt) {
+            const long long t0 = (long long)tt * nkt;
+            const int first_b = (int)(((t0 + 1) * G - 1) / U);
+            const int last_b = (int)(((t0 + nkt) * G - 1) / U);
+            const int ncontrib = last_b - first_b + 1;
+            const int my_slot = (tt == (int)(u_begin / nkt)) ? 0 : 1;
+            float* slab = ws.slabs + ((size_t)(2 * blockIdx.x + my_slot)) * (BM * BN);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[((i * FN + j) * 16 + r) * NTHREADS + tid] = acc[i][j][r];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int old = __hip_atomic_fetch_add(ws.cnt + tt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == ncontrib - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                bcast[0] = old;
+            }
+            __syncthreads();
+            if (bcast[0] != ncontrib - 1) continue;   // somebody else finishes this tile
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int c = 0; c < ncontrib; ++c) {
+                const int bb = first_b + c;
+                const int bfirst_tile = (int)(((U * bb) / G) / nkt);
+                const float* sl = ws.slabs + ((size_t)(2 * bb + (tt == bfirst_tile ? 0 : 1))) * (BM * BN);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += sl[((i * FN + j) * 16 + r) * NTHREADS + tid];
+            }
         }
-        if (more) store_lds(buf ^ 1);
-        __syncthreads();
-    }
 
-    // ---- epilogue -------------------------------------------------------------------------------
-    float* __restrict__ out = sg.out;
-    const float* res = sg.res;
-    const float alpha = sg.alpha ? *sg.alpha : 1.f;
-    const bool has_alpha = sg.alpha != nullptr;
-    const int res_delta_n = 0;
-    (void)res_delta_n;
+        // ---- epilogue -------------------------------------------------------------------------------
+        float* __restrict__ out = sg.out;
+        const float* res = sg.res;
+        const float alpha = sg.alpha ? *sg.alpha : 1.f;
+        const bool has_alpha = sg.alpha != nullptr;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int co = n0 + (wn * FN + j) * 32 + li;
-        const bool cok = co < p.Cout;
-        const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
-        const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
+        for (int j = 0; j < FN; ++j) {
+            const int co = n0 + (wn * FN + j) * 32 + li;
+            const bool cok = co < p.Cout;
+            const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
+            const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
+            for (int i = 0; i < FM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int oo = rows[row].out_off;
-                if (oo >= 0 && cok) {
-                    float v = acc[i][j][r];
-                    if (p.scale) v *= sc;
-                    v += sh;
-                    if (has_alpha) v *= alpha;
-                    if (res) v += res[oo + co];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    out[oo + co] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int oo = rows[row].out_off;
+                    if (oo >= 0 && cok) {
+                        float v = acc[i][j][r];
+                        if (p.scale) v *= sc;
+                        v += sh;
+                        if (has_alpha) v *= alpha;
+                        if (res) v += res[oo + co];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        out[oo + co] = v;
+                    }
                 }
             }
         }
@@ -366,26 +437,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad
     }
 }
 
-// dW[co][k] (+)= rowscale[co] * sum_s part[s][co][k];  rowdot[co] = sum_k w[co][k] * G[co][k]
+// dW[co][k] (+)= rowscale[co] * sum_s part[s][co][k];  rowdot[co] += sum_k w[co][k] * G[co][k]
+// grid (Cout, K/1024): every thread sums one float4 column of the nsplit slabs (coalesced across the block);
+// rowdot is accumulated with one atomic per block (the caller zeroes it).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int Cout,
                                                             int K, const float* __restrict__ w,
                                                             const float* __restrict__ rowscale,
                                                             float* __restrict__ dW, int accumulate,
                                                             float* __restrict__ rowdot) {
     const int co = blockIdx.x;
+    const int k = (blockIdx.y * 256 + threadIdx.x) * 4;
     const int64_t slab = (int64_t)Cout * K;
     const float rs = rowscale ? rowscale[co] : 1.f;
     float dot = 0.f;
-    for (int k = threadIdx.x * 4; k < K; k += 256 * 4) {
+    if (k < K) {
         const int64_t o = (int64_t)co * K + k;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < nsplit; ++s) {
+        int s = 0;
+        for (; s + 3 < nsplit; s += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (s + 0) * slab + o);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (s + 1) * slab + o);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (s + 2) * slab + o);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (s + 3) * slab + o);
+            g.x += (v0.x + v1.x) + (v2.x + v3.x); g.y += (v0.y + v1.y) + (v2.y + v3.y);
+            g.z += (v0.z + v1.z) + (v2.z + v3.z); g.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; s < nsplit; ++s) {
             const float4 v = *reinterpret_cast<const float4*>(part + s * slab + o);
             g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
         }
         if (rowdot) {
             const float4 ww = *reinterpret_cast<const float4*>(w + o);
-            dot += ww.x * g.x + ww.y * g.y + ww.z * g.z + ww.w * g.w;
+            dot = ww.x * g.x + ww.y * g.y + ww.z * g.z + ww.w * g.w;
         }
         float4 o4 = make_float4(rs * g.x, rs * g.y, rs * g.z, rs * g.w);
         if (accumulate) {
@@ -399,7 +482,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         dot = erd::wave_sum(dot);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
         __syncthreads();
-        if (threadIdx.x == 0) rowdot[co] = red[0] + red[1] + red[2] + red[3];
+        if (threadIdx.x == 0) atomicAdd(rowdot + co, red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -426,6 +509,18 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     int tiles = 0;
@@ -434,15 +529,32 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
         tiles += (int)((M + BM - 1) / BM);
     }
     const int ntn = (d->Cout + BN - 1) / BN;
+    tiles *= ntn;
     if (tiles == 0) return 0;
-    const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(float4) + BM * sizeof(RowInfo);
+    const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
+    const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(float4) + BM * sizeof(RowInfo) + 16;
     auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles * ntn), dim3(NTHREADS), lds, st, *d);
+    // persistent stream-K grid when a workspace is supplied and tile-granular dispatch would leave a
+    // ragged last round; otherwise one workgroup per tile.
+    const int slots = 2 * num_cus();
+    int G = tiles;
+    SkWs ws{nullptr, nullptr};
+    const size_t cnt_bytes = ((size_t)tiles * sizeof(int) + 255) / 256 * 256;
+    const size_t need = cnt_bytes + (size_t)2 * slots * BM * BN * sizeof(float);
+    const bool ragged = tiles < 8 * slots && (tiles % slots) != 0;
+    // short K loops (1x1 convs on few channels) are latency/HBM-bound: they want many independent workgroups
+    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && nkt >= 16 && (int64_t)tiles * nkt >= slots) {
+        G = slots;
+        ws.cnt = reinterpret_cast<int*>(d->sk_ws);
+        ws.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(d->sk_ws) + cnt_bytes);
+        (void)hipMemsetAsync(ws.cnt, 0, (size_t)tiles * sizeof(int), st);
+    }
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), lds, st, *d, tiles, ws);
     return erd::check_launch("conv_igemm");
 }
 
@@ -465,6 +577,10 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     return launch_igemm<128, 128, 2, 2>(d, st);
 }
 
+extern "C" size_t erd_conv_igemm_ws_bytes(int max_tiles) {
+    return ((size_t)max_tiles * sizeof(int) + 255) / 256 * 256 + (size_t)2 * 2 * num_cus() * 128 * 128 * sizeof(float);
+}
+
 extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d != nullptr && d->x && d->dz && d->part, "wgrad: null pointer");
     ERD_REQUIRE(d->ntaps >= 1 && d->ntaps <= ERD_MAX_TAPS, "wgrad: ntaps=%d", d->ntaps);
@@ -477,7 +593,7 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     auto kern = conv_wgrad_kernel<BM, BN>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(nci * d->ntaps, nco, d->nsplit), dim3(NTHREADS), lds, (hipStream_t)stream, *d);
@@ -489,8 +605,9 @@ extern "C" int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, 
                                 erd_stream_t stream) {
     ERD_REQUIRE(part && dW && nsplit >= 1 && K % 4 == 0, "wgrad_reduce: bad args");
     ERD_REQUIRE(!rowdot || w, "wgrad_reduce: rowdot needs w");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, part, nsplit, Cout, K, w,
-                       rowscale, dW, accumulate, rowdot);
+    if (rowdot) (void)hipMemsetAsync(rowdot, 0, sizeof(float) * Cout, (hipStream_t)stream);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, (K + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, part,
+                       nsplit, Cout, K, w, rowscale, dW, accumulate, rowdot);
     return erd::check_launch("wgrad_reduce");
 }
 

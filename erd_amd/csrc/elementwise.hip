@@ -126,36 +126,75 @@ __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restr
 
 // dz = dy * (y>0) (dz may alias dy); colsum[c] += sum over rows of dz.  rows are [npix][C] with an image
 // stride (level views of [N][A][C] buffers): row r -> img r / rows_per_img.
+// Thread (column group c4 = tid % C4w, row lane = tid / C4w) streams float4s down its column, 4 rows in flight;
+// the block combines its row lanes through LDS and issues ONE atomic per channel.
 __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __restrict__ y, const float* dy, float* dz,
                                                                int64_t npix, int C, int64_t nstride,
                                                                int64_t rows_per_img, float* __restrict__ colsum,
                                                                int use_relu, int rows_per_block) {
-    // thread layout: C/4 float4 columns x (256/(C/4)) row lanes ; C in {64..2048}: C4 may exceed 256
+    __shared__ float4 red[256];
     const int C4 = C >> 2;
+    const int C4w = C4 < 256 ? C4 : 256;            // columns handled concurrently
+    const int lanes = 256 / C4w;
+    const int rl = threadIdx.x / C4w;
+    const bool dense = nstride == rows_per_img * C;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = min(npix, r_begin + rows_per_block);
-    for (int c4 = threadIdx.x % min(C4, 256); c4 < C4; c4 += 256) {
-        const int lanes = C4 >= 256 ? 1 : 256 / C4;
-        const int rl = C4 >= 256 ? 0 : threadIdx.x / C4;
-        if (rl >= lanes) break;
+    for (int c4 = threadIdx.x % C4w; c4 < C4; c4 += 256) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t r = r_begin + rl; r < r_end; r += lanes) {
-            const int64_t img = r / rows_per_img;
-            const int64_t off = img * nstride + (r - img * rows_per_img) * C + c4 * 4;
-            float4 g = *reinterpret_cast<const float4*>(dy + off);
-            if (use_relu) {
-                const float4 yy = *reinterpret_cast<const float4*>(y + off);
-                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-                *reinterpret_cast<float4*>(dz + off) = g;
+        if (rl < lanes) {
+            auto offset = [&](int64_t r) -> int64_t {
+                if (dense) return r * C + c4 * 4;
+                const int64_t img = r / rows_per_img;
+                return img * nstride + (r - img * rows_per_img) * C + c4 * 4;
+            };
+            int64_t r = r_begin + rl;
+            for (; r + 3 * lanes < r_end; r += 4 * lanes) {
+                int64_t o[4];
+                float4 g[4], yy[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[q] = offset(r + q * lanes);
+                    g[q] = *reinterpret_cast<const float4*>(dy + o[q]);
+                    if (use_relu) yy[q] = *reinterpret_cast<const float4*>(y + o[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (use_relu) {
+                        g[q].x = yy[q].x > 0.f ? g[q].x : 0.f; g[q].y = yy[q].y > 0.f ? g[q].y : 0.f;
+                        g[q].z = yy[q].z > 0.f ? g[q].z : 0.f; g[q].w = yy[q].w > 0.f ? g[q].w : 0.f;
+                        *reinterpret_cast<float4*>(dz + o[q]) = g[q];
+                    }
+                    s.x += g[q].x; s.y += g[q].y; s.z += g[q].z; s.w += g[q].w;
+                }
             }
-            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            for (; r < r_end; r += lanes) {
+                const int64_t o = offset(r);
+                float4 g = *reinterpret_cast<const float4*>(dy + o);
+                if (use_relu) {
+                    const float4 yy = *reinterpret_cast<const float4*>(y + o);
+                    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+                    *reinterpret_cast<float4*>(dz + o) = g;
+                }
+                s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            }
         }
         if (colsum) {
-            atomicAdd(colsum + c4 * 4 + 0, s.x);
-            atomicAdd(colsum + c4 * 4 + 1, s.y);
-            atomicAdd(colsum + c4 * 4 + 2, s.z);
-            atomicAdd(colsum + c4 * 4 + 3, s.w);
+            __syncthreads();
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (threadIdx.x < C4w) {
+                float4 t = red[threadIdx.x];
+                for (int j = 1; j < lanes; ++j) {
+                    const float4 v = red[threadIdx.x + j * C4w];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                atomicAdd(colsum + c4 * 4 + 0, t.x);
+                atomicAdd(colsum + c4 * 4 + 1, t.y);
+                atomicAdd(colsum + c4 * 4 + 2, t.z);
+                atomicAdd(colsum + c4 * 4 + 3, t.w);
+            }
         }
     }
 }
@@ -536,8 +575,9 @@ extern "C" int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, i
                                    erd_stream_t stream) {
     ERD_REQUIRE(dy && C % 4 == 0 && (!use_relu || (y && dz)), "relu_bwd: bad args");
     if (npix == 0) return 0;
-    int rpb = 64;
-    while ((npix + rpb - 1) / rpb > 4096) rpb *= 2;
+    ERD_REQUIRE((C / 4) <= 256 ? (256 % (C / 4) == 0) : ((C / 4) % 256 == 0), "relu_bwd: C=%d unsupported", C);
+    int rpb = 128;
+    while ((npix + rpb - 1) / rpb > 2048) rpb *= 2;
     hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((unsigned)((npix + rpb - 1) / rpb)), dim3(256), 0,
                        (hipStream_t)stream, y, dy, dz, npix, C, nstride_rows, rows_per_img, colsum, use_relu, rpb);
     return erd::check_launch("relu_bwd_colsum");

@@ -478,20 +478,24 @@ __global__ __launch_bounds__(256) void gfl_losses_kernel(const float* __restrict
         for (int i = threadIdx.x; i < nrows * C4; i += 256) dst[i] = reinterpret_cast<float4*>(sm)[i];
         return;
     }
-    // ---- forward reductions: per level {qfl, giou*w, dfl*w, w}; a 64-row block may straddle levels ----
+    // ---- forward reductions: per level {qfl, giou*w, dfl*w, w}: LDS partials, one global atomic per block ----
     qsum += __shfl_xor(qsum, 1, 64);
     qsum += __shfl_xor(qsum, 2, 64);
     dfl_l += __shfl_xor(dfl_l, 1, 64);
     dfl_l += __shfl_xor(dfl_l, 2, 64);
+    __shared__ double lsum[ERD_MAX_SEG * 4];
+    if (threadIdx.x < ERD_MAX_SEG * 4) lsum[threadIdx.x] = 0.0;
+    __syncthreads();
     if (ok && q == 0) {
-        double* o = out_sums + l * 4;
-        atomicAdd(o + 0, (double)(qsum * lw));
+        atomicAdd(&lsum[l * 4 + 0], (double)(qsum * lw));
         if (is_pos) {
-            atomicAdd(o + 1, (double)(giou_l * wt));
-            atomicAdd(o + 2, (double)(dfl_l * wt));
-            atomicAdd(o + 3, (double)wt);
+            atomicAdd(&lsum[l * 4 + 1], (double)(giou_l * wt));
+            atomicAdd(&lsum[l * 4 + 2], (double)(dfl_l * wt));
+            atomicAdd(&lsum[l * 4 + 3], (double)wt);
         }
     }
+    __syncthreads();
+    if (threadIdx.x < lv.n * 4 && lsum[threadIdx.x] != 0.0) atomicAdd(out_sums + threadIdx.x, lsum[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------

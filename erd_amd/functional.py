@@ -27,6 +27,23 @@ def _to_oihw(dw_ohwi: Tensor) -> Tensor:
     return dw_ohwi.permute(0, 3, 1, 2)
 
 
+_FOLD_CACHE = {}
+
+
+def _bn_fold_cached(gamma, beta, mean, var, eps):
+    """folded (scale, shift) of a frozen-statistics BN; cached while gamma/beta are frozen too (teacher, stem,
+    layer1): keyed on the tensors' storage + in-place version counters, so loading a checkpoint invalidates it."""
+    if gamma.requires_grad or beta.requires_grad:
+        return K.bn_fold(gamma.detach(), beta.detach(), mean, var, eps)
+    key = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr())
+    ver = (gamma._version, beta._version, mean._version, var._version, eps)
+    hit = _FOLD_CACHE.get(key)
+    if hit is None or hit[0] != ver:
+        hit = (ver, K.bn_fold(gamma.detach(), beta.detach(), mean, var, eps))
+        _FOLD_CACHE[key] = hit
+    return hit[1]
+
+
 class ConvBNAct(Function):
     """y = [relu]( conv(x, w) * scale + shift [+ res] ) with scale/shift folded from a frozen-statistics BN
     (resnet.py:263-302 Bottleneck; norm_eval=True resnet.py:648-657).  gamma/beta still receive gradients
@@ -35,7 +52,7 @@ class ConvBNAct(Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, mean, var, res, k: int, stride: int, pad: int, relu: bool, eps: float):
         wk = ohwi(w)
-        scale, shift = K.bn_fold(gamma.detach(), beta.detach(), mean, var, eps)
+        scale, shift = _bn_fold_cached(gamma, beta, mean, var, eps)
         N, H, W_, _ = x.shape
         OH, OW = K.conv_out_size(H, k, stride, pad), K.conv_out_size(W_, k, stride, pad)
         out = torch.empty((N, OH, OW, wk.shape[0]), dtype=torch.float32, device=x.device)

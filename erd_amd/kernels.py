@@ -136,6 +136,19 @@ def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor
         sg.res_nstride = res.stride(0)
 
 
+STREAMK = True     # stream-K work decomposition of the implicit-GEMM launches (see conv_mfma.hip)
+_SK_TILES = 1 << 16
+
+
+def _attach_sk_ws(d: ConvDesc, device) -> None:
+    if not STREAMK:
+        d.sk_ws, d.sk_ws_bytes = 0, 0
+        return
+    nbytes = int(_lib.load().erd_conv_igemm_ws_bytes(_SK_TILES))
+    ws = workspace("streamk", nbytes, device)
+    d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), nbytes
+
+
 def conv_out_size(h: int, k: int, s: int, p: int) -> int:
     return (h + 2 * p - k) // s + 1
 
@@ -166,6 +179,7 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     d.scale = 0 if scale is None else scale.data_ptr()
     d.shift = 0 if shift is None else shift.data_ptr()
     d.relu = 1 if relu else 0
+    _attach_sk_ws(d, w.device)
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
     _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream())
 
@@ -219,6 +233,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.scale = 0
         d.shift = 0
         d.relu = 0
+        _attach_sk_ws(d, wt.device)
         flop = 2.0 * sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg)) * Cin * len(taps) * Cout
         _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream())
 

@@ -218,8 +218,8 @@ class ResNet(nn.Module):
             raise TypeError("fp32 inputs only")
         x = x.contiguous()
         with torch.no_grad():
-            scale, shift = K.bn_fold(self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var,
-                                     self.bn1.eps)
+            scale, shift = Fn._bn_fold_cached(self.bn1.weight, self.bn1.bias, self.bn1.running_mean,
+                                              self.bn1.running_var, self.bn1.eps)
             h = K.stem(x, Fn.ohwi(self.conv1.weight), scale, shift)
         outs = []
         for i, name in enumerate(self.res_layers):

@@ -67,12 +67,17 @@ typedef struct {
     const float* scale;  /* optional [Cout]: v = acc*scale[co]            */
     const float* shift;  /* optional [Cout]: v += shift[co]  (bias / folded BN) */
     int relu;            /* v = max(v,0) last */
+    /* optional stream-K workspace (>= erd_conv_igemm_ws_bytes()): lets the launch split the K loop of
+     * boundary tiles across workgroups so that all CUs finish together; NULL = one workgroup per tile. */
+    void* sk_ws;
+    size_t sk_ws_bytes;
 } erd_conv_desc;
 
 /* replaces: F.conv2d dispatches at resnet.py:268-283, res_layer.py:57-63, fpn.py:196,215-220,
  * gfl_head.py:224-229 (+ fused frozen-stat BN resnet.py:268-300 / bias / ReLU / residual add);
  * and, run on dz with transformed weights, their convolution_backward (input grad). */
 int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream);
+size_t erd_conv_igemm_ws_bytes(int max_tiles);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
