@@ -269,6 +269,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] += sl[((i * FN + j) * 16 + r) * NTHREADS + tid];
             }
+            if (tid == 0) ws.cnt[tt] = 0;   // leave the ticket zeroed for the next launch (stream-ordered)
         }
 
         // ---- epilogue -------------------------------------------------------------------------------
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);   // [2][BK][BM]
     float* Bs = As + 2 * BK * BM;                 // [2][BK][BN]
+    int2* offs = reinterpret_cast<int2*>(Bs + 2 * BK * BN);   // [2][BK]: (dz offset, x offset) per pixel, -1 = zero row
 
     const int tid = threadIdx.x;
     const int nci = (p.Cin + BN - 1) / BN;
@@ -332,45 +334,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad
     const float* __restrict__ x = p.x;
     const float* __restrict__ dz = p.dz;
 
-    // A rows (pixels) handled by this thread: ar0 + AR*j ; B rows: br0 + BR*j
     const int achunk = tid % AC, ar0 = tid / AC;
     const int bchunk = tid % BC, br0 = tid / BC;
     const bool a_cok = co0 + achunk * 4 < p.Cout;
     const bool b_cok = ci0 + bchunk * 4 < p.Cin;
+    const int a_col = co0 + achunk * 4, b_col = ci0 + bchunk * 4;
 
-    float4 ra[AJ], rb[BJ];
-    auto load_global = [&](int kt) {
-        const int pbase = kt * BK;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const int pp = pbase + ar0 + AR * j;
-            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pp < P && a_cok) {
+    // pixel -> element offsets of one K-slice, computed once by 32 threads (the divisions live here only)
+    auto compute_offsets = [&](int kt, int slot) {
+        if (tid < BK) {
+            const int pp = kt * BK + tid;
+            int2 o = make_int2(-1, -1);
+            if (pp < P && kt < kt_end) {
                 const int n = pp / GHW;
                 const int rem = pp - n * GHW;
                 const int a = rem / p.GW;
                 const int b = rem - a * p.GW;
-                const int64_t off = n * p.dz_nstride +
-                                    (int64_t)((a * p.out_stride + p.oy) * p.OW + (b * p.out_stride + p.ox)) * p.Cout +
-                                    co0 + achunk * 4;
-                ra[j] = *reinterpret_cast<const float4*>(dz + off);
+                o.x = (int)(n * p.dz_nstride) + ((a * p.out_stride + p.oy) * p.OW + (b * p.out_stride + p.ox)) * p.Cout;
+                const int ih = a * p.in_stride + dyt, iw = b * p.in_stride + dxt;
+                if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
+                    o.y = (int)(n * p.x_nstride) + (ih * p.IW + iw) * p.Cin;
             }
+            offs[slot * BK + tid] = o;
+        }
+    };
+
+    float4 ra[AJ], rb[BJ];
+    auto load_global = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int o = offs[slot * BK + ar0 + AR * j].x;
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o >= 0 && a_cok) ra[j] = *reinterpret_cast<const float4*>(dz + (o + a_col));
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int pp = pbase + br0 + BR * j;
+            const int o = offs[slot * BK + br0 + BR * j].y;
             rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pp < P && b_cok) {
-                const int n = pp / GHW;
-                const int rem = pp - n * GHW;
-                const int a = rem / p.GW;
-                const int b = rem - a * p.GW;
-                const int ih = a * p.in_stride + dyt, iw = b * p.in_stride + dxt;
-                if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
-                    const int64_t off = n * p.x_nstride + (int64_t)(ih * p.IW + iw) * p.Cin + ci0 + bchunk * 4;
-                    rb[j] = *reinterpret_cast<const float4*>(x + off);
-                }
-            }
+            if (o >= 0 && b_cok) rb[j] = *reinterpret_cast<const float4*>(x + (o + b_col));
         }
     };
     auto store_lds = [&](int buf) {
@@ -394,13 +395,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kt_begin < kt_end) {
-        load_global(kt_begin);
+        compute_offsets(kt_begin, 0);
+        __syncthreads();
+        load_global(0);
+        compute_offsets(kt_begin + 1, 1);
         store_lds(0);
         __syncthreads();
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int buf = (kt - kt_begin) & 1;
             const bool more = kt + 1 < kt_end;
-            if (more) load_global(kt + 1);
+            if (more) load_global(buf ^ 1);     // offsets of slice kt+1 were published before the last barrier
+            compute_offsets(kt + 2, buf);       // slot `buf` was last read while loading slice kt (previous iteration)
             const float* Ab = As + buf * BK * BM;
             const float* Bb = Bs + buf * BK * BN;
 #pragma unroll
@@ -544,15 +549,17 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     const int slots = 2 * num_cus();
     int G = tiles;
     SkWs ws{nullptr, nullptr};
-    const size_t cnt_bytes = ((size_t)tiles * sizeof(int) + 255) / 256 * 256;
-    const size_t need = cnt_bytes + (size_t)2 * slots * BM * BN * sizeof(float);
+    // workspace layout (fixed, independent of this launch's tile count): [slabs: 2*slots*128*128 floats][tickets]
+    const size_t slab_bytes = (size_t)2 * slots * 128 * 128 * sizeof(float);
+    const size_t need = slab_bytes + (size_t)tiles * sizeof(int);
     const bool ragged = tiles < 8 * slots && (tiles % slots) != 0;
     // short K loops (1x1 convs on few channels) are latency/HBM-bound: they want many independent workgroups
     if (d->sk_ws && d->sk_ws_bytes >= need && ragged && nkt >= 16 && (int64_t)tiles * nkt >= slots) {
         G = slots;
-        ws.cnt = reinterpret_cast<int*>(d->sk_ws);
-        ws.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(d->sk_ws) + cnt_bytes);
-        (void)hipMemsetAsync(ws.cnt, 0, (size_t)tiles * sizeof(int), st);
+        ws.slabs = reinterpret_cast<float*>(d->sk_ws);
+        ws.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(d->sk_ws) + slab_bytes);
+        // tickets are zero on entry: the workspace is zero-initialised by its owner and every reducer re-zeroes
+        // the ticket it consumed
     }
     hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), lds, st, *d, tiles, ws);
     return erd::check_launch("conv_igemm");
@@ -578,7 +585,7 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
 }
 
 extern "C" size_t erd_conv_igemm_ws_bytes(int max_tiles) {
-    return ((size_t)max_tiles * sizeof(int) + 255) / 256 * 256 + (size_t)2 * 2 * num_cus() * 128 * 128 * sizeof(float);
+    return (size_t)2 * 2 * num_cus() * 128 * 128 * sizeof(float) + (size_t)max_tiles * sizeof(int);
 }
 
 extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
@@ -587,9 +594,11 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "wgrad: Cin=%d Cout=%d must be multiples of 4", d->Cin, d->Cout);
     ERD_REQUIRE(d->nsplit >= 1 && d->nsplit <= 65535, "wgrad: nsplit=%d", d->nsplit);
     ERD_REQUIRE((int64_t)d->N * d->GH * d->GW < (1ll << 31), "wgrad: too many pixels");
+    ERD_REQUIRE((int64_t)d->N * d->x_nstride < (1ll << 31) && (int64_t)d->N * d->dz_nstride < (1ll << 31),
+                "wgrad: tensors exceed 2^31 elements");
     constexpr int BM = 128, BN = 128;
     const int nci = (d->Cin + BN - 1) / BN, nco = (d->Cout + BM - 1) / BM;
-    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
+    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float) + 2 * BK * sizeof(int2);
     auto kern = conv_wgrad_kernel<BM, BN>;
     static bool attr_done = false;
     if (!attr_done) {

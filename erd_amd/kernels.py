@@ -136,7 +136,8 @@ def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor
         sg.res_nstride = res.stride(0)
 
 
-STREAMK = True     # stream-K work decomposition of the implicit-GEMM launches (see conv_mfma.hip)
+import os as _os
+STREAMK = _os.environ.get('ERD_STREAMK', '1') != '0'     # stream-K work decomposition of the implicit-GEMM launches (see conv_mfma.hip)
 _SK_TILES = 1 << 16
 
 
@@ -145,7 +146,11 @@ def _attach_sk_ws(d: ConvDesc, device) -> None:
         d.sk_ws, d.sk_ws_bytes = 0, 0
         return
     nbytes = int(_lib.load().erd_conv_igemm_ws_bytes(_SK_TILES))
-    ws = workspace("streamk", nbytes, device)
+    key = ("streamk", str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)    # tickets must start at zero
+        _WS[key] = ws
     d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), nbytes
 
 

@@ -68,7 +68,8 @@ typedef struct {
     const float* shift;  /* optional [Cout]: v += shift[co]  (bias / folded BN) */
     int relu;            /* v = max(v,0) last */
     /* optional stream-K workspace (>= erd_conv_igemm_ws_bytes()): lets the launch split the K loop of
-     * boundary tiles across workgroups so that all CUs finish together; NULL = one workgroup per tile. */
+     * boundary tiles across workgroups so that all CUs finish together; NULL = one workgroup per tile.
+     * The ticket area (the last max_tiles*4 bytes) must be ZERO on entry; the kernel leaves it zero. */
     void* sk_ws;
     size_t sk_ws_bytes;
 } erd_conv_desc;

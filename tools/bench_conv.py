@@ -15,7 +15,7 @@ SHAPES = [  # name, Cin, Cout, H, W, k, s
     ("L3.conv1", 1024, 256, 50, 84, 1, 1), ("L3.conv2", 256, 256, 50, 84, 3, 1), ("L3.conv3", 256, 1024, 50, 84, 1, 1),
     ("L4.conv1", 2048, 512, 25, 42, 1, 1), ("L4.conv2", 512, 512, 25, 42, 3, 1), ("L4.conv3", 512, 2048, 25, 42, 1, 1),
     ("fpn.lat3", 512, 256, 100, 168, 1, 1), ("fpn.out3", 256, 256, 100, 168, 3, 1),
-    ("head.P4", 256, 256, 50, 84, 3, 1), ("head.cls80", 256, 80, 100, 168, 3, 1), ("head.reg68", 256, 68, 100, 168, 3, 1),
+    ("head.P4", 256, 256, 50, 84, 3, 1), ("big.gemm", 2048, 2048, 128, 128, 1, 1), ("big.3x3", 256, 256, 200, 336, 3, 1), ("head.cls80", 256, 80, 100, 168, 3, 1), ("head.reg68", 256, 68, 100, 168, 3, 1),
 ]
 only = sys.argv[1:] 
 
