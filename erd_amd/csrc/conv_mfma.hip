@@ -18,12 +18,13 @@
 // Forward conv, stride-1 input-gradient and the 4 parity classes of a stride-2 input-gradient are
 // all expressed through the tap list of erd_conv_desc (include/erd_hip.h).
 #include "erd_common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;        // floats per K-slice (one 128-B row)
+constexpr int BK = 32;        // floats per K-slice of the wgrad kernel / default igemm variant
 constexpr int NTHREADS = 256;
 
 struct RowInfo {
@@ -48,20 +49,22 @@ struct SkWs {
     float* slabs;    // [2*G][BM*BN]
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
-                                                                  const SkWs ws) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW>
+__global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
+                                                                     const SkWs ws) {
     constexpr int FM = BM / (WAVES_M * 32);
     constexpr int FN = BN / (WAVES_N * 32);
-    constexpr int AJ = BM / 32;  // float4 loads per thread for A
-    constexpr int BJ = BN / 32;
-    constexpr int NACC = FM * FN * 16;
+    constexpr int CH = BKT / 4;              // 16-B chunks per K-slice row (8 for BK=32, 4 for BK=16)
+    constexpr int RPP = NTHREADS / CH;       // rows staged per pass
+    constexpr int AJ = BM / RPP;             // float4 loads per thread for A
+    constexpr int BJ = BN / RPP;
+    constexpr int BK = BKT;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*8]
-    float4* Bs = As + 2 * BM * 8;                                  // [2][BN*8]
-    RowInfo* rows = reinterpret_cast<RowInfo*>(Bs + 2 * BN * 8);   // [BM]
+    float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*CH]
+    float4* Bs = As + 2 * BM * CH;                                 // [2][BN*CH]
+    RowInfo* rows = reinterpret_cast<RowInfo*>(Bs + 2 * BN * CH);  // [BM]
     int* bcast = reinterpret_cast<int*>(rows + BM);                // [4]
 
     const int tid = threadIdx.x;
@@ -75,8 +78,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_
     const int G = gridDim.x;
     const long long u_begin = (U * blockIdx.x) / G, u_end = (U * (blockIdx.x + 1)) / G;
 
-    const int chunk = tid & 7;
-    const int r0 = tid >> 3;  // 0..31
+    const int chunk = tid % CH;
+    const int r0 = tid / CH;
+    auto swzc = [](int row, int c) { return CH == 8 ? (c ^ ((row >> 1) & 7)) : (c ^ ((row >> 2) & 3)); };
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_
         int a_off[AJ], a_ih[AJ], a_iw[AJ];
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const RowInfo ri = rows[r0 + 32 * j];
+            const RowInfo ri = rows[r0 + RPP * j];
             a_off[j] = ri.in_off + chunk * 4;
             a_ih[j] = ri.ih0;
             a_iw[j] = ri.iw0;
@@ -141,43 +145,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_
         bool b_ok[BJ];
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int co = n0 + r0 + 32 * j;
+            const int co = n0 + r0 + RPP * j;
             b_ok[j] = co < p.Cout;
             b_off[j] = (b_ok[j] ? co : 0) * p.wrow + chunk * 4;
         }
 
         float4 ra[AJ], rb[BJ];
         int tap = ks / cpt, cc = ks - tap * cpt;
-
-        auto load_global = [&]() {
-            const int dyt = p.dy[tap], dxt = p.dx[tap];
-            const int kb = p.wk[tap] + cc * BK;
-            const int cb = cc * BK;
-            const bool cok = cb + chunk * 4 < Cin;   // Cin % 4 == 0: a 16-B chunk is all-in or all-out
-#pragma unroll
-            for (int j = 0; j < AJ; ++j) {
-                const int ih = a_ih[j] + dyt, iw = a_iw[j] + dxt;
-                const bool ok = cok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
-                ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) ra[j] = *reinterpret_cast<const float4*>(in + (a_off[j] + (ih * IW + iw) * Cin + cb));
-            }
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b_ok[j] && cok) rb[j] = *reinterpret_cast<const float4*>(w + (b_off[j] + kb));
-            }
+        // wave-uniform description of the K-slice being fetched
+        int dyt = 0, dxt = 0, kb = 0, cb = 0;
+        bool cok = false;
+        auto slice_begin = [&]() {
+            dyt = p.dy[tap];
+            dxt = p.dx[tap];
+            kb = p.wk[tap] + cc * BK;
+            cb = cc * BK;
+            cok = cb + chunk * 4 < Cin;   // Cin % 4 == 0: a 16-B chunk is all-in or all-out
             if (++cc == cpt) { cc = 0; ++tap; }
+        };
+        // branch-free loads (clamped address + select) so that the scheduler can sink them between MFMAs
+        auto load_a = [&](int j) {
+            const int ih = a_ih[j] + dyt, iw = a_iw[j] + dxt;
+            const bool ok = cok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+            const int off = ok ? a_off[j] + (ih * IW + iw) * Cin + cb : 0;
+            const float4 v = *reinterpret_cast<const float4*>(in + off);
+            ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto load_b = [&](int j) {
+            const bool ok = b_ok[j] && cok;
+            const float4 v = *reinterpret_cast<const float4*>(w + (ok ? b_off[j] + kb : 0));
+            rb[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         };
         auto store_lds = [&](int buf) {
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                const int row = r0 + 32 * j;
-                As[buf * BM * 8 + row * 8 + swz(row, chunk)] = ra[j];
+                const int row = r0 + RPP * j;
+                As[buf * BM * CH + row * CH + swzc(row, chunk)] = ra[j];
             }
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
-                const int row = r0 + 32 * j;
-                Bs[buf * BN * 8 + row * 8 + swz(row, chunk)] = rb[j];
+                const int row = r0 + RPP * j;
+                Bs[buf * BN * CH + row * CH + swzc(row, chunk)] = rb[j];
             }
         };
 
@@ -189,38 +197,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const erd_conv_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        load_global();
+        slice_begin();
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) load_a(j);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) load_b(j);
         store_lds(0);
         __syncthreads();
 
+        constexpr int KSTEPS = BK / 8;
+        constexpr int APS = (AJ + KSTEPS - 1) / KSTEPS, BPS = (BJ + KSTEPS - 1) / KSTEPS;   // loads per k-step
         for (int kt = ks; kt < ke; ++kt) {
             const int buf = (kt - ks) & 1;
             const bool more = kt + 1 < ke;
-            if (more) load_global();
-            const float4* Ab = As + buf * BM * 8;
-            const float4* Bb = Bs + buf * BN * 8;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            if (more) slice_begin();
+            const float4* Ab = As + buf * BM * CH;
+            const float4* Bb = Bs + buf * BN * CH;
+            // fragment reads run one k-step ahead of the MFMAs that consume them (register double buffer)
+            float4 fa[2][FM], fb[2][FN];
+            auto read_frags = [&](int kk, int slot) {
                 const int c = 2 * kk + h;
-                float4 fa[FM], fb[FN];
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int row = (wm * FM + i) * 32 + li;
-                    fa[i] = Ab[row * 8 + swz(row, c)];
+                    fa[slot][i] = Ab[row * CH + swzc(row, c)];
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int row = (wn * FN + j) * 32 + li;
-                    fb[j] = Bb[row * 8 + swz(row, c)];
+                    fb[slot][j] = Bb[row * CH + swzc(row, c)];
+                }
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int cur = kk & 1;
+                if (kk + 1 < KSTEPS) read_frags(kk + 1, cur ^ 1);
+                // next slice's global loads, a few per k-step, issued under this step's MFMAs
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < APS; ++q)
+                        if (kk * APS + q < AJ) load_a(kk * APS + q);
+#pragma unroll
+                    for (int q = 0; q < BPS; ++q)
+                        if (kk * BPS + q < BJ) load_b(kk * BPS + q);
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
                     }
             }
             if (more) store_lds(buf ^ 1);
@@ -526,8 +555,9 @@ int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKT, int MINW>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
+    constexpr int BK = BKT;
     int tiles = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const int64_t M = (int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW;
@@ -537,8 +567,8 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     tiles *= ntn;
     if (tiles == 0) return 0;
     const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
-    const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(float4) + BM * sizeof(RowInfo) + 16;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
+    const size_t lds = (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4) + BM * sizeof(RowInfo) + 16;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -546,15 +576,15 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     }
     // persistent stream-K grid when a workspace is supplied and tile-granular dispatch would leave a
     // ragged last round; otherwise one workgroup per tile.
-    const int slots = 2 * num_cus();
+    const int slots = MINW * num_cus();
     int G = tiles;
     SkWs ws{nullptr, nullptr};
     // workspace layout (fixed, independent of this launch's tile count): [slabs: 2*slots*128*128 floats][tickets]
-    const size_t slab_bytes = (size_t)2 * slots * 128 * 128 * sizeof(float);
+    const size_t slab_bytes = (size_t)2 * 4 * num_cus() * 128 * 128 * sizeof(float);
     const size_t need = slab_bytes + (size_t)tiles * sizeof(int);
     const bool ragged = tiles < 8 * slots && (tiles % slots) != 0;
     // short K loops (1x1 convs on few channels) are latency/HBM-bound: they want many independent workgroups
-    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && nkt >= 16 && (int64_t)tiles * nkt >= slots) {
+    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && nkt * BKT >= 512 && (int64_t)tiles * nkt >= slots) {
         G = slots;
         ws.slabs = reinterpret_cast<float*>(d->sk_ws);
         ws.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(d->sk_ws) + slab_bytes);
@@ -580,12 +610,16 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
                     "conv: segment %d exceeds 2^31 elements", s);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2>(d, st);
-    return launch_igemm<128, 128, 2, 2>(d, st);
+    // Variant choice (measured, tools/bench_conv.py): long K loops are MFMA-bound and want the BK=32 / stream-K
+    // kernel; short ones (1x1 convs on <=256 channels) are prologue/epilogue-latency bound and want many small
+    // co-resident workgroups (BK=16, half the LDS and staging registers -> 4 workgroups per CU).
+    if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2>(d, st);
+    if (d->ntaps * d->Cin <= 256) return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
+    return launch_igemm<128, 128, 2, 2, 32, 2>(d, st);
 }
 
 extern "C" size_t erd_conv_igemm_ws_bytes(int max_tiles) {
-    return (size_t)2 * 2 * num_cus() * 128 * 128 * sizeof(float) + (size_t)max_tiles * sizeof(int);
+    return (size_t)2 * 4 * num_cus() * 128 * 128 * sizeof(float) + (size_t)max_tiles * sizeof(int);
 }
 
 extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {

@@ -164,26 +164,33 @@ class ERDTrainer:
     def train_step(self, inputs: Tensor, data_samples) -> Dict[str, Tensor]:
         model = self.model
         cur = torch.cuda.current_stream(self.device)
-        teacher_out = None
         if self.overlap_teacher:
-            # teacher forward of THIS batch on the side stream, concurrent with the tail of the previous
-            # step's all-reduce + SGD on the main stream
+            # The frozen teacher (forward + ERS + NMS) runs on the side stream, concurrently with (a) the tail of the
+            # previous step's gradient all-reduce + the deferred SGD launch and (b) the student's forward on the
+            # main stream: two independent kernel streams fill each other's partially filled dispatch rounds.
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side), torch.no_grad():
                 teacher_out = model.teacher_pass(inputs)
-        self._apply_pending()
-        self.flat.zero_grad()
-        if self.overlap_teacher:
+            self._apply_pending()
+            self.flat.zero_grad()
+            K.zero_arena_begin(self.device)
+            s_cls, s_bbox, sizes = model._forward_cat(inputs)
             cur.wait_stream(self.side)
             for t in teacher_out.tensors():
                 t.record_stream(cur)
-            losses = model.loss(inputs, data_samples, teacher_out=teacher_out)
+            losses = model.bbox_head.loss_cat(teacher_out.t_cls, teacher_out.t_bbox, s_cls, s_bbox, sizes, data_samples,
+                                              teacher_out.ers, teacher_out.keep, model.ori_num_classes,
+                                              model.dist_loss_weight)
         else:
+            self._apply_pending()
+            self.flat.zero_grad()
+            K.zero_arena_begin(self.device)
             losses = model(inputs, data_samples, mode="loss")
         total, log_vars = parse_losses(losses)
         if self.sync is not None:
             self.sync.arm()
         total.backward()
+        K.zero_arena_end()
         self._pending = True
         self.iter += 1
         if not self.overlap_teacher:

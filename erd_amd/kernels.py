@@ -78,6 +78,38 @@ def workspace(name: str, nbytes: int, device) -> Tensor:
     return buf
 
 
+# ---------------------------------------------------------------------------------------------
+# zero arena: the step needs a few hundred small zero-initialised accumulators (column sums, row dots, ...).
+# One memset per step over a bump-allocated arena replaces a fill launch per accumulator.
+# ---------------------------------------------------------------------------------------------
+_ARENA = {"buf": None, "off": 0, "key": None}
+
+
+def zero_arena_begin(device, nbytes: int = 8 << 20) -> None:
+    """called once per step (on the stream the step runs on) by the trainer"""
+    if _ARENA["buf"] is None or _ARENA["buf"].device != torch.device(device):
+        _ARENA["buf"] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _ARENA["buf"].zero_()
+    _ARENA["off"] = 0
+    _ARENA["key"] = torch.cuda.current_stream().cuda_stream
+
+
+def zeros_f32(n: int, device) -> Tensor:
+    """n zeroed floats: a slice of the step's arena when one is active on this stream, else torch.zeros"""
+    a = _ARENA
+    nb = (n * 4 + 255) // 256 * 256
+    if a["buf"] is None or a["key"] != torch.cuda.current_stream().cuda_stream or a["off"] + nb > a["buf"].numel() \
+            or a["buf"].device != torch.device(device):
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    out = a["buf"][a["off"]:a["off"] + n * 4].view(torch.float32)
+    a["off"] += nb
+    return out
+
+
+def zero_arena_end() -> None:
+    _ARENA["key"] = None
+
+
 def ws_float(name: str, n: int, device) -> Tensor:
     return workspace(name, n * 4, device)[: n * 4].view(torch.float32)
 
@@ -316,7 +348,7 @@ def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum
     """(dz, colsum): dz = dy*(y>0) (new buffer) or dy itself; colsum[c] = sum over pixels of dz."""
     _check_map(dy)
     N, H, W, Cc = dy.shape
-    colsum = torch.zeros(Cc, dtype=torch.float32, device=dy.device) if want_colsum else None
+    colsum = zeros_f32(Cc, dy.device) if want_colsum else None
     dz = dy
     if use_relu:
         _check_map(y)
@@ -363,8 +395,8 @@ def gn_relu_backward(c: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mr: Ten
     lv = make_levels(sizes)
     stats = workspace("gn_stats", N * lv.nseg * G * 16, c.device)
     dc = torch.empty_like(c)
-    dgamma = torch.zeros_like(gamma)
-    dbeta = torch.zeros_like(beta)
+    dgamma = zeros_f32(gamma.numel(), c.device)
+    dbeta = zeros_f32(beta.numel(), c.device)
     call("erd_gn_relu_bwd", _p(c), _p(dy), _p(gamma), _p(beta), _p(mr), _p(stats), _p(dc), _p(dgamma), _p(dbeta), N, A,
          Cc, G, C.byref(lv), _stream())
     return dc, dgamma, dbeta
