@@ -27,20 +27,68 @@ def _to_oihw(dw_ohwi: Tensor) -> Tensor:
     return dw_ohwi.permute(0, 3, 1, 2)
 
 
-_FOLD_CACHE = {}
+# ---------------------------------------------------------------------------------------------------
+# fork/join helper: the weight-gradient GEMM of a layer is independent of its input-gradient GEMM, so it is
+# enqueued on an auxiliary HIP stream; two MFMA-bound kernels in flight fill each other's ragged dispatch rounds.
+# ---------------------------------------------------------------------------------------------------
+_AUX = {}
+import os as _os
+WGRAD_ON_AUX_STREAM = _os.environ.get('ERD_WGRAD_AUX', '0') != '0'
+TOWERS_ON_TWO_STREAMS = _os.environ.get('ERD_TOWER_AUX', '1') != '0'
+
+
+_TOWER = {}
+
+
+def aux_stream(device) -> "torch.cuda.Stream":
+    """the auxiliary stream paired with the current stream (used for the head's second tower)"""
+    cur = torch.cuda.current_stream(device)
+    if not TOWERS_ON_TWO_STREAMS:
+        return cur
+    key = (str(device), cur.cuda_stream)
+    if key not in _TOWER:
+        _TOWER[key] = torch.cuda.Stream(device=device)
+    return _TOWER[key]
+
+
+class _Fork:
+    def __init__(self, device):
+        self.cur = torch.cuda.current_stream(device)
+        key = (str(device), self.cur.cuda_stream)
+        if key not in _AUX:
+            _AUX[key] = torch.cuda.Stream(device=device)
+        self.aux = _AUX[key] if WGRAD_ON_AUX_STREAM else None
+
+    def __enter__(self):
+        if self.aux is not None:
+            self.aux.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.aux)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.aux is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+    def join(self):
+        if self.aux is not None:
+            self.cur.wait_stream(self.aux)
 
 
 def _bn_fold_cached(gamma, beta, mean, var, eps):
     """folded (scale, shift) of a frozen-statistics BN; cached while gamma/beta are frozen too (teacher, stem,
-    layer1): keyed on the tensors' storage + in-place version counters, so loading a checkpoint invalidates it."""
+    layer1).  The cache lives ON the parameter object (dies with it -- a pointer-keyed table would hand a stale
+    entry to a new tensor that happens to reuse the address) and is validated against the storage pointers and
+    in-place version counters of all four tensors, so loading a checkpoint / re-homing the data invalidates it."""
     if gamma.requires_grad or beta.requires_grad:
         return K.bn_fold(gamma.detach(), beta.detach(), mean, var, eps)
-    key = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr())
-    ver = (gamma._version, beta._version, mean._version, var._version, eps)
-    hit = _FOLD_CACHE.get(key)
+    ver = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(),
+           gamma._version, beta._version, mean._version, var._version, eps)
+    hit = getattr(gamma, "_erd_fold", None)
     if hit is None or hit[0] != ver:
         hit = (ver, K.bn_fold(gamma.detach(), beta.detach(), mean, var, eps))
-        _FOLD_CACHE[key] = hit
+        gamma._erd_fold = hit
     return hit[1]
 
 
@@ -71,20 +119,24 @@ class ConvBNAct(Function):
         dz, dbeta = K.relu_bwd_colsum(out if relu else None, dy, relu, want_colsum=need_g or need_b)
         wk = ohwi(w)
         dW = dgamma = None
+        fork = _Fork(x.device)
         if need_w or need_g:
-            part, S = K.conv_wgrad_partials([x], [dz], k, stride, pad)
             dWk = torch.empty_like(wk)
             rowdot = torch.empty_like(scale) if need_g else None
-            K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
+            dgamma = torch.empty_like(scale) if need_g else None
+            with fork:
+                part, S = K.conv_wgrad_partials([x], [dz], k, stride, pad)
+                K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
+                if need_g:
+                    K.bn_dgamma(rowdot, dbeta, mean, var, eps, out=dgamma)
             dW = _to_oihw(dWk)
-            if need_g:
-                dgamma = K.bn_dgamma(rowdot, dbeta, mean, var, eps)
         dx = None
         if need_x:
             wt = K.weight_transpose(wk, scale)
             # a strided 1x1 (projection shortcut) reaches only the even pixels: the rest of dx is zero
             dx = torch.zeros_like(x) if k < stride else torch.empty_like(x)
             K.conv_dgrad([dz], wt, [dx], k, stride, pad)
+        fork.join()
         dres = dz if (has_res and ctx.needs_input_grad[6]) else None
         return dx, dW, dgamma, (dbeta if need_b else None), None, None, dres, None, None, None, None, None
 
@@ -110,16 +162,19 @@ class ConvBias(Function):
         dy = dy.contiguous()
         wk = ohwi(w)
         dW = db = dx = None
+        fork = _Fork(x.device)
         if ctx.needs_input_grad[1]:
-            part, S = K.conv_wgrad_partials([x], [dy], k, stride, pad)
             dWk = torch.empty_like(wk)
-            K.wgrad_reduce(part, S, wk, None, dWk, False, None)
+            with fork:
+                part, S = K.conv_wgrad_partials([x], [dy], k, stride, pad)
+                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
             dW = _to_oihw(dWk)
         if ctx.needs_input_grad[2]:
             db = K.colsum(dy)
         if ctx.needs_input_grad[0]:
             dx = torch.zeros_like(x) if k < stride else torch.empty_like(x)
             K.conv_dgrad([dy], K.weight_transpose(wk), [dx], k, stride, pad)
+        fork.join()
         return dx, dW, db, None, None, None
 
 
@@ -229,14 +284,17 @@ class HeadConvGN(Function):
         wk = ohwi(w)
         dW = dx = None
         xv, dv = K.level_views(x_cat, sizes), K.level_views(dc, sizes)
+        fork = _Fork(x_cat.device)
         if ctx.needs_input_grad[1]:
-            part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
             dWk = torch.empty_like(wk)
-            K.wgrad_reduce(part, S, wk, None, dWk, False, None)
+            with fork:
+                part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
+                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
             dW = _to_oihw(dWk)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x_cat)
             K.conv_dgrad(dv, K.weight_transpose(wk), K.level_views(dx, sizes), 3, 1, 1)
+        fork.join()
         return dx, dW, dgamma, dbeta, None, None
 
 
@@ -260,16 +318,19 @@ class HeadConvBias(Function):
         wk = ohwi(w)
         dW = db = dx = None
         xv, dv = K.level_views(x_cat, sizes), K.level_views(dy, sizes)
+        fork = _Fork(x_cat.device)
         if ctx.needs_input_grad[1]:
-            part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
             dWk = torch.empty_like(wk)
-            K.wgrad_reduce(part, S, wk, None, dWk, False, None)
+            with fork:
+                part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
+                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
             dW = _to_oihw(dWk)
         if ctx.needs_input_grad[2]:
             db = K.colsum(dy)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x_cat)
             K.conv_dgrad(dv, K.weight_transpose(wk), K.level_views(dx, sizes), 3, 1, 1)
+        fork.join()
         return dx, dW, db, None
 
 

@@ -359,8 +359,9 @@ def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum
     return dz, colsum
 
 
-def bn_dgamma(rowdot: Tensor, dbeta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5) -> Tensor:
-    dg = torch.empty_like(dbeta)
+def bn_dgamma(rowdot: Tensor, dbeta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5,
+              out: Optional[Tensor] = None) -> Tensor:
+    dg = torch.empty_like(dbeta) if out is None else out
     call("erd_bn_dgamma", _p(rowdot), _p(dbeta), _p(mean), _p(var), eps, _p(dg), 0, dbeta.numel(), _stream())
     return dg
 

@@ -474,15 +474,24 @@ class GFLHead(nn.Module):
         """[N,A,256] -> (cls [N,A,C], bbox [N,A,68]) : gfl_head.py:205-230 on all levels at once."""
         _gpu_only(p_cat, "GFLHead.forward")
         sizes = [tuple(s) for s in sizes]
-        c, r = p_cat, p_cat
+        # the two towers are independent: the reg tower runs on an auxiliary HIP stream (autograd replays its
+        # backward on that stream too), so both directions keep two MFMA-bound kernel streams in flight
+        cur = torch.cuda.current_stream(p_cat.device)
+        aux = Fn.aux_stream(p_cat.device)
+        aux.wait_stream(cur)
+        with torch.cuda.stream(aux):
+            r = p_cat
+            for m in self.reg_convs:
+                r = Fn.HeadConvGN.apply(r, m.conv.weight, m.gn.weight, m.gn.bias, sizes, m.gn.eps)
+            pre = Fn.HeadConvBias.apply(r, self.gfl_reg.weight, self.gfl_reg.bias, sizes)
+            alphas = torch.stack([s.scale for s in self.scales])
+            bbox = Fn.LevelScale.apply(pre, alphas, sizes)
+        c = p_cat
         for m in self.cls_convs:
             c = Fn.HeadConvGN.apply(c, m.conv.weight, m.gn.weight, m.gn.bias, sizes, m.gn.eps)
-        for m in self.reg_convs:
-            r = Fn.HeadConvGN.apply(r, m.conv.weight, m.gn.weight, m.gn.bias, sizes, m.gn.eps)
         cls = Fn.HeadConvBias.apply(c, self.gfl_cls.weight, self.gfl_cls.bias, sizes)
-        pre = Fn.HeadConvBias.apply(r, self.gfl_reg.weight, self.gfl_reg.bias, sizes)
-        alphas = torch.stack([s.scale for s in self.scales])
-        bbox = Fn.LevelScale.apply(pre, alphas, sizes)
+        cur.wait_stream(aux)
+        bbox.record_stream(cur)
         return cls, bbox
 
     def forward(self, x: Sequence[Tensor]):
