@@ -44,6 +44,14 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // contributor order (deterministic) and runs the epilogue.  With G == tiles this is plain data-parallel.
 // Why: at bs=4 most ERD layers have 0.5..4 "CU-rounds" of 128x128 tiles; tile-granular dispatch wastes
 // 10-48 % of the matrix pipes in the last round, unit-granular dispatch wastes < 1/nkt.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x7fffffffu;   // past num_records of any buffer we build: the load returns zeros
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 struct SkWs {
     int* cnt;        // [tiles] arrival tickets (zeroed before the launch)
     float* slabs;    // [2*G][BM*BN]
@@ -132,49 +140,51 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         }
         __syncthreads();
 
-        int a_off[AJ], a_ih[AJ], a_iw[AJ];
+        // per-row byte offset of tap (0,0) and a validity bit per tap: the K loop then needs one add + one select
+        // per 16-B load, and zero padding comes from the buffer's out-of-range rule (no branches, no zero fill)
+        unsigned a_base[AJ], a_mask[AJ];
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const RowInfo ri = rows[r0 + RPP * j];
-            a_off[j] = ri.in_off + chunk * 4;
-            a_ih[j] = ri.ih0;
-            a_iw[j] = ri.iw0;
+            a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk * 4) * 4u;
+            unsigned m = 0;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int ih = ri.ih0 + p.dy[t], iw = ri.iw0 + p.dx[t];
+                m |= ((unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW) ? (1u << t) : 0u;
+            }
+            a_mask[j] = m;
         }
         const int n0 = nt * BN;
-        int b_off[BJ];
-        bool b_ok[BJ];
+        unsigned b_base[BJ];
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int co = n0 + r0 + RPP * j;
-            b_ok[j] = co < p.Cout;
-            b_off[j] = (b_ok[j] ? co : 0) * p.wrow + chunk * 4;
+            b_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunk * 4) * 4u : OOB;
         }
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(w), 0, (int)((long long)p.Cout * p.wrow * 4), 0x00020000);
 
         float4 ra[AJ], rb[BJ];
         int tap = ks / cpt, cc = ks - tap * cpt;
         // wave-uniform description of the K-slice being fetched
-        int dyt = 0, dxt = 0, kb = 0, cb = 0;
+        int adelta = 0, bdelta = 0, ctap = 0;
         bool cok = false;
         auto slice_begin = [&]() {
-            dyt = p.dy[tap];
-            dxt = p.dx[tap];
-            kb = p.wk[tap] + cc * BK;
-            cb = cc * BK;
+            const int cb = cc * BK;
+            ctap = tap;
+            adelta = ((p.dy[tap] * IW + p.dx[tap]) * Cin + cb) * 4;    // bytes, relative to tap (0,0)
+            bdelta = (p.wk[tap] + cb) * 4;
             cok = cb + chunk * 4 < Cin;   // Cin % 4 == 0: a 16-B chunk is all-in or all-out
             if (++cc == cpt) { cc = 0; ++tap; }
         };
-        // branch-free loads (clamped address + select) so that the scheduler can sink them between MFMAs
         auto load_a = [&](int j) {
-            const int ih = a_ih[j] + dyt, iw = a_iw[j] + dxt;
-            const bool ok = cok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
-            const int off = ok ? a_off[j] + (ih * IW + iw) * Cin + cb : 0;
-            const float4 v = *reinterpret_cast<const float4*>(in + off);
-            ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = cok && ((a_mask[j] >> ctap) & 1u);
+            ra[j] = buf_load16(rs_in, ok ? a_base[j] + (unsigned)adelta : OOB);
         };
         auto load_b = [&](int j) {
-            const bool ok = b_ok[j] && cok;
-            const float4 v = *reinterpret_cast<const float4*>(w + (ok ? b_off[j] + kb : 0));
-            rb[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = buf_load16(rs_w, cok ? b_base[j] + (unsigned)bdelta : OOB);
         };
         auto store_lds = [&](int buf) {
 #pragma unroll
@@ -388,19 +398,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad
         }
     };
 
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dz), 0, (int)((long long)p.N * p.dz_nstride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x), 0, (int)((long long)p.N * p.x_nstride * 4), 0x00020000);
     float4 ra[AJ], rb[BJ];
-    auto load_global = [&](int slot) {
+    auto load_global = [&](int slot) {   // branch-free: zero rows come from the buffer's out-of-range rule
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int o = offs[slot * BK + ar0 + AR * j].x;
-            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o >= 0 && a_cok) ra[j] = *reinterpret_cast<const float4*>(dz + (o + a_col));
+            ra[j] = buf_load16(rs_dz, (o >= 0 && a_cok) ? (unsigned)(o + a_col) * 4u : OOB);
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int o = offs[slot * BK + br0 + BR * j].y;
-            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o >= 0 && b_cok) rb[j] = *reinterpret_cast<const float4*>(x + (o + b_col));
+            rb[j] = buf_load16(rs_x, (o >= 0 && b_cok) ? (unsigned)(o + b_col) * 4u : OOB);
         }
     };
     auto store_lds = [&](int buf) {
@@ -606,8 +618,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     for (int s = 0; s < d->nseg; ++s) {
         const erd_conv_seg& g = d->seg[s];
         ERD_REQUIRE(g.in && g.out, "conv: null tensor in segment %d", s);
-        ERD_REQUIRE((int64_t)g.N * g.in_nstride < (1ll << 31) && (int64_t)g.N * g.out_nstride < (1ll << 31),
-                    "conv: segment %d exceeds 2^31 elements", s);
+        ERD_REQUIRE((int64_t)g.N * g.in_nstride < (1ll << 29) && (int64_t)g.N * g.out_nstride < (1ll << 31),
+                    "conv: segment %d too large (input must stay below 2 GiB: 32-bit buffer byte offsets)", s);
     }
     hipStream_t st = (hipStream_t)stream;
     // Variant choice (measured, tools/bench_conv.py): long K loops are MFMA-bound and want the BK=32 / stream-K
@@ -628,8 +640,8 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "wgrad: Cin=%d Cout=%d must be multiples of 4", d->Cin, d->Cout);
     ERD_REQUIRE(d->nsplit >= 1 && d->nsplit <= 65535, "wgrad: nsplit=%d", d->nsplit);
     ERD_REQUIRE((int64_t)d->N * d->GH * d->GW < (1ll << 31), "wgrad: too many pixels");
-    ERD_REQUIRE((int64_t)d->N * d->x_nstride < (1ll << 31) && (int64_t)d->N * d->dz_nstride < (1ll << 31),
-                "wgrad: tensors exceed 2^31 elements");
+    ERD_REQUIRE((int64_t)d->N * d->x_nstride < (1ll << 29) && (int64_t)d->N * d->dz_nstride < (1ll << 29),
+                "wgrad: tensors must stay below 2 GiB (32-bit buffer byte offsets)");
     constexpr int BM = 128, BN = 128;
     const int nci = (d->Cin + BN - 1) / BN, nco = (d->Cout + BM - 1) / BM;
     const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float) + 2 * BK * sizeof(int2);
