@@ -22,7 +22,7 @@ f32 = C.c_float
 
 class ConvSeg(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("res", C.c_void_p), ("alpha", C.c_void_p),
-                ("N", i32), ("IH", i32), ("IW", i32), ("GH", i32), ("GW", i32), ("OH", i32), ("OW", i32),
+                ("mask", C.c_void_p), ("N", i32), ("IH", i32), ("IW", i32), ("GH", i32), ("GW", i32), ("OH", i32), ("OW", i32),
                 ("in_nstride", i64), ("out_nstride", i64), ("res_nstride", i64)]
 
 
@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
                 ("Cin", i32), ("Cout", i32), ("wrow", i32), ("ntaps", i32),
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS), ("wk", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
-                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32), ("colsum", C.c_void_p),
                 ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t)]
 
 

@@ -72,7 +72,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*CH]
     float4* Bs = As + 2 * BM * CH;                                 // [2][BN*CH]
-    RowInfo* rows = reinterpret_cast<RowInfo*>(Bs + 2 * BN * CH);  // [BM]
+    constexpr int OPER_BYTES = 2 * (BM + BN) * CH * 16;
+    constexpr int STAGE_BYTES = 64 * (BN + 4) * 4 + NTHREADS * 16;  // epilogue staging (+ column-sum scratch) re-uses the operand region
+    constexpr int REGION = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
+    RowInfo* rows = reinterpret_cast<RowInfo*>(smem + REGION);     // [BM]
     int* bcast = reinterpret_cast<int*>(rows + BM);                // [4]
 
     const int tid = threadIdx.x;
@@ -311,32 +314,79 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             if (tid == 0) ws.cnt[tt] = 0;   // leave the ticket zeroed for the next launch (stream-ordered)
         }
 
-        // ---- epilogue -------------------------------------------------------------------------------
+        // ---- epilogue: accumulators -> LDS (64 rows at a time) -> coalesced float4 rows --------------------
+        // A lane owns one output column, so direct stores would be 64 dword stores per lane (store-issue bound).
+        // Staging the tile through the (now idle) operand LDS turns them into 16-B stores of whole 512-B rows and
+        // lets scale/shift/residual/mask be applied on float4s.
         float* __restrict__ out = sg.out;
         const float* res = sg.res;
+        const float* msk = sg.mask;
         const float alpha = sg.alpha ? *sg.alpha : 1.f;
         const bool has_alpha = sg.alpha != nullptr;
+        float* stage = reinterpret_cast<float*>(smem);          // [64][BN + 4]
+        constexpr int SLD = BN + 4;
+        constexpr int C4N = BN / 4;                             // float4 columns of the tile
+        constexpr int RPS = NTHREADS / C4N;                     // rows stored per sweep
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int co = n0 + (wn * FN + j) * 32 + li;
-            const bool cok = co < p.Cout;
-            const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
-            const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
+        for (int half = 0; half < WAVES_M; ++half) {
+            __syncthreads();                                    // operand tiles / previous half fully consumed
+            if (wm == half) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int oo = rows[row].out_off;
-                    if (oo >= 0 && cok) {
-                        float v = acc[i][j][r];
-                        if (p.scale) v *= sc;
-                        v += sh;
-                        if (has_alpha) v *= alpha;
-                        if (res) v += res[oo + co];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        out[oo + co] = v;
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            stage[row * SLD + (wn * FN + j) * 32 + li] = acc[i][j][r];
+                        }
+            }
+            __syncthreads();
+            const int c4 = tid % C4N;
+            const int co = n0 + c4 * 4;
+            float4 csum_keep = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.Cout) {
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+                if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
+                float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int rr = tid / C4N; rr < FM * 32; rr += RPS) {
+                    const int oo = rows[half * FM * 32 + rr].out_off;
+                    if (oo < 0) continue;
+                    float4 v = *reinterpret_cast<const float4*>(stage + rr * SLD + c4 * 4);
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (has_alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
+                    if (res) {
+                        const float4 rv = *reinterpret_cast<const float4*>(res + oo + co);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (msk) {      // gradient of the ReLU that produced this tensor's forward twin (fused dz = dy*(y>0))
+                        const float4 mv = *reinterpret_cast<const float4*>(msk + oo + co);
+                        v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                        v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(out + oo + co) = v;
+                    csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+                }
+                if (p.colsum) csum_keep = csum;
+            }
+            if (p.colsum) {     // per-channel sum of what was stored (d beta of the upstream BN): LDS-combine the row
+                                // lanes, then one atomic per channel per half tile
+                float4* red = reinterpret_cast<float4*>(stage + 64 * SLD);      // [RPS][C4N], behind the staged rows
+                __syncthreads();
+                red[tid] = (co < p.Cout) ? csum_keep : make_float4(0.f, 0.f, 0.f, 0.f);
+                __syncthreads();
+                if (tid < C4N && co < p.Cout) {
+                    float4 t = red[tid];
+                    for (int q = 1; q < RPS; ++q) {
+                        const float4 v = red[q * C4N + tid];
+                        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                    }
+                    atomicAdd(p.colsum + co + 0, t.x);
+                    atomicAdd(p.colsum + co + 1, t.y);
+                    atomicAdd(p.colsum + co + 2, t.z);
+                    atomicAdd(p.colsum + co + 3, t.w);
                 }
             }
         }
@@ -579,7 +629,8 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     tiles *= ntn;
     if (tiles == 0) return 0;
     const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
-    const size_t lds = (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4) + BM * sizeof(RowInfo) + 16;
+    const size_t oper = (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4), stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
+    const size_t lds = (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16;
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {

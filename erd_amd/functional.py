@@ -141,6 +141,102 @@ class ConvBNAct(Function):
         return dx, dW, dgamma, (dbeta if need_b else None), None, None, dres, None, None, None, None, None
 
 
+class BottleneckFn(Function):
+    """A whole ResNet bottleneck (resnet.py:263-302) as ONE autograd node with a hand-scheduled backward:
+        o1 = relu(bn1(conv1 x)); o2 = relu(bn2(conv2 o1)); y = relu(bn3(conv3 o2) + shortcut(x))
+    Backward: only y's ReLU needs its own pass (its gradient has several producers); the masks of o2 / o1 and the
+    d-beta column sums are applied in the EPILOGUE of the input-gradient GEMM that produces their gradient, and the
+    identity shortcut's gradient is the residual operand of conv1's input-gradient GEMM -- no stand-alone ReLU
+    backward, no gradient-accumulation kernels inside the block."""
+
+    @staticmethod
+    def forward(ctx, x, stride: int, eps: float, *params):
+        # params: (w,g,b,mean,var) x {conv1,conv2,conv3[,downsample]}
+        has_down = len(params) == 20
+        P = [params[5 * i:5 * i + 5] for i in range(4 if has_down else 3)]
+        dev = x.device
+
+        def cba(inp, prm, k, s, pad, res, relu):
+            w, g, b, m, v = prm
+            wk = ohwi(w)
+            scale, shift = _bn_fold_cached(g, b, m, v, eps)
+            N, H, W_, _ = inp.shape
+            out = torch.empty((N, K.conv_out_size(H, k, s, pad), K.conv_out_size(W_, k, s, pad), wk.shape[0]),
+                              dtype=torch.float32, device=dev)
+            K.conv_forward([inp], wk, [out], k, s, pad, scale=scale, shift=shift,
+                           res=None if res is None else [res], relu=relu)
+            return out, scale
+
+        o1, s1 = cba(x, P[0], 1, 1, 0, None, True)
+        o2, s2 = cba(o1, P[1], 3, stride, 1, None, True)
+        sd = None
+        idn = x
+        if has_down:
+            idn, sd = cba(x, P[3], 1, stride, 0, None, False)
+        y, s3 = cba(o2, P[2], 1, 1, 0, idn, True)
+        ctx.cfg = (stride, eps, has_down)
+        ctx.save_for_backward(x, o1, o2, y, s1, s2, s3, *( [sd] if has_down else []), *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, eps, has_down = ctx.cfg
+        saved = ctx.saved_tensors
+        x, o1, o2, y, s1, s2, s3 = saved[:7]
+        off = 7
+        sd = None
+        if has_down:
+            sd = saved[7]
+            off = 8
+        params = saved[off:]
+        P = [params[5 * i:5 * i + 5] for i in range(4 if has_down else 3)]
+        need = ctx.needs_input_grad
+        need_x = need[0]
+        dev = x.device
+        grads = [None] * len(params)
+
+        def wgrad(idx, xin, dz, k, s, pad, scale, dbeta):
+            """dW (scaled by the folded BN), d gamma, d beta of conv `idx`"""
+            w, g, b, m, v = P[idx]
+            base = 3 + 5 * idx
+            if not (need[base] or need[base + 1] or need[base + 2]):
+                return
+            wk = ohwi(w)
+            part, S = K.conv_wgrad_partials([xin], [dz], k, s, pad)
+            dWk = torch.empty_like(wk)
+            rowdot = torch.empty_like(scale) if need[base + 1] else None
+            K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
+            if need[base]:
+                grads[5 * idx] = _to_oihw(dWk)
+            if need[base + 1]:
+                grads[5 * idx + 1] = K.bn_dgamma(rowdot, dbeta, m, v, eps)
+            if need[base + 2]:
+                grads[5 * idx + 2] = dbeta
+
+        dz3, db3 = K.relu_bwd_colsum(y, dy.contiguous(), True)
+        wgrad(2, o2, dz3, 1, 1, 0, s3, db3)
+        dz2 = torch.empty_like(o2)
+        db2 = K.zeros_f32(o2.shape[3], dev)
+        K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[2][0]), s3), [dz2], 1, 1, 0, relu_mask=[o2], colsum=db2)
+        wgrad(1, o1, dz2, 3, stride, 1, s2, db2)
+        dz1 = torch.empty_like(o1)
+        db1 = K.zeros_f32(o1.shape[3], dev)
+        K.conv_dgrad([dz2], K.weight_transpose(ohwi(P[1][0]), s2), [dz1], 3, stride, 1, relu_mask=[o1], colsum=db1)
+        wgrad(0, x, dz1, 1, 1, 0, s1, db1)
+        dx = None
+        if need_x:
+            dx = torch.empty_like(x)
+            wt1 = K.weight_transpose(ohwi(P[0][0]), s1)
+            if has_down:
+                K.conv_dgrad([dz1], wt1, [dx], 1, 1, 0)
+                K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[3][0]), sd), [dx], 1, stride, 0, accumulate=True)
+            else:
+                K.conv_dgrad([dz1], wt1, [dx], 1, 1, 0, res=[dz3])      # + identity gradient, in the epilogue
+        if has_down:
+            wgrad(3, x, dz3, 1, stride, 0, sd, db3)
+        return (dx, None, None, *grads)
+
+
 class ConvBias(Function):
     """y = conv(x, w) + b on one map (FPN laterals, fpn.py:177-179)."""
 

@@ -150,13 +150,19 @@ def make_levels(sizes: Sequence[Tuple[int, int]]) -> Levels:
 # ---------------------------------------------------------------------------------------------
 # convolution (forward form, input-gradient form, weight gradient)
 # ---------------------------------------------------------------------------------------------
-def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor], alpha: Optional[Tensor]):
+def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor], alpha: Optional[Tensor],
+              mask: Optional[Tensor] = None):
     _check_map(x)
     _check_map(out)
     sg.inp = x.data_ptr()
     sg.out = out.data_ptr()
     sg.res = 0 if res is None else res.data_ptr()
     sg.alpha = 0 if alpha is None else alpha.data_ptr()
+    sg.mask = 0
+    if mask is not None:
+        _check_map(mask)
+        assert mask.shape == out.shape and mask.stride(0) == out.stride(0), "mask must share the output geometry"
+        sg.mask = mask.data_ptr()
     sg.N, sg.IH, sg.IW = x.shape[0], x.shape[1], x.shape[2]
     sg.GH, sg.GW = GH, GW
     sg.OH, sg.OW = out.shape[1], out.shape[2]
@@ -216,6 +222,7 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     d.scale = 0 if scale is None else scale.data_ptr()
     d.shift = 0 if shift is None else shift.data_ptr()
     d.relu = 1 if relu else 0
+    d.colsum = 0
     _attach_sk_ws(d, w.device)
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
     _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream())
@@ -230,7 +237,8 @@ def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
 
 
 def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int, stride: int, pad: int,
-               accumulate: bool = False) -> None:
+               accumulate: bool = False, res: Optional[Sequence[Tensor]] = None,
+               relu_mask: Optional[Sequence[Tensor]] = None, colsum: Optional[Tensor] = None) -> None:
     """dxs[i] (+)= conv_transpose(dzs[i]); wt = weight_transpose(w) is [Cin,k,k,Cout].
     stride 1: one launch; stride 2: one launch per output-parity class (no zero-multiplies).
     Pixels of dx that no tap reaches (k=1, stride 2) are NOT written: pass accumulate=True on a
@@ -258,7 +266,8 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
             GW = (dx.shape[2] - px + stride - 1) // stride
             if GH <= 0 or GW <= 0:
                 skip = True
-            _fill_seg(d.seg[i], dz, dx, max(GH, 0), max(GW, 0), dx if accumulate else None, None)
+            r = dx if accumulate else (None if res is None else res[i])
+            _fill_seg(d.seg[i], dz, dx, max(GH, 0), max(GW, 0), r, None, None if relu_mask is None else relu_mask[i])
         if skip and len(dzs) == 1:
             continue
         d.w = wt.data_ptr()
@@ -270,6 +279,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.scale = 0
         d.shift = 0
         d.relu = 0
+        d.colsum = 0 if colsum is None else colsum.data_ptr()
         _attach_sk_ws(d, wt.device)
         flop = 2.0 * sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg)) * Cin * len(taps) * Cout
         _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream())

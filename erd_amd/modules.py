@@ -144,7 +144,18 @@ class Bottleneck(nn.Module):
         return Fn.ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, res,
                                   conv.k, conv.stride, conv.padding, relu, bn.eps)
 
+    def _params(self):
+        mods = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+        if self.downsample is not None:
+            mods.append((self.downsample[0], self.downsample[1]))
+        out = []
+        for c, b in mods:
+            out += [c.weight, b.weight, b.bias, b.running_mean, b.running_var]
+        return out
+
     def forward(self, x: Tensor) -> Tensor:      # NHWC map
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return Fn.BottleneckFn.apply(x, self.stride, self.bn1.eps, *self._params())
         out = self._cba(x, self.conv1, self.bn1, None, True)
         out = self._cba(out, self.conv2, self.bn2, None, True)
         identity = x

@@ -52,6 +52,8 @@ typedef struct {
     float* out;          /* [N][OH][OW][Cout], image stride out_nstride */
     const float* res;    /* optional residual, same geometry as out (may alias out) */
     const float* alpha;  /* optional device scalar multiplied in the epilogue */
+    const float* mask;   /* optional, same geometry as out: the result is zeroed where mask <= 0 (ReLU backward
+                          * of the tensor whose gradient this launch produces) */
     int N, IH, IW, GH, GW, OH, OW;
     int64_t in_nstride, out_nstride, res_nstride;
 } erd_conv_seg;
@@ -66,7 +68,8 @@ typedef struct {
     int in_stride, out_stride, oy, ox;
     const float* scale;  /* optional [Cout]: v = acc*scale[co]            */
     const float* shift;  /* optional [Cout]: v += shift[co]  (bias / folded BN) */
-    int relu;            /* v = max(v,0) last */
+    int relu;            /* v = max(v,0) */
+    float* colsum;       /* optional [Cout]: += column sums of the stored result (atomic) */
     /* optional stream-K workspace (>= erd_conv_igemm_ws_bytes()): lets the launch split the K loop of
      * boundary tiles across workgroups so that all CUs finish together; NULL = one workgroup per tile.
      * The ticket area (the last max_tiles*4 bytes) must be ZERO on entry; the kernel leaves it zero. */

@@ -137,3 +137,48 @@ def test_head_functions():
     assert relerr(g1g.grad.cpu(), g1.grad) < 2e-4 and relerr(b1g.grad.cpu(), b1.grad) < 2e-4
     assert relerr(w2g.grad.cpu(), w2.grad) < 1e-4 and relerr(b2g.grad.cpu(), b2.grad) < 1e-4
     assert relerr(alg.grad.cpu(), al.grad) < 1e-4
+
+
+@pytest.mark.parametrize("cin,planes,stride,down", [(256, 64, 1, False), (256, 128, 2, True), (512, 128, 1, False),
+                                                    (1024, 512, 2, True)])
+def test_fused_bottleneck_block(cin, planes, stride, down):
+    """the hand-scheduled bottleneck backward (ReLU masks / d-beta sums / shortcut add fused into GEMM epilogues)
+    against torch autograd of the reference block (resnet.py:263-302)."""
+    from erd_amd.modules import Bottleneck
+    if not down:
+        assert cin == planes * 4
+    N, H, W = 2, 12, 14
+    blk = Bottleneck(cin, planes, stride, down)
+    sd = {}
+    for i, (k, v) in enumerate(blk.state_dict().items()):
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            sd[k] = v
+        elif leaf == "running_var" or (leaf == "weight" and v.dim() == 1):
+            sd[k] = 0.5 + G.rand(100 + i, *v.shape)
+        elif v.dim() == 4:
+            sd[k] = G.randn(100 + i, *v.shape, scale=(2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5)
+        else:
+            sd[k] = G.randn(100 + i, *v.shape, scale=0.2)
+    blk.load_state_dict(sd)
+    blk = blk.cuda()
+    x = G.randn(90, N, cin, H, W).requires_grad_(True)
+    ref = {k: v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v for k, v in sd.items()}
+
+    def bn(t, p):
+        return F.batch_norm(t, ref[p + ".running_mean"], ref[p + ".running_var"], ref[p + ".weight"], ref[p + ".bias"],
+                            False, 0.0, 1e-5)
+    o = F.relu(bn(F.conv2d(x, ref["conv1.weight"]), "bn1"))
+    o = F.relu(bn(F.conv2d(o, ref["conv2.weight"], None, stride, 1), "bn2"))
+    o = bn(F.conv2d(o, ref["conv3.weight"]), "bn3")
+    idn = bn(F.conv2d(x, ref["downsample.0.weight"], None, stride), "downsample.1") if down else x
+    y = F.relu(o + idn)
+    dy = G.randn(91, *y.shape)
+    y.backward(dy)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    out = blk(xg)
+    assert relerr(out.detach().permute(0, 3, 1, 2).cpu(), y.detach()) < 2e-5
+    out.backward(dy.permute(0, 2, 3, 1).contiguous().cuda())
+    assert relerr(xg.grad.permute(0, 3, 1, 2).cpu(), x.grad) < 1e-4
+    for k, p in blk.named_parameters():
+        assert relerr(p.grad.cpu(), ref[k].grad) < 3e-4, k
