@@ -117,8 +117,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("ERD_FORCE_DIST") == "1":      # (the latter: exercise the RCCL path on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # 'nccl' == RCCL on ROCm
 
     from erd_amd import functional as Fn
@@ -140,7 +141,7 @@ def main():
         set_serial(True)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +172,7 @@ def main():
         ktime = K.timing_end()
         set_serial(args.serial)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss = float(log["loss"]) if log is not None else float("nan")
@@ -204,7 +205,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

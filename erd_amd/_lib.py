@@ -35,10 +35,15 @@ class ConvDesc(C.Structure):
                 ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t)]
 
 
-class WgradDesc(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p),
+class WgradSeg(C.Structure):
+    _fields_ = [("x_off", i64), ("dz_off", i64),
                 ("N", i32), ("IH", i32), ("IW", i32), ("GH", i32), ("GW", i32), ("OH", i32), ("OW", i32),
-                ("x_nstride", i64), ("dz_nstride", i64),
+                ("x_nstride", i64), ("dz_nstride", i64)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p), ("x_elems", i64), ("dz_elems", i64),
+                ("nseg", i32), ("seg", WgradSeg * ERD_MAX_SEG),
                 ("Cin", i32), ("Cout", i32), ("ntaps", i32),
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),

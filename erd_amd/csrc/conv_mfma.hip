@@ -413,8 +413,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad
     const int tap = blockIdx.x / nci;
     const int ci0 = (blockIdx.x % nci) * BN;
     const int co0 = blockIdx.y * BM;
-    const int GHW = p.GH * p.GW;
-    const int P = p.N * GHW;
+    int P = 0;
+    for (int l = 0; l < p.nseg; ++l) P += p.seg[l].N * p.seg[l].GH * p.seg[l].GW;
     const int nkt_total = (P + BK - 1) / BK;
     const int per = (nkt_total + gridDim.z - 1) / gridDim.z;
     const int kt_begin = blockIdx.z * per;
@@ -432,26 +432,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad
     // pixel -> element offsets of one K-slice, computed once by 32 threads (the divisions live here only)
     auto compute_offsets = [&](int kt, int slot) {
         if (tid < BK) {
-            const int pp = kt * BK + tid;
+            int pp = kt * BK + tid;
             int2 o = make_int2(-1, -1);
             if (pp < P && kt < kt_end) {
+                int l = 0;
+#pragma unroll 1
+                for (; l < p.nseg - 1; ++l) {      // which map does this pixel of the concatenated K axis belong to
+                    const int pl = p.seg[l].N * p.seg[l].GH * p.seg[l].GW;
+                    if (pp < pl) break;
+                    pp -= pl;
+                }
+                const erd_wgrad_seg& g = p.seg[l];
+                const int GHW = g.GH * g.GW;
                 const int n = pp / GHW;
                 const int rem = pp - n * GHW;
-                const int a = rem / p.GW;
-                const int b = rem - a * p.GW;
-                o.x = (int)(n * p.dz_nstride) + ((a * p.out_stride + p.oy) * p.OW + (b * p.out_stride + p.ox)) * p.Cout;
+                const int a = rem / g.GW;
+                const int b = rem - a * g.GW;
+                o.x = (int)(g.dz_off + n * g.dz_nstride) +
+                      ((a * p.out_stride + p.oy) * g.OW + (b * p.out_stride + p.ox)) * p.Cout;
                 const int ih = a * p.in_stride + dyt, iw = b * p.in_stride + dxt;
-                if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
-                    o.y = (int)(n * p.x_nstride) + (ih * p.IW + iw) * p.Cin;
+                if ((unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW)
+                    o.y = (int)(g.x_off + n * g.x_nstride) + (ih * g.IW + iw) * p.Cin;
             }
             offs[slot * BK + tid] = o;
         }
     };
 
     const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(dz), 0, (int)((long long)p.N * p.dz_nstride * 4), 0x00020000);
+        const_cast<float*>(dz), 0, (int)(p.dz_elems * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x), 0, (int)((long long)p.N * p.x_nstride * 4), 0x00020000);
+        const_cast<float*>(x), 0, (int)(p.x_elems * 4), 0x00020000);
     float4 ra[AJ], rb[BJ];
     auto load_global = [&](int slot) {   // branch-free: zero rows come from the buffer's out-of-range rule
 #pragma unroll
@@ -676,8 +686,18 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     // Variant choice (measured, tools/bench_conv.py): long K loops are MFMA-bound and want the BK=32 / stream-K
     // kernel; short ones (1x1 convs on <=256 channels) are prologue/epilogue-latency bound and want many small
     // co-resident workgroups (BK=16, half the LDS and staging registers -> 4 workgroups per CU).
+    static const int variant = getenv("ERD_IGEMM_VARIANT") ? atoi(getenv("ERD_IGEMM_VARIANT")) : 0;   // tuning aid
+    if (variant == 9) return launch_igemm<128, 128, 2, 2, 32, 1>(d, st);
+    if (variant == 1) return launch_igemm<128, 128, 2, 2, 16, 3>(d, st);
+    if (variant == 2) return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
     if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2>(d, st);
-    if (d->ntaps * d->Cin <= 256) return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
+    int64_t mtiles = 0;
+    for (int s = 0; s < d->nseg; ++s) mtiles += ((int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW + 127) / 128;
+    const int64_t tiles = mtiles * ((d->Cout + 127) / 128);
+    // short K loops, or so many tiles that tile-granular dispatch is already balanced: four small workgroups per
+    // CU hide each other's staging/barrier phases best (measured 136 vs 131 TF on 8192 tiles x K=2048)
+    if (d->ntaps * d->Cin <= 256 || tiles >= 16 * 2 * num_cus())
+        return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
     return launch_igemm<128, 128, 2, 2, 32, 2>(d, st);
 }
 
@@ -690,8 +710,11 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d->ntaps >= 1 && d->ntaps <= ERD_MAX_TAPS, "wgrad: ntaps=%d", d->ntaps);
     ERD_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "wgrad: Cin=%d Cout=%d must be multiples of 4", d->Cin, d->Cout);
     ERD_REQUIRE(d->nsplit >= 1 && d->nsplit <= 65535, "wgrad: nsplit=%d", d->nsplit);
-    ERD_REQUIRE((int64_t)d->N * d->GH * d->GW < (1ll << 31), "wgrad: too many pixels");
-    ERD_REQUIRE((int64_t)d->N * d->x_nstride < (1ll << 29) && (int64_t)d->N * d->dz_nstride < (1ll << 29),
+    ERD_REQUIRE(d->nseg >= 1 && d->nseg <= ERD_MAX_SEG, "wgrad: nseg=%d", d->nseg);
+    int64_t npix = 0;
+    for (int l = 0; l < d->nseg; ++l) npix += (int64_t)d->seg[l].N * d->seg[l].GH * d->seg[l].GW;
+    ERD_REQUIRE(npix < (1ll << 31), "wgrad: too many pixels");
+    ERD_REQUIRE(d->x_elems > 0 && d->dz_elems > 0 && d->x_elems < (1ll << 29) && d->dz_elems < (1ll << 29),
                 "wgrad: tensors must stay below 2 GiB (32-bit buffer byte offsets)");
     constexpr int BM = 128, BN = 128;
     const int nci = (d->Cin + BN - 1) / BN, nco = (d->Cout + BM - 1) / BM;

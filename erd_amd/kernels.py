@@ -292,33 +292,48 @@ def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
     return int(max(1, min(want, kt // 8 if kt >= 8 else 1, 512)))
 
 
+def _extent(t: Tensor):
+    """(base data_ptr, element count) of the allocation slice a strided map spans"""
+    last = sum((sz - 1) * st for sz, st in zip(t.shape, t.stride()))
+    return t.data_ptr(), last + 1
+
+
 def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, stride: int, pad: int):
-    """returns (part [S_total, Cout, k*k, Cin], S_total): split-K partial slabs over all segments."""
+    """returns (part [S, Cout, k*k, Cin], S): split-K partial slabs.  All segments (maps sharing the weights, e.g.
+    the head's five levels) are summed in ONE launch: their pixels are concatenated along the GEMM K axis."""
     _require_gpu(*xs, *dzs)
     Cin, Cout = xs[0].shape[3], dzs[0].shape[3]
-    splits = [_pick_nsplit(dz.shape[0] * dz.shape[1] * dz.shape[2], Cout, Cin, k * k) for dz in dzs]
-    S = sum(splits)
+    npix = sum(dz.shape[0] * dz.shape[1] * dz.shape[2] for dz in dzs)
+    S = _pick_nsplit(npix, Cout, Cin, k * k)
     slab = Cout * k * k * Cin
     part = ws_float("wgrad_part", S * slab, xs[0].device)
-    off = 0
-    for x, dz, ns in zip(xs, dzs, splits):
+    xb = min(x.data_ptr() for x in xs)
+    zb = min(z.data_ptr() for z in dzs)
+    d = WgradDesc()
+    d.x, d.dz = xb, zb
+    xe = ze = 0
+    d.nseg = len(xs)
+    for i, (x, dz) in enumerate(zip(xs, dzs)):
         _check_map(x)
         _check_map(dz)
-        d = WgradDesc()
-        d.x, d.dz = x.data_ptr(), dz.data_ptr()
-        d.N, d.IH, d.IW = x.shape[0], x.shape[1], x.shape[2]
-        d.GH, d.GW, d.OH, d.OW = dz.shape[1], dz.shape[2], dz.shape[1], dz.shape[2]
-        d.x_nstride, d.dz_nstride = x.stride(0), dz.stride(0)
-        d.Cin, d.Cout, d.ntaps = Cin, Cout, k * k
-        for kh in range(k):
-            for kw in range(k):
-                d.dy[kh * k + kw], d.dx[kh * k + kw] = kh - pad, kw - pad
-        d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
-        d.part = part.data_ptr() + off * slab * 4
-        d.nsplit = ns
-        flop = 2.0 * dz.shape[0] * dz.shape[1] * dz.shape[2] * Cout * Cin * k * k
-        _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream())
-        off += ns
+        sg = d.seg[i]
+        px, nx = _extent(x)
+        pz, nz = _extent(dz)
+        sg.x_off, sg.dz_off = (px - xb) // 4, (pz - zb) // 4
+        xe, ze = max(xe, sg.x_off + nx), max(ze, sg.dz_off + nz)
+        sg.N, sg.IH, sg.IW = x.shape[0], x.shape[1], x.shape[2]
+        sg.GH, sg.GW, sg.OH, sg.OW = dz.shape[1], dz.shape[2], dz.shape[1], dz.shape[2]
+        sg.x_nstride, sg.dz_nstride = x.stride(0), dz.stride(0)
+    d.x_elems, d.dz_elems = xe, ze
+    d.Cin, d.Cout, d.ntaps = Cin, Cout, k * k
+    for kh in range(k):
+        for kw in range(k):
+            d.dy[kh * k + kw], d.dx[kh * k + kw] = kh - pad, kw - pad
+    d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
+    d.part = part.data_ptr()
+    d.nsplit = S
+    flop = 2.0 * npix * Cout * Cin * k * k
+    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream())
     return part, S
 
 

@@ -85,12 +85,22 @@ size_t erd_conv_igemm_ws_bytes(int max_tiles);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
+ * Up to ERD_MAX_SEG feature maps that share the weights (the head's five levels) are summed in ONE
+ * launch: their pixels are concatenated along K; every segment is given by element offsets from the
+ * common base pointers x / dz (the level-concatenated buffers).
  * replaces: convolution_backward (weight grad) of the same call sites. */
 typedef struct {
-    const float* x;      /* [N][IH][IW][Cin] */
-    const float* dz;     /* [N][OH][OW][Cout], read at (a*out_stride+oy, b*out_stride+ox) */
+    int64_t x_off, dz_off;   /* element offsets of this map inside x / dz */
     int N, IH, IW, GH, GW, OH, OW;
     int64_t x_nstride, dz_nstride;
+} erd_wgrad_seg;
+
+typedef struct {
+    const float* x;      /* base of the input maps  [N][IH][IW][Cin] */
+    const float* dz;     /* base of the output-gradient maps [N][OH][OW][Cout], read at (a*out_stride+oy, ...) */
+    int64_t x_elems, dz_elems;   /* extent of the two allocations (for the buffer descriptors) */
+    int nseg;
+    erd_wgrad_seg seg[ERD_MAX_SEG];
     int Cin, Cout, ntaps;
     int dy[ERD_MAX_TAPS], dx[ERD_MAX_TAPS];
     int in_stride, out_stride, oy, ox;
