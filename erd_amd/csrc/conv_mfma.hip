@@ -397,8 +397,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 // weight gradient: G[co][t][ci] = sum_p dz[p][co] * x[p+tap t][ci]; K = pixels (split over gridDim.z)
 // LDS tiles are k-major ([32 px][128 ch], exactly the global layout); fragments by ds_read_b32.
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const erd_wgrad_desc p) {
+template <int BM, int BN, int BKW, int MINW>
+__global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wgrad_desc p) {
+    constexpr int BK = BKW;            // pixels per K-slice
     constexpr int FM = BM / 64, FN = BN / 64;  // 2x2 waves
     constexpr int AC = BM / 4, BC = BN / 4;    // float4 chunks per row
     constexpr int AJ = (BK * AC) / NTHREADS, BJ = (BK * BC) / NTHREADS;
@@ -701,6 +702,23 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     return launch_igemm<128, 128, 2, 2, 32, 2>(d, st);
 }
 
+namespace {
+template <int BKW, int MINW>
+int launch_wgrad(const erd_wgrad_desc* d, hipStream_t st) {
+    constexpr int BM = 128, BN = 128;
+    const int nci = (d->Cin + BN - 1) / BN, nco = (d->Cout + BM - 1) / BM;
+    const size_t lds = (size_t)2 * BKW * (BM + BN) * sizeof(float) + 2 * BKW * sizeof(int2);
+    auto kern = conv_wgrad_kernel<BM, BN, BKW, MINW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nci * d->ntaps, nco, d->nsplit), dim3(NTHREADS), lds, st, *d);
+    return erd::check_launch("conv_wgrad");
+}
+}  // namespace
+
 extern "C" size_t erd_conv_igemm_ws_bytes(int max_tiles) {
     return (size_t)2 * 4 * num_cus() * 128 * 128 * sizeof(float) + (size_t)max_tiles * sizeof(int);
 }
@@ -716,17 +734,11 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(npix < (1ll << 31), "wgrad: too many pixels");
     ERD_REQUIRE(d->x_elems > 0 && d->dz_elems > 0 && d->x_elems < (1ll << 29) && d->dz_elems < (1ll << 29),
                 "wgrad: tensors must stay below 2 GiB (32-bit buffer byte offsets)");
-    constexpr int BM = 128, BN = 128;
-    const int nci = (d->Cin + BN - 1) / BN, nco = (d->Cout + BM - 1) / BM;
-    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float) + 2 * BK * sizeof(int2);
-    auto kern = conv_wgrad_kernel<BM, BN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(nci * d->ntaps, nco, d->nsplit), dim3(NTHREADS), lds, (hipStream_t)stream, *d);
-    return erd::check_launch("conv_wgrad");
+    // K-slices of 16 pixels: half the LDS / staging registers of a 32-pixel slice -> four workgroups per CU hide each
+    // other's staging and barrier phases (measured +10 % over 32-pixel slices at two per CU, tools/bench_conv.py)
+    static const int variant = getenv("ERD_WGRAD_VARIANT") ? atoi(getenv("ERD_WGRAD_VARIANT")) : 1;   // tuning aid
+    if (variant == 0) return launch_wgrad<32, 2>(d, (hipStream_t)stream);
+    return launch_wgrad<16, 4>(d, (hipStream_t)stream);
 }
 
 extern "C" int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, const float* w,

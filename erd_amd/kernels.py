@@ -288,7 +288,8 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * ntaps
     kt = (npix + 31) // 32
-    want = max(1, (1024 + tiles - 1) // tiles)          # ~4 blocks per CU
+    target = 1024 if _os.environ.get("ERD_WGRAD_VARIANT", "1") == "0" else 2048
+    want = max(1, (target + tiles - 1) // tiles)          # two dispatch rounds of 4 workgroups per CU
     return int(max(1, min(want, kt // 8 if kt >= 8 else 1, 512)))
 
 
