@@ -55,7 +55,13 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
 struct SkWs {
     int* cnt;        // [tiles] arrival tickets (zeroed before the launch)
     float* slabs;    // [2*G][BM*BN]
+    int xcd_order;   // 1: XCD-aware work order (default); 0: dispatch order (A/B aid, ERD_XCD=0)
 };
+
+int xcd_order_enabled() {
+    static const int v = getenv("ERD_XCD") ? atoi(getenv("ERD_XCD")) : 1;
+    return v;
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW>
 __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
@@ -87,7 +93,15 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 
     const long long U = (long long)total_tiles * nkt;
     const int G = gridDim.x;
-    const long long u_begin = (U * blockIdx.x) / G, u_end = (U * (blockIdx.x + 1)) / G;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Give every XCD one CONTIGUOUS
+    // chunk of the work list, so that the N-tiles of one pixel tile and spatially adjacent pixel tiles (3x3 halo)
+    // hit the same L2 instead of being fetched through the fabric by up to 8 of them.  Bijective for any G.
+    int wg = blockIdx.x;
+    if (ws.xcd_order) {
+        const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long u_begin = (U * wg) / G, u_end = (U * (wg + 1)) / G;
 
     const int chunk = tid % CH;
     const int r0 = tid / CH;
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             const int last_b = (int)(((t0 + nkt) * G - 1) / U);
             const int ncontrib = last_b - first_b + 1;
             const int my_slot = (tt == (int)(u_begin / nkt)) ? 0 : 1;
-            float* slab = ws.slabs + ((size_t)(2 * blockIdx.x + my_slot)) * (BM * BN);
+            float* slab = ws.slabs + ((size_t)(2 * wg + my_slot)) * (BM * BN);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 // LDS tiles are k-major ([32 px][128 ch], exactly the global layout); fragments by ds_read_b32.
 // -------------------------------------------------------------------------------------------------
 template <int BM, int BN, int BKW, int MINW>
-__global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wgrad_desc p) {
+__global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wgrad_desc p, const int xcd_order) {
     constexpr int BK = BKW;            // pixels per K-slice
     constexpr int FM = BM / 64, FN = BN / 64;  // 2x2 waves
     constexpr int AC = BM / 4, BC = BN / 4;    // float4 chunks per row
@@ -411,14 +425,24 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wg
 
     const int tid = threadIdx.x;
     const int nci = (p.Cin + BN - 1) / BN;
-    const int tap = blockIdx.x / nci;
-    const int ci0 = (blockIdx.x % nci) * BN;
-    const int co0 = blockIdx.y * BM;
+    // 1-D grid; consecutive workgroups = the (tap, ci-tile, co-tile) combinations of one pixel range (split).  Left in
+    // dispatch order (spread over the 8 XCDs): pinning a split to one XCD's L2 measured 3-20 % SLOWER here (36
+    // workgroups hammering the same L2 lines), unlike the igemm kernel (ERD_XCD=2 re-enables it for A/B runs).
+    int wg = blockIdx.x;
+    if (xcd_order) {
+        const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nxb = nci * p.ntaps, nyb = (p.Cout + BM - 1) / BM;
+    const int bx = wg % nxb, by = (wg / nxb) % nyb, bz = wg / (nxb * nyb);
+    const int tap = bx / nci;
+    const int ci0 = (bx % nci) * BN;
+    const int co0 = by * BM;
     int P = 0;
     for (int l = 0; l < p.nseg; ++l) P += p.seg[l].N * p.seg[l].GH * p.seg[l].GW;
     const int nkt_total = (P + BK - 1) / BK;
-    const int per = (nkt_total + gridDim.z - 1) / gridDim.z;
-    const int kt_begin = blockIdx.z * per;
+    const int per = (nkt_total + p.nsplit - 1) / p.nsplit;
+    const int kt_begin = bz * per;
     const int kt_end = min(nkt_total, kt_begin + per);
     const int dyt = p.dy[tap], dxt = p.dx[tap];
     const float* __restrict__ x = p.x;
@@ -529,7 +553,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wg
         }
     }
     // partial slab [z][Cout][ntaps][Cin]
-    float* __restrict__ part = p.part + (int64_t)blockIdx.z * p.Cout * p.ntaps * p.Cin;
+    float* __restrict__ part = p.part + (int64_t)bz * p.Cout * p.ntaps * p.Cin;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int ci = ci0 + (wn * FN + j) * 32 + li;
@@ -652,7 +676,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     // ragged last round; otherwise one workgroup per tile.
     const int slots = MINW * num_cus();
     int G = tiles;
-    SkWs ws{nullptr, nullptr};
+    SkWs ws{nullptr, nullptr, xcd_order_enabled()};
     // workspace layout (fixed, independent of this launch's tile count): [slabs: 2*slots*128*128 floats][tickets]
     const size_t slab_bytes = (size_t)2 * 4 * num_cus() * 128 * 128 * sizeof(float);
     const size_t need = slab_bytes + (size_t)tiles * sizeof(int);
@@ -714,7 +738,7 @@ int launch_wgrad(const erd_wgrad_desc* d, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nci * d->ntaps, nco, d->nsplit), dim3(NTHREADS), lds, st, *d);
+    hipLaunchKernelGGL(kern, dim3(nci * d->ntaps * nco * d->nsplit), dim3(NTHREADS), lds, st, *d, xcd_order_enabled() == 2 ? 1 : 0);
     return erd::check_launch("conv_wgrad");
 }
 }  // namespace
