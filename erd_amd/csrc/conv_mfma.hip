@@ -19,12 +19,14 @@
 // all expressed through the tap list of erd_conv_desc (include/erd_hip.h).
 #include "erd_common.h"
 #include <stdlib.h>
+#ifndef ERD_SGB
+#define ERD_SGB 0
+#endif
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;        // floats per K-slice of the wgrad kernel / default igemm variant
 constexpr int NTHREADS = 256;
 
 struct RowInfo {
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     constexpr int AJ = BM / RPP;             // float4 loads per thread for A
     constexpr int BJ = BN / RPP;
     constexpr int BK = BKT;
+    constexpr bool SGB = ERD_SGB;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -278,6 +281,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
                     }
+                if (SGB) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);      // DS reads of the next step first
+                    __builtin_amdgcn_sched_group_barrier(0x20, APS + BPS, 0);     // then the next slice's VMEM reads
+                    __builtin_amdgcn_sched_group_barrier(0x8, FM * FN * 4, 0);    // then this step's MFMAs
+                }
             }
             if (more) store_lds(buf ^ 1);
             __syncthreads();
