@@ -214,7 +214,8 @@ __global__ void bn_dgamma_kernel(const float* __restrict__ rowdot, const float* 
 // stats_ws: double [N][nseg][G][2] (sum, sumsq) accumulated with f64 atomics, then folded to
 // mean_rstd float [N][nseg][G][2].
 // ------------------------------------------------------------------------------------------------
-constexpr int GN_ROWS = 128;  // rows per block
+constexpr int GN_ROWS = 128;       // rows per block of the streaming (apply) kernels
+constexpr int GN_STAT_ROWS = 512;  // rows per block of the statistics kernels (fewer atomics per byte)
 
 __device__ __forceinline__ int find_level(const erd_levels& lv, int64_t a) {
     int s = 0;
@@ -231,13 +232,13 @@ struct GnChunks {
     int start[ERD_MAX_SEG + 1];
 };
 __device__ __forceinline__ void gn_chunk(const erd_levels& lv, const GnChunks& ch, int bx, int& s, int64_t& r0,
-                                         int64_t& r1) {
+                                         int64_t& r1, int rows = GN_ROWS) {
     s = 0;
 #pragma unroll 1
     for (; s < ch.nseg - 1; ++s)
         if (bx < ch.start[s + 1]) break;
-    r0 = lv.off[s] + (int64_t)(bx - ch.start[s]) * GN_ROWS;
-    r1 = min(lv.off[s] + lv.cnt[s], r0 + GN_ROWS);
+    r0 = lv.off[s] + (int64_t)(bx - ch.start[s]) * rows;
+    r1 = min(lv.off[s] + lv.cnt[s], r0 + rows);
 }
 
 template <int C, int G>
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     static_assert(CPG == 8 && C4 == 64, "tuned for C=256, G=32");
     const int n = blockIdx.y;
     int s; int64_t r0, r1;
-    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1, GN_STAT_ROWS);
     const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 4 row lanes
     float sum = 0.f, sq = 0.f;
     for (int64_t r = r0 + rl; r < r1; r += 4) {
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
                                                            GnChunks ch) {
     const int n = blockIdx.y;
     int s; int64_t r0, r1;
-    gn_chunk(lv, ch, blockIdx.x, s, r0, r1);
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1, GN_STAT_ROWS);
     const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int g = c4 >> 1;
     const float2 mr = *reinterpret_cast<const float2*>(mean_rstd + (((int64_t)n * lv.nseg + s) * G + g) * 2);
@@ -409,13 +410,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     }
 }
 
-GnChunks make_chunks(const erd_levels* lv) {
+GnChunks make_chunks(const erd_levels* lv, int rows = GN_ROWS) {
     GnChunks ch;
     ch.nseg = lv->nseg;
     int acc = 0;
     for (int s = 0; s < lv->nseg; ++s) {
         ch.start[s] = acc;
-        acc += (int)((lv->cnt[s] + GN_ROWS - 1) / GN_ROWS);
+        acc += (int)((lv->cnt[s] + rows - 1) / rows);
     }
     ch.start[lv->nseg] = acc;
     for (int s = lv->nseg + 1; s <= ERD_MAX_SEG; ++s) ch.start[s] = acc;
@@ -598,9 +599,10 @@ extern "C" int erd_gn_relu_fwd(const float* c, float* y, const float* gamma, con
     ERD_REQUIRE(C == 256 && G == 32, "gn_fwd: only C=256,G=32 (gfl_head.py:109-110) is built");
     hipStream_t st = (hipStream_t)stream;
     const GnChunks ch = make_chunks(lv);
+    const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
-    hipLaunchKernelGGL((gn_stats_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, stats_ws, A, *lv, ch);
+    hipLaunchKernelGGL((gn_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N), dim3(256), 0, st, c, stats_ws, A, *lv, chs);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nst + 255) / 256), dim3(256), 0, st, stats_ws, mean_rstd, N, G, *lv,
                        C / G, eps);
     hipLaunchKernelGGL((gn_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, y, gamma, beta,
@@ -615,10 +617,11 @@ extern "C" int erd_gn_relu_bwd(const float* c, const float* dy, const float* gam
     ERD_REQUIRE(C == 256 && G == 32, "gn_bwd: only C=256,G=32 is built");
     hipStream_t st = (hipStream_t)stream;
     const GnChunks ch = make_chunks(lv);
+    const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
-    hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
-                       beta, mean_rstd, stats_ws, dgamma, dbeta, A, *lv, ch);
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
+                       beta, mean_rstd, stats_ws, dgamma, dbeta, A, *lv, chs);
     hipLaunchKernelGGL((gn_bwd_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
                        beta, mean_rstd, stats_ws, dc, A, *lv, ch);
     return erd::check_launch("gn_relu_bwd");

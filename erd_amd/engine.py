@@ -170,7 +170,7 @@ class ERDTrainer:
             # main stream: two independent kernel streams fill each other's partially filled dispatch rounds.
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side), torch.no_grad():
-                teacher_out = model.teacher_pass(inputs)
+                teacher_out = model.teacher_pass(inputs, data_samples)
             self._apply_pending()
             self.flat.zero_grad()
             K.zero_arena_begin(self.device)
@@ -180,7 +180,7 @@ class ERDTrainer:
                 t.record_stream(cur)
             losses = model.bbox_head.loss_cat(teacher_out.t_cls, teacher_out.t_bbox, s_cls, s_bbox, sizes, data_samples,
                                               teacher_out.ers, teacher_out.keep, model.ori_num_classes,
-                                              model.dist_loss_weight)
+                                              model.dist_loss_weight, targets=teacher_out.targets)
         else:
             self._apply_pending()
             self.flat.zero_grad()

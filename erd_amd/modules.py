@@ -575,9 +575,11 @@ class GFLHeadIncrementERD(GFLHead):
         self.loss_ld = MODELS.build(loss_ld)
 
     def loss_cat(self, t_cls, t_bbox, s_cls, s_bbox, sizes, batch_data_samples, ers: dict, keep: Tensor,
-                 ori_num_classes: int, dist_loss_weight: float) -> dict:
-        gts, _, metas = unpack_gt_instances(batch_data_samples)
-        t = self._targets(sizes, gts, metas, s_cls.device)
+                 ori_num_classes: int, dist_loss_weight: float, targets: Optional[SimpleNamespace] = None) -> dict:
+        if targets is None:
+            gts, _, metas = unpack_gt_instances(batch_data_samples)
+            targets = self._targets(sizes, gts, metas, s_cls.device)
+        t = targets
         t.c_old, t.distill = int(ori_num_classes), True
         t.t_cls, t.t_bbox, t.ers, t.keep = t_cls, t_bbox, ers, keep
         t.lw_ld, t.T, t.dist_loss_weight = self.loss_ld.loss_weight, float(self.loss_ld.T), float(dist_loss_weight)
@@ -786,14 +788,19 @@ class GFLIncrementERD(GFL):
         ib = [r["idx_bbox"][i, :int(cnt[i, 1])] for i in range(tc.shape[0])]
         return ic, [tc[i][ic[i]] for i in range(len(ic))], ib, [tb[i][ib[i]] for i in range(len(ib))]
 
-    def teacher_pass(self, batch_inputs: Tensor) -> "TeacherOut":
-        """the no-grad half of `loss` (:205-208): teacher forward, ERS, and the NMS of the selected teacher
-        boxes.  Independent of the student's parameters, so the trainer may run it on a side stream."""
+    def teacher_pass(self, batch_inputs: Tensor, batch_data_samples=None) -> "TeacherOut":
+        """the no-grad half of `loss` (:205-208): teacher forward, ERS, the NMS of the selected teacher boxes and
+        (when the data samples are given) the ATSS targets -- everything that does not depend on the student's
+        parameters, so the trainer runs it on a side stream."""
         t_cls, t_bbox, sizes = self.ori_model._forward_cat(batch_inputs)
         ers = self.sel_pos_cat(t_cls, t_bbox)
         anchors = self.bbox_head.prior_generator.grid_priors_cat(sizes, t_cls.device)
         keep, kcnt = K.distill_nms(t_cls, t_bbox, anchors, ers["idx_bbox"], ers["counts"], 0.005)
-        return TeacherOut(t_cls, t_bbox, sizes, ers, keep, kcnt)
+        out = TeacherOut(t_cls, t_bbox, sizes, ers, keep, kcnt)
+        if batch_data_samples is not None:
+            gts, _, metas = unpack_gt_instances(batch_data_samples)
+            out.targets = self.bbox_head._targets(sizes, gts, metas, t_cls.device)
+        return out
 
     def loss(self, batch_inputs: Tensor, batch_data_samples, teacher_out: Optional["TeacherOut"] = None) -> dict:
         """:202-220: teacher fwd -> ERS (+ NMS) -> student fwd -> losses."""
@@ -803,15 +810,19 @@ class GFLIncrementERD(GFL):
         t = teacher_out
         s_cls, s_bbox, sizes = self._forward_cat(batch_inputs)
         return self.bbox_head.loss_cat(t.t_cls, t.t_bbox, s_cls, s_bbox, sizes, batch_data_samples, t.ers, t.keep,
-                                       self.ori_num_classes, self.dist_loss_weight)
+                                       self.ori_num_classes, self.dist_loss_weight, targets=t.targets)
 
 
 class TeacherOut:
     def __init__(self, t_cls, t_bbox, sizes, ers, keep, keep_count):
         self.t_cls, self.t_bbox, self.sizes, self.ers, self.keep, self.keep_count = t_cls, t_bbox, sizes, ers, keep, keep_count
+        self.targets: Optional[SimpleNamespace] = None
 
     def tensors(self) -> List[Tensor]:
-        return [self.t_cls, self.t_bbox, self.keep, self.keep_count] + list(self.ers.values())
+        out = [self.t_cls, self.t_bbox, self.keep, self.keep_count] + list(self.ers.values())
+        if self.targets is not None:
+            out += [v for v in vars(self.targets).values() if isinstance(v, torch.Tensor)]
+        return out
 
 
 def parse_losses(losses: Dict[str, Union[Tensor, List[Tensor]]]) -> Tuple[Tensor, Dict[str, Tensor]]:
