@@ -298,13 +298,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             const int last_b = (int)(((t0 + nkt) * G - 1) / U);
             const int ncontrib = last_b - first_b + 1;
             const int my_slot = (tt == (int)(u_begin / nkt)) ? 0 : 1;
-            float* slab = ws.slabs + ((size_t)(2 * wg + my_slot)) * (BM * BN);
+            // slab layout: float4 q = (fragment, register quad) of lane tid at [q][tid]: 16-B stores/loads, coalesced
+            float4* slab = reinterpret_cast<float4*>(ws.slabs + ((size_t)(2 * wg + my_slot)) * (BM * BN));
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) slab[((i * FN + j) * 16 + r) * NTHREADS + tid] = acc[i][j][r];
+                    for (int g = 0; g < 4; ++g)
+                        slab[((i * FN + j) * 4 + g) * NTHREADS + tid] = make_float4(
+                            acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
@@ -316,22 +319,34 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             }
             __syncthreads();
             if (bcast[0] != ncontrib - 1) continue;   // somebody else finishes this tile
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            for (int c = 0; c < ncontrib; ++c) {
-                const int bb = first_b + c;
-                const int bfirst_tile = (int)(((U * bb) / G) / nkt);
-                const float* sl = ws.slabs + ((size_t)(2 * bb + (tt == bfirst_tile ? 0 : 1))) * (BM * BN);
+            // Two contributors (the common case): a + b == b + a bit for bit, so the reducer keeps its own
+            // accumulators and adds the other slab.  Three or more: re-sum every slab in K order from zero so the
+            // result does not depend on who arrived last.
+            const bool pair = ncontrib == 2;
+            if (!pair) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += sl[((i * FN + j) * 16 + r) * NTHREADS + tid];
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            for (int c = 0; c < ncontrib; ++c) {
+                const int bb = first_b + c;
+                if (pair && bb == wg) continue;
+                const int bfirst_tile = (int)(((U * bb) / G) / nkt);
+                const float4* sl = reinterpret_cast<const float4*>(
+                    ws.slabs + ((size_t)(2 * bb + (tt == bfirst_tile ? 0 : 1))) * (BM * BN));
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 v = sl[((i * FN + j) * 4 + g) * NTHREADS + tid];
+                            acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y;
+                            acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w;
+                        }
             }
             if (tid == 0) ws.cnt[tt] = 0;   // leave the ticket zeroed for the next launch (stream-ordered)
         }

@@ -215,7 +215,7 @@ __global__ void bn_dgamma_kernel(const float* __restrict__ rowdot, const float* 
 // mean_rstd float [N][nseg][G][2].
 // ------------------------------------------------------------------------------------------------
 constexpr int GN_ROWS = 128;       // rows per block of the streaming (apply) kernels
-constexpr int GN_STAT_ROWS = 512;  // rows per block of the statistics kernels (fewer atomics per byte)
+constexpr int GN_STAT_ROWS = 512;  // rows per block of the backward statistics kernel (fewer atomics per byte)
 
 __device__ __forceinline__ int find_level(const erd_levels& lv, int64_t a) {
     int s = 0;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     static_assert(CPG == 8 && C4 == 64, "tuned for C=256, G=32");
     const int n = blockIdx.y;
     int s; int64_t r0, r1;
-    gn_chunk(lv, ch, blockIdx.x, s, r0, r1, GN_STAT_ROWS);
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1, GN_ROWS);
     const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 4 row lanes
     float sum = 0.f, sq = 0.f;
     for (int64_t r = r0 + rl; r < r1; r += 4) {
@@ -599,7 +599,7 @@ extern "C" int erd_gn_relu_fwd(const float* c, float* y, const float* gamma, con
     ERD_REQUIRE(C == 256 && G == 32, "gn_fwd: only C=256,G=32 (gfl_head.py:109-110) is built");
     hipStream_t st = (hipStream_t)stream;
     const GnChunks ch = make_chunks(lv);
-    const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
+    const GnChunks chs = ch;   // (512-row chunks measured 2.8x slower here: too few blocks per level)
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
     hipLaunchKernelGGL((gn_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N), dim3(256), 0, st, c, stats_ws, A, *lv, chs);

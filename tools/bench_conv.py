@@ -17,7 +17,11 @@ SHAPES = [  # name, Cin, Cout, H, W, k, s
     ("fpn.lat3", 512, 256, 100, 168, 1, 1), ("fpn.out3", 256, 256, 100, 168, 3, 1),
     ("head.P4", 256, 256, 50, 84, 3, 1), ("big.gemm", 2048, 2048, 128, 128, 1, 1), ("big.3x3", 256, 256, 200, 336, 3, 1), ("head.cls80", 256, 80, 100, 168, 3, 1), ("head.reg68", 256, 68, 100, 168, 3, 1),
 ]
-only = sys.argv[1:] 
+only = sys.argv[1:]
+for spec in os.environ.get("SHAPES", "").split(";"):      # extra shapes: name,Cin,Cout,H,W,k,s
+    if spec:
+        f = spec.split(",")
+        SHAPES.append((f[0],) + tuple(int(v) for v in f[1:]))
 
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
