@@ -573,6 +573,43 @@ def distill_nms(t_cls, t_bbox, anchors, idx_bbox, counts, iou_thr: float = 0.005
     return keep, kcnt
 
 
+def predict_topk(cls: Tensor, bbox: Tensor, anchors: Tensor, sizes, strides, img_hw: Tensor, score_thr: float,
+                 nms_pre: int):
+    """per (image, level) top-nms_pre candidates above score_thr, decoded (gfl_head.py:408-502).
+    Returns boxes [N, L*nms_pre, 4], scores, labels (int32) [N, L*nms_pre], num [N] (int32), level-major."""
+    N, A, Cc = cls.shape
+    dev = cls.device
+    L = len(sizes)
+    cols = L * nms_pre
+    boxes = torch.empty((N, cols, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, cols), dtype=torch.float32, device=dev)
+    labels = torch.empty((N, cols), dtype=torch.int32, device=dev)
+    num = torch.empty((N,), dtype=torch.int32, device=dev)
+    nbytes = int(_lib.load().erd_predict_ws_bytes(N, L, nms_pre))
+    ws = workspace("predict", nbytes, dev)
+    lv = make_levels(sizes)
+    call("erd_predict_topk", _p(cls), _p(bbox), _p(anchors), N, A, Cc, C.byref(lv), _iarr(strides), _p(img_hw),
+         float(score_thr), int(nms_pre), _p(boxes), _p(scores), _p(labels), _p(num), _p(ws), C.c_size_t(nbytes),
+         _stream())
+    return boxes, scores, labels, num
+
+
+def predict_nms(boxes: Tensor, scores: Tensor, labels: Tensor, num: Tensor, inv_scale: Tensor, min_bbox_size: float,
+                iou_thr: float, max_per_img: int):
+    """rescale + size filter + class-offset NMS + top max_per_img (base_dense_head.py:424-486).
+    Returns dets [N, max_per_img, 5], det_labels [N, max_per_img] (int64), det_num [N] (int32)."""
+    N, cols, _ = boxes.shape
+    dev = boxes.device
+    dets = torch.zeros((N, max_per_img, 5), dtype=torch.float32, device=dev)
+    det_labels = torch.zeros((N, max_per_img), dtype=torch.int64, device=dev)
+    det_num = torch.empty((N,), dtype=torch.int32, device=dev)
+    nbytes = N * cols * 48
+    ws = workspace("predict_nms", nbytes, dev)
+    call("erd_predict_nms", _p(boxes), _p(scores), _p(labels), _p(num), N, cols, _p(inv_scale), float(min_bbox_size),
+         float(iou_thr), int(max_per_img), _p(dets), _p(det_labels), _p(det_num), _p(ws), C.c_size_t(nbytes), _stream())
+    return dets, det_labels, det_num
+
+
 def kd_kl(s_bbox, t_bbox, s_cls, keep, c_old, T):
     N, A, c_s = s_cls.shape
     sums = torch.empty((N,), dtype=torch.float64, device=s_cls.device)

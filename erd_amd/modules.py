@@ -511,6 +511,65 @@ class GFLHead(nn.Module):
         cls, bbox = self.forward_cat(cat, sizes)
         return ([_nchw(v) for v in K.level_views(cls, sizes)], [_nchw(v) for v in K.level_views(bbox, sizes)])
 
+    # -- inference ------------------------------------------------------------
+    def predict_by_feat_cat(self, cls: Tensor, bbox: Tensor, sizes, batch_img_metas, cfg=None, rescale: bool = False,
+                            with_nms: bool = True) -> List[InstanceData]:
+        """BaseDenseHead.predict_by_feat + GFLHead._predict_by_feat_single + _bbox_post_process
+        (base_dense_head.py:201-289,424-486; gfl_head.py:408-502) for the whole batch on the GPU: two C-ABI calls
+        (erd_predict_topk, erd_predict_nms), one device->host copy of the N detection counts at the end."""
+        _gpu_only(cls, "GFLHead.predict_by_feat")
+        cfg = self.test_cfg if cfg is None else cfg
+        if cfg is None:
+            raise ValueError("predict needs a test_cfg (nms_pre, score_thr, nms, max_per_img)")
+        if not with_nms:
+            raise NotImplementedError("with_nms=False is the test-time-augmentation path (out of scope)")
+        nms = dict(cfg["nms"])
+        if nms.get("type", "nms") != "nms" or nms.get("class_agnostic", False):
+            raise NotImplementedError("only class-aware hard NMS (the ERD configs) is built")
+        sizes = [tuple(s) for s in sizes]
+        N, dev = cls.shape[0], cls.device
+        anchors = self.prior_generator.grid_priors_cat(sizes, dev)
+        hw = torch.tensor([[float(m["img_shape"][0]), float(m["img_shape"][1])] for m in batch_img_metas],
+                          dtype=torch.float32).to(dev, non_blocking=True)
+        if rescale:
+            for m in batch_img_metas:
+                assert m.get("scale_factor") is not None       # base_dense_head.py:459
+            inv = [[1 / m["scale_factor"][0], 1 / m["scale_factor"][1]] for m in batch_img_metas]
+        else:
+            inv = [[1.0, 1.0]] * N
+        inv = torch.tensor(inv, dtype=torch.float32).to(dev, non_blocking=True)
+        nms_pre = int(cfg.get("nms_pre", -1))
+        if nms_pre <= 0:
+            raise NotImplementedError("nms_pre <= 0 (keep every candidate) is not built; the ERD configs use 1000")
+        strides = list(self.prior_generator.strides)
+        boxes, scores, labels, num = K.predict_topk(cls.contiguous(), bbox.contiguous(), anchors, sizes, strides, hw,
+                                                    float(cfg["score_thr"]), nms_pre)
+        dets, det_labels, det_num = K.predict_nms(boxes, scores, labels, num, inv, float(cfg.get("min_bbox_size", -1)),
+                                                  float(nms["iou_threshold"]), int(cfg["max_per_img"]))
+        counts = det_num.tolist()
+        out = []
+        for n in range(N):
+            r = InstanceData()
+            r.bboxes = dets[n, :counts[n], :4]
+            r.scores = dets[n, :counts[n], 4]
+            r.labels = det_labels[n, :counts[n]]
+            out.append(r)
+        return out
+
+    def predict_by_feat(self, cls_scores: Sequence[Tensor], bbox_preds: Sequence[Tensor], score_factors=None,
+                        batch_img_metas=None, cfg=None, rescale: bool = False, with_nms: bool = True):
+        """reference signature (per-level NCHW maps)"""
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        cat = lambda ms: torch.cat([_nhwc(m).reshape(m.shape[0], -1, m.shape[1]) for m in ms], 1).contiguous()
+        return self.predict_by_feat_cat(cat(cls_scores), cat(bbox_preds), sizes, batch_img_metas, cfg, rescale, with_nms)
+
+    def predict(self, x: Sequence[Tensor], batch_data_samples, rescale: bool = False):
+        """base_dense_head.py:171-199"""
+        metas = [d.metainfo for d in batch_data_samples]
+        with torch.no_grad():
+            cls, bbox = self.forward(x)
+        return self.predict_by_feat(cls, bbox, batch_img_metas=metas, rescale=rescale)
+
     # -- targets ------------------------------------------------------------------------------------
     def _targets(self, sizes, batch_gt_instances, batch_img_metas, device) -> SimpleNamespace:
         """anchors + ATSS assignment for the batch (gfl_head.py:504-669) -- all on the GPU, no host sync."""
@@ -691,7 +750,14 @@ class GFL(nn.Module):
         return self.bbox_head.loss_by_feat_cat(cls, bbox, sizes, gts, metas)
 
     def predict(self, batch_inputs, batch_data_samples, rescale: bool = True):
-        raise NotImplementedError("inference/eval path is a 'next' row (SURVEY.md 8(f) rank 1), not built in round 1")
+        """SingleStageDetector.predict (single_stage.py:78-112) + add_pred_to_datasample (base.py:130-156)."""
+        with torch.no_grad():
+            cls, bbox, sizes = self._forward_cat(batch_inputs)
+            results = self.bbox_head.predict_by_feat_cat(cls, bbox, sizes, [d.metainfo for d in batch_data_samples],
+                                                         rescale=rescale)
+        for d, r in zip(batch_data_samples, results):
+            d.pred_instances = r
+        return batch_data_samples
 
     def forward(self, inputs: Tensor, data_samples=None, mode: str = "tensor"):
         if mode == "loss":

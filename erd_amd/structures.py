@@ -36,6 +36,13 @@ class InstanceData:
     def keys(self):
         return list(self._data.keys())
 
+    def __getitem__(self, item) -> "InstanceData":
+        """index every field alike (mask / index tensor / slice), as mmengine's InstanceData does"""
+        out = InstanceData(metainfo=self._meta)
+        for k, v in self._data.items():
+            setattr(out, k, v[item])
+        return out
+
     @property
     def metainfo(self):
         return dict(self._meta)
@@ -46,6 +53,7 @@ class DetDataSample:
         self._meta = dict(metainfo or {})
         self.gt_instances: Optional[InstanceData] = None
         self.ignored_instances: Optional[InstanceData] = None
+        self.pred_instances: Optional[InstanceData] = None
 
     @property
     def metainfo(self):

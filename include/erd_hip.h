@@ -236,6 +236,27 @@ int erd_loss_finalize(const double* lvl_sums, const float* avg, const double* l2
 int erd_loss_avg(const int32_t* num_pos, int N, const double* lvl_sums, int nlvl, float* avg,
                  erd_stream_t stream);
 
+/* ---- inference post-processing ----------------------------------------------
+ * GFLHead._predict_by_feat_single (gfl_head.py:408-502) + filter_scores_and_topk (models/utils/misc.py:308-354):
+ * per (image, level) the nms_pre highest sigmoid scores above score_thr (score desc, then (anchor, class) index
+ * asc), decoded with Integral x stride around the anchor centre and clamped to img_hw[n] = (H, W).
+ * cls [N][A][C], bbox [N][A][68] level-concatenated; outputs are level-major per image:
+ * boxes [N][nlvl*nms_pre][4], scores / labels [N][nlvl*nms_pre], num[N] = valid entries. */
+size_t erd_predict_ws_bytes(int N, int nlvl, int nms_pre);
+int erd_predict_topk(const float* cls, const float* bbox, const float* anchors, int N, int64_t A, int C,
+                     const erd_levels* lv, const int* strides, const float* img_hw, float score_thr,
+                     int nms_pre, float* boxes, float* scores, int32_t* labels, int32_t* num, void* ws,
+                     size_t ws_bytes, erd_stream_t stream);
+/* BaseDenseHead._bbox_post_process (base_dense_head.py:424-486): boxes * inv_scale[n] = (1/sw, 1/sh), drop
+ * w or h <= min_bbox_size (min_bbox_size < 0: keep all), mmcv.ops.batched_nms restated (class offsets in fp32,
+ * IoU > iou_thr suppresses; UNPINNED vs mmcv), first max_per_img survivors in score order.
+ * dets [N][max_per_img][5] = (x1,y1,x2,y2,score), det_labels [N][max_per_img] int64, det_num[N].
+ * ws: N*max_cols*48 bytes. */
+int erd_predict_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* num,
+                    int N, int max_cols, const float* inv_scale, float min_bbox_size, float iou_thr,
+                    int max_per_img, float* dets, int64_t* det_labels, int32_t* det_num, void* ws,
+                    size_t ws_bytes, erd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

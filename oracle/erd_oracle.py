@@ -672,6 +672,72 @@ def gfl_head_loss(s_cls_maps, s_bbox_maps, gt_bboxes, gt_labels, metas, num_clas
     return dict(loss_cls=lc, loss_bbox=[x / avg2 for x in lb], loss_dfl=[x / avg2 for x in ld])
 
 
+# ----------------------------------------------------------------------------
+# inference: gfl_head.py:408-502, models/utils/misc.py:308-354,
+# base_dense_head.py:201-289,424-486, single_stage.py:78-112
+# ----------------------------------------------------------------------------
+def filter_scores_and_topk(scores: Tensor, score_thr: float, topk: int):
+    """misc.py:308-354.  The reference sorts with torch's default (unstable) sort, so tied scores may
+    come out in any order there; the restatement (and the HIP path) break ties by ascending
+    (anchor, class) index, which is one of the reference's valid outcomes."""
+    valid = scores > score_thr
+    s = scores[valid]
+    vidx = torch.nonzero(valid)
+    k = min(topk, vidx.size(0))
+    s, order = s.sort(descending=True, stable=True)
+    top = vidx[order[:k]]
+    return s[:k], top[:, 1], top[:, 0]
+
+
+def predict_single(cls_maps: Sequence[Tensor], bbox_maps: Sequence[Tensor], img_shape, scale_factor=None,
+                   score_thr: float = 0.05, nms_pre: int = 1000, min_bbox_size: float = 0,
+                   iou_thr: float = 0.6, max_per_img: int = 100, strides: Sequence[int] = STRIDES,
+                   with_nms: bool = True):
+    """GFLHead._predict_by_feat_single + BaseDenseHead._bbox_post_process for ONE image.
+    cls_maps[l] [C,h,w], bbox_maps[l] [68,h,w].  scale_factor = (w_scale, h_scale) or None (rescale=False).
+    Returns (bboxes [D,4], scores [D], labels [D])."""
+    sizes = [tuple(m.shape[-2:]) for m in cls_maps]
+    anchors = grid_anchors(sizes, strides)
+    bb, ss, ll = [], [], []
+    for l, (cm, bm) in enumerate(zip(cls_maps, bbox_maps)):
+        C = cm.shape[0]
+        dist = integral(bm.permute(1, 2, 0)) * strides[l]
+        scores = cm.permute(1, 2, 0).reshape(-1, C).sigmoid()
+        s, labels, keep = filter_scores_and_topk(scores, score_thr, nms_pre)
+        boxes = distance2bbox(anchor_centers(anchors[l])[keep], dist[keep])
+        boxes[:, 0::2].clamp_(min=0, max=img_shape[1])      # transforms.py:175-179 (max_shape = img_shape)
+        boxes[:, 1::2].clamp_(min=0, max=img_shape[0])
+        bb.append(boxes); ss.append(s); ll.append(labels)
+    boxes, scores, labels = torch.cat(bb), torch.cat(ss), torch.cat(ll)
+    if scale_factor is not None:                              # base_dense_head.py:458-461, transforms.py:411-414
+        boxes = boxes * boxes.new_tensor([1 / f for f in scale_factor]).repeat((1, 2))
+    if min_bbox_size >= 0:                                    # :470-474
+        w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+        ok = (w > min_bbox_size) & (h > min_bbox_size)
+        if not ok.all():
+            boxes, scores, labels = boxes[ok], scores[ok], labels[ok]
+    if with_nms and boxes.numel() > 0:                        # :477-484
+        keep = nms_class_offset(boxes, scores, labels, iou_thr)[:max_per_img]
+        boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+    return boxes, scores, labels
+
+
+def predict_by_feat(cls_maps: Sequence[Tensor], bbox_maps: Sequence[Tensor], metas, rescale: bool = False, **cfg):
+    """base_dense_head.py:201-289: per image over batched [N,C,h,w] maps."""
+    out = []
+    for i, m in enumerate(metas):
+        out.append(predict_single([c[i] for c in cls_maps], [b[i] for b in bbox_maps], m["img_shape"],
+                                  m["scale_factor"] if rescale else None, **cfg))
+    return out
+
+
+def gfl_predict(sd: Dict[str, Tensor], x: Tensor, metas, depth: int = 50, rescale: bool = True, **cfg):
+    """SingleStageDetector.predict (single_stage.py:78-112): forward + predict_by_feat."""
+    with torch.no_grad():
+        cls, bbox = gfl_forward(sd, x, depth)
+        return predict_by_feat(cls, bbox, metas, rescale=rescale, **cfg)
+
+
 def parse_losses(losses: Dict[str, object]) -> Tensor:
     """mmengine BaseModel.parse_losses (external, UNPINNED; D9): tensor -> mean, list -> sum of
     means; total = sum over keys containing 'loss'."""

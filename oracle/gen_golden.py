@@ -223,11 +223,36 @@ def gen_f7(ref):
     np.savez_compressed(os.path.join(OUT, "f7_tiny_e2e.npz"), **out)
 
 
+def gen_f8(ref):
+    """inference post-processing through the reference's GFLHead.predict_by_feat (mmcv NMS = the stub restatement,
+    UNPINNED).  Asserts the fixture's decisions have margin: no score within 1e-6 of score_thr or of the top-k cut."""
+    _, student = ref_stub.build_reference_erd()
+    teacher40, _ = ref_stub.build_reference_erd()
+    out = {}
+    for case in (0, 1):
+        cls, bbox, metas, rescale = G.f8_inputs(case)
+        head = student.bbox_head if cls[0].shape[1] == 80 else teacher40.bbox_head
+        with torch.no_grad():
+            res = head.predict_by_feat(cls, bbox, batch_img_metas=metas, rescale=rescale)
+        for i, r in enumerate(res):
+            out[f"c{case}_i{i}_bboxes"] = npy(r.bboxes)
+            out[f"c{case}_i{i}_scores"] = npy(r.scores)
+            out[f"c{case}_i{i}_labels"] = npy(r.labels)
+            for cm in cls:
+                s = cm[i].permute(1, 2, 0).reshape(-1).sigmoid()
+                v = s[s > 0.05].sort(descending=True).values
+                if v.numel() > 1000:                 # the top-k cut decides
+                    assert float(v[999] - v[1000]) > 1e-6
+                else:                                # the score threshold decides
+                    assert float((s - 0.05).abs().min()) > 1e-6
+    np.savez_compressed(os.path.join(OUT, "f8_predict_unpinned_nms.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_stub.load_reference()
-    for fn in (gen_f1, gen_f2, gen_f3, gen_f4, gen_f5, gen_f6, gen_f7):
+    for fn in (gen_f1, gen_f2, gen_f3, gen_f4, gen_f5, gen_f6, gen_f7, gen_f8):
         fn(ref)
         print("wrote", fn.__name__)
 

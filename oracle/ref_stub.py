@@ -103,6 +103,16 @@ class InstanceData:
     def keys(self):
         return list(self._fields.keys())
 
+    def __getitem__(self, item):
+        """index every field alike (mmengine.structures.InstanceData.__getitem__: mask / index tensor / slice)"""
+        out = InstanceData(metainfo=self._meta)
+        for k, v in self._fields.items():
+            setattr(out, k, v[item])
+        return out
+
+    def pop(self, k, *default):
+        return self._fields.pop(k, *default)
+
     @property
     def metainfo(self):
         return dict(self._meta)

@@ -107,3 +107,24 @@ def f6_inputs(N=2, H=256, W=256, c_old=40, c_all=80):
     gtl = [randint(650 + i, 0, c_all - c_old, 3 + 2 * i) for i in range(N)]
     metas = [dict(img_shape=(H - 5, W - 3), pad_shape=(H, W), batch_input_shape=(H, W)) for _ in range(N)]
     return sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas
+
+
+# ---- F8: inference post-processing ---------------------------------------------------------------------
+def f8_inputs(case):
+    """case 0: 2 images, 256x256 pyramid, 80 classes, ~half of the scores above 0.05 (top-k cut on levels 0-2),
+    img_shape smaller than the pad (boxes clamp to zero size and are filtered), rescale by (1.6, 1.5).
+    case 1: 1 image, 128x96, 40 classes, few candidates (no level reaches nms_pre), no rescale."""
+    if case == 0:
+        N, H, W, C = 2, 256, 256, 80
+        sizes = [(H // s, W // s) for s in (8, 16, 32, 64, 128)]
+        cls = [randn(800 + l, N, C, h, w, scale=1.5, shift=-3.0) for l, (h, w) in enumerate(sizes)]
+        bbox = [randn(810 + l, N, 68, h, w, scale=1.5) for l, (h, w) in enumerate(sizes)]
+        metas = [dict(img_shape=(200, 220), pad_shape=(H, W), batch_input_shape=(H, W), scale_factor=(1.6, 1.5))
+                 for _ in range(N)]
+        return cls, bbox, metas, True
+    N, H, W, C = 1, 128, 96, 40
+    sizes = [(-(-H // s), -(-W // s)) for s in (8, 16, 32, 64, 128)]
+    cls = [randn(820 + l, N, C, h, w, scale=1.2, shift=-6.0) for l, (h, w) in enumerate(sizes)]
+    bbox = [randn(830 + l, N, 68, h, w, scale=2.5) for l, (h, w) in enumerate(sizes)]
+    metas = [dict(img_shape=(H, W), pad_shape=(H, W), batch_input_shape=(H, W), scale_factor=(1.0, 1.0))]
+    return cls, bbox, metas, False

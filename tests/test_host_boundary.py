@@ -112,7 +112,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     from erd_amd import _lib
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "erd_hip.h")).read()
-    declared = sorted(set(re.findall(r"^(?:int|const char\*)\s+(erd_\w+)\s*\(", header, re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(erd_\w+)\s*\(", header, re.M)))
     assert declared, "no declarations parsed"
     assert sorted(_lib.EXPORTS) == declared
     for name in declared:

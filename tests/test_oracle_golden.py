@@ -133,6 +133,29 @@ def test_f5_nms_unpinned(golden):
             assert np.array_equal(O.nms_class_offset(b, s, ids, thr).numpy(), g[f"s{i}_t{j}_keep"])
 
 
+@pytest.mark.parametrize("case", [0, 1])
+def test_f8_predict_unpinned_nms(golden, case):
+    """inference post-processing: the restatement reproduces the reference's GFLHead.predict_by_feat bit for bit
+    (NMS itself = the mmcv restatement, unpinned)."""
+    g = golden("f8_predict_unpinned_nms.npz")
+    cls, bbox, metas, rescale = G.f8_inputs(case)
+    res = O.predict_by_feat(cls, bbox, metas, rescale=rescale)
+    for i, (b, s, l) in enumerate(res):
+        assert np.array_equal(b.numpy(), g[f"c{case}_i{i}_bboxes"])
+        assert np.array_equal(s.numpy(), g[f"c{case}_i{i}_scores"])
+        assert np.array_equal(l.numpy(), g[f"c{case}_i{i}_labels"])
+    assert len(res[0][0]) == (100 if case == 0 else 52)
+
+
+def test_filter_scores_and_topk_known_answer():
+    # misc.py:308-354 on a hand-made case: threshold is strict, order is score-descending, k caps the list
+    scores = torch.tensor([[0.1, 0.9], [0.5, 0.05], [0.7, 0.3]])
+    s, labels, keep = O.filter_scores_and_topk(scores, 0.05, 3)
+    assert s.tolist() == pytest.approx([0.9, 0.7, 0.5]) and labels.tolist() == [1, 0, 0] and keep.tolist() == [0, 2, 1]
+    s, labels, keep = O.filter_scores_and_topk(scores, 0.05, 100)
+    assert len(s) == 5 and 0.05 not in s.tolist()
+
+
 def test_weighted_loss_docstring_values():
     # losses/utils.py:80-96 docstring: mean 1.5, avg_factor=2 -> 3.0 (+eps)
     loss = torch.tensor([1.0, 2.0, 1.0, 2.0])   # l1(pred=[0,2,3], target=[1,0,1]) style values
