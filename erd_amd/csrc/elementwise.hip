@@ -562,6 +562,52 @@ extern "C" int erd_maxpool3x3s2(const float* in, float* out, int N, int H, int W
     return erd::check_launch("maxpool");
 }
 
+namespace {
+// DetDataPreprocessor (data_preprocessor.py:110-183 + mmengine ImgDataPreprocessor): one image [3][h][w] (uint8 or
+// fp32, CHW) -> its slot [3][H][W] of the batch: optional channel flip, float, (x - mean) / std, pad_value beyond
+// (h, w).  The subtraction and the division stay two IEEE operations (no reciprocal, no fma), so the result is
+// bit-identical to the host arithmetic.
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ img, int h, int w, float* __restrict__ out,
+                                                         int H, int W, float m0, float m1, float m2, float s0, float s1,
+                                                         float s2, int flip, float pad_value) {
+    const int64_t plane = (int64_t)H * W;
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= plane) return;
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    const bool inside = y < h && x < w;
+    const int64_t src = (int64_t)y * w + x;
+    const int64_t sp = (int64_t)h * w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = pad_value;
+        if (inside) {
+            const float px = (float)img[(flip ? 2 - c : c) * sp + src];
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            v = __fdiv_rn(__fsub_rn(px, mean), sd);
+        }
+        out[c * plane + i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int erd_preprocess_image(const void* img, int is_uint8, int h, int w, float* out, int H, int W,
+                                    const float* mean3, const float* std3, int flip_channels, float pad_value,
+                                    erd_stream_t stream) {
+    ERD_REQUIRE(img && out && mean3 && std3, "preprocess: null");
+    ERD_REQUIRE(h > 0 && w > 0 && H >= h && W >= w, "preprocess: image %dx%d does not fit the %dx%d slot", h, w, H, W);
+    const int64_t plane = (int64_t)H * W;
+    const dim3 grid((unsigned)((plane + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (is_uint8)
+        hipLaunchKernelGGL(preprocess_kernel<uint8_t>, grid, dim3(256), 0, st, reinterpret_cast<const uint8_t*>(img), h, w,
+                           out, H, W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], flip_channels, pad_value);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(img), h, w, out,
+                           H, W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], flip_channels, pad_value);
+    return erd::check_launch("preprocess");
+}
+
 extern "C" int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                            float* scale, float* shift, int64_t n, erd_stream_t stream) {
     ERD_REQUIRE(gamma && beta && mean && var && scale && shift, "bn_fold: null");

@@ -362,6 +362,17 @@ def stem(x_nchw: Tensor, w_ohwi: Tensor, scale: Tensor, shift: Tensor) -> Tensor
     return z
 
 
+def preprocess_into(img: Tensor, out_slot: Tensor, mean, std, flip_channels: bool, pad_value: float) -> None:
+    """one CHW image (uint8 / fp32, on the GPU) -> out_slot [3,H,W] (a slice of the batch tensor)"""
+    _require_gpu(img, out_slot)
+    assert img.dim() == 3 and img.shape[0] == 3 and img.is_contiguous() and out_slot.is_contiguous()
+    assert img.dtype in (torch.uint8, torch.float32), img.dtype
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    call("erd_preprocess_image", _p(img), int(img.dtype == torch.uint8), img.shape[1], img.shape[2], _p(out_slot),
+         out_slot.shape[1], out_slot.shape[2], m, s, int(flip_channels), float(pad_value), _stream())
+
+
 def bn_fold(gamma: Tensor, beta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5):
     _require_gpu(gamma)
     scale = torch.empty_like(gamma)

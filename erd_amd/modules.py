@@ -692,6 +692,8 @@ class DetDataPreprocessor(nn.Module):
         self.channel_conversion = bgr_to_rgb or rgb_to_bgr
         self.register_buffer("mean", torch.tensor(mean if mean is not None else [0., 0., 0.]).view(3, 1, 1), False)
         self.register_buffer("std", torch.tensor(std if std is not None else [1., 1., 1.]).view(3, 1, 1), False)
+        self._mean_host = [float(v) for v in self.mean.flatten()]      # fp32-rounded, as the buffers hold them
+        self._std_host = [float(v) for v in self.std.flatten()]
 
     def forward(self, data: dict, training: bool = False) -> dict:
         imgs, samples = data["inputs"], data.get("data_samples")
@@ -699,12 +701,15 @@ class DetDataPreprocessor(nn.Module):
         H = max(int(math.ceil(im.shape[1] / d)) * d for im in imgs)
         W = max(int(math.ceil(im.shape[2] / d)) * d for im in imgs)
         dev = self.mean.device
-        batch = torch.full((len(imgs), 3, H, W), float(self.pad_value), device=dev)
+        if dev.type != "cuda":
+            raise RuntimeError("DetDataPreprocessor runs on the GPU (erd_amd has no CPU path): move the model first")
+        batch = torch.empty((len(imgs), 3, H, W), dtype=torch.float32, device=dev)
+        mean, std = self._mean_host, self._std_host
         for i, im in enumerate(imgs):
-            x = im.to(dev, non_blocking=True)
-            if self.channel_conversion:
-                x = x[[2, 1, 0]]
-            batch[i, :, :x.shape[1], :x.shape[2]] = (x.float() - self.mean) / self.std
+            x = im.to(dev, non_blocking=True).contiguous()
+            if x.dtype not in (torch.uint8, torch.float32):
+                x = x.float()
+            K.preprocess_into(x, batch[i], mean, std, self.channel_conversion, float(self.pad_value))
             if samples is not None:
                 samples[i].set_metainfo(dict(img_shape=(im.shape[1], im.shape[2]), pad_shape=(H, W),
                                              batch_input_shape=(H, W)))

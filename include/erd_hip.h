@@ -127,6 +127,13 @@ int erd_stem_conv7x7_bn_relu(const float* x_nchw, const float* w_ohwi, const flo
                              erd_stream_t stream);
 int erd_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, erd_stream_t stream);
 
+/* ---- DetDataPreprocessor (data_preprocessor.py:110-183; mmengine ImgDataPreprocessor): one CHW image (uint8 or
+ * fp32, device) -> out[3][H][W]: optional channel flip (bgr_to_rgb), (x - mean) / std, pad_value outside (h, w).
+ * mean3 / std3 are HOST pointers to 3 floats. */
+int erd_preprocess_image(const void* img, int is_uint8, int h, int w, float* out, int H, int W,
+                         const float* mean3, const float* std3, int flip_channels, float pad_value,
+                         erd_stream_t stream);
+
 /* ---- frozen-statistics BN helpers ---------------------------------------------------------- */
 /* scale = gamma*rsqrt(var+eps), shift = beta-mean*scale over n channels (resnet.py:268-300, eval BN) */
 int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,

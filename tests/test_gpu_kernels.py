@@ -216,3 +216,29 @@ def test_level_scale_colsum_sgd(K):
         opt.step()
         K.sgd_momentum_(pg, g.cuda(), buf, 0.02, 0.9, 1e-4, 1.0, it == 0)
     assert relerr(pg.cpu(), ref_p[0]) < 1e-6
+
+
+def test_data_preprocessor_bit_exact_vs_oracle():
+    """DetDataPreprocessor (R21): BGR->RGB, (x-mean)/std, zero pad to /32 after normalisation -- bit-exact vs the oracle
+    on ragged uint8 images; float inputs and a non-zero pad value too."""
+    from erd_amd import MODELS, DetDataSample
+    from oracle import erd_oracle as O
+    rng = np.random.RandomState(11)
+    imgs = [torch.from_numpy(rng.randint(0, 256, size=(3, h, w), dtype=np.uint8)) for h, w in [(123, 153), (97, 160), (128, 31)]]
+    want, metas = O.preprocess(imgs)
+    pre = MODELS.build(dict(type="DetDataPreprocessor", mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375],
+                            bgr_to_rgb=True, pad_size_divisor=32)).cuda()
+    samples = [DetDataSample() for _ in imgs]
+    out = pre(dict(inputs=imgs, data_samples=samples), True)
+    assert out["inputs"].shape == want.shape and torch.equal(out["inputs"].cpu(), want)
+    for s, m in zip(samples, metas):
+        assert s.metainfo["img_shape"] == m["img_shape"] and s.metainfo["pad_shape"] == m["pad_shape"] \
+            and s.metainfo["batch_input_shape"] == m["batch_input_shape"]
+    # float inputs, no channel flip, pad value 7
+    pre2 = MODELS.build(dict(type="DetDataPreprocessor", mean=[1.5, 2.5, 3.5], std=[2.0, 3.0, 7.0], pad_size_divisor=16,
+                             pad_value=7)).cuda()
+    f = [torch.from_numpy(rng.rand(3, 20, 33).astype(np.float32)) * 255]
+    got = pre2(dict(inputs=f), False)["inputs"].cpu()
+    ref = torch.full((1, 3, 32, 48), 7.0)
+    ref[0, :, :20, :33] = (f[0] - torch.tensor([1.5, 2.5, 3.5]).view(3, 1, 1)) / torch.tensor([2.0, 3.0, 7.0]).view(3, 1, 1)
+    assert torch.equal(got, ref)
