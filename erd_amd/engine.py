@@ -132,6 +132,10 @@ class ERDTrainer:
         self.momentum, self.weight_decay = momentum, weight_decay
         self.warmup_iters, self.warmup_start = warmup_iters, warmup_start_factor
         self.iter = 0
+        self.epoch_factor = 1.0              # MultiStepLR factor of the current epoch (set by the runner)
+        self.lr_factor = None                # optional callable iter -> factor replacing the built-in warm-up
+        self.last_lr = self.base_lr
+        self._pending_lr = self.base_lr
         self._first = True
         self._pending = False                # an un-applied gradient sits in flat.grad
         self.sync = BucketedGradSync(self.flat) if self.distributed else None
@@ -141,6 +145,8 @@ class ERDTrainer:
 
     # -- schedule (schedule_1x.py:7-17: LinearLR warm-up; MultiStep handled by the caller per epoch) ------------
     def lr_at(self, it: int, epoch_factor: float = 1.0) -> float:
+        if self.lr_factor is not None:
+            return self.base_lr * self.lr_factor(it) * epoch_factor
         f = 1.0
         if it < self.warmup_iters:
             f = self.warmup_start + (1.0 - self.warmup_start) * it / max(self.warmup_iters - 1, 1)
@@ -152,13 +158,41 @@ class ERDTrainer:
             return
         if self.sync is not None:
             self.sync.wait()
-        K.sgd_momentum_(self.flat.data, self.flat.grad, self.flat.momentum, self.lr_at(self.iter - 1), self.momentum,
+        K.sgd_momentum_(self.flat.data, self.flat.grad, self.flat.momentum, self._pending_lr, self.momentum,
                         self.weight_decay, 1.0 / self.world, self._first)
         self._first = False
         self._pending = False
 
     def flush(self) -> None:
         self._apply_pending()
+
+    # -- optimizer state in torch.optim.SGD's state_dict layout (what the reference's checkpoints hold) ---------
+    def optimizer_state_dict(self) -> dict:
+        self.flush()
+        index = {id(p): i for i, p in enumerate(self.model.parameters())}
+        state = {}
+        if not self._first:
+            for p, off in zip(self.flat.params, self.flat.offsets):
+                buf = _storage_view(self.flat.momentum, off, p)
+                state[index[id(p)]] = dict(momentum_buffer=buf.detach().cpu().contiguous().clone())
+        group = dict(lr=self.last_lr, momentum=self.momentum, dampening=0, weight_decay=self.weight_decay, nesterov=False,
+                     maximize=False, foreach=None, differentiable=False, initial_lr=self.base_lr,
+                     params=list(range(len(index))))
+        return dict(state=state, param_groups=[group])
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        self.flush()
+        params = list(self.model.parameters())
+        slot = {id(p): (p, off) for p, off in zip(self.flat.params, self.flat.offsets)}
+        loaded = 0
+        for i, st in sd.get("state", {}).items():
+            p = params[int(i)]
+            if id(p) not in slot or "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                continue
+            p, off = slot[id(p)]
+            _storage_view(self.flat.momentum, off, p).copy_(st["momentum_buffer"].to(self.device))
+            loaded += 1
+        self._first = loaded == 0
 
     # -- the step ------------------------------------------------------------------------------------------------------
     def train_step(self, inputs: Tensor, data_samples) -> Dict[str, Tensor]:
@@ -192,6 +226,7 @@ class ERDTrainer:
         total.backward()
         K.zero_arena_end()
         self._pending = True
+        self._pending_lr = self.last_lr = self.lr_at(self.iter, self.epoch_factor)
         self.iter += 1
         if not self.overlap_teacher:
             self._apply_pending()

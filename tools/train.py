@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Train a detector from a reference-format config on MI355X (the thin launcher of SURVEY.md 8(f) rank 4).
+
+    python tools/train.py configs/gfl_increment/gfl_r50_fpn_1x_coco_first_40_incre_last_40_cats.py \
+        --work-dir work_dirs/erd --cfg-options train_dataloader.batch_size=4 --synthetic 100
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
+
+Same flags as the reference's tools/train.py:15-129 (--work-dir, --amp, --auto-scale-lr, --resume, --cfg-options,
+--launcher).  There is no COCO on this machine and no image decoder pipeline yet, so the data source is
+`--synthetic ITERS_PER_EPOCH` (batches shaped like the reference's demo_mm_inputs); `--amp` is refused (fp32 path).
+"""
+import argparse
+import ast
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def parse_cfg_options(items):
+    out = {}
+    for it in items or []:
+        k, v = it.split("=", 1)
+        try:
+            out[k] = ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            out[k] = [s for s in v.split(",")] if "," in v else v
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Train a detector (erd_amd)")
+    ap.add_argument("config")
+    ap.add_argument("--work-dir")
+    ap.add_argument("--amp", action="store_true")
+    ap.add_argument("--auto-scale-lr", action="store_true")
+    ap.add_argument("--resume", nargs="?", type=str, const="auto")
+    ap.add_argument("--cfg-options", nargs="+")
+    ap.add_argument("--launcher", choices=["none", "pytorch"], default="none")
+    ap.add_argument("--synthetic", type=int, default=50, metavar="ITERS", help="synthetic iterations per epoch")
+    ap.add_argument("--image-size", type=int, nargs=2, default=(800, 1333), metavar=("H", "W"))
+    ap.add_argument("--max-iters", type=int, default=None)
+    ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
+    args = ap.parse_args(argv)
+    if args.amp:
+        raise SystemExit("--amp: the MI355X path computes in fp32 (bf16 is not built)")
+
+    import torch
+    import torch.distributed as dist
+    from erd_amd import Config
+    from erd_amd.runner import Runner, SyntheticDetData
+
+    cfg = Config.fromfile(args.config)
+    cfg.merge_from_dict(parse_cfg_options(args.cfg_options))
+    cfg.work_dir = args.work_dir or cfg.get("work_dir") or os.path.join(
+        "work_dirs", os.path.splitext(os.path.basename(args.config))[0])
+    if args.auto_scale_lr:
+        if "auto_scale_lr" not in cfg or "base_batch_size" not in cfg.auto_scale_lr:
+            raise RuntimeError('Can not find "auto_scale_lr" or "auto_scale_lr.base_batch_size" in your configuration file.')
+        cfg.auto_scale_lr.enable = True
+    if args.resume == "auto":
+        cfg.resume, cfg.load_from = True, None
+    elif args.resume is not None:
+        cfg.resume, cfg.load_from = True, args.resume
+
+    local_rank = int(os.environ.get("LOCAL_RANK", args.local_rank))
+    torch.cuda.set_device(local_rank)
+    if args.launcher == "pytorch":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    head = cfg.model.bbox_head
+    ori = cfg.model.get("ori_setting")
+    num_new = head.num_classes - (ori.ori_num_classes if ori else 0)
+    data = SyntheticDetData(int(cfg.train_dataloader.batch_size), num_new, args.synthetic, tuple(args.image_size),
+                            seed=rank)
+    runner = Runner.from_cfg(cfg, data=data)
+    runner.train(max_iters=args.max_iters)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
