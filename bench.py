@@ -96,6 +96,22 @@ def cpu_baseline(seconds_budget: float = 30.0):
                        "oracle/erd_oracle.py on torch-CPU fp32, %.1f s" % dt)
 
 
+def pmc_traffic_per_launch(symbol_prefix: str):
+    """HBM-side bytes per launch of the kernels whose symbol starts with `symbol_prefix`, from the committed PMC
+    summary (two separate rocprofv3 --pmc passes, tools/pmc_traffic.py; FETCH_SIZE doubled as the gfx950 note in
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process -> None when absent."""
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if not files:
+        return None, None
+    d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+    n = sum(v["launches"] for k, v in d.items() if k.startswith(symbol_prefix) and v.get("traffic_MB"))
+    if not n:
+        return None, None
+    mb = sum(v["launches"] * v["traffic_MB"] for k, v in d.items() if k.startswith(symbol_prefix) and v.get("traffic_MB"))
+    return int(mb / n * 1e6), "profiles/" + files[-1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,14 +207,17 @@ def main():
         }
         if ktime:
             dom = max(ktime.values(), key=lambda r: r["ms"])
+            traffic, traffic_src = pmc_traffic_per_launch("conv_wgrad" if dom["kernel"] == "conv_wgrad" else "conv_igemm")
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"],
                                "achieved": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                               "traffic": None, "pass": f"{rsteps} extra steps, streams serialized",
+                               "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, PMC)",
+                               "traffic_source": traffic_src, "pass": f"{rsteps} extra steps, streams serialized",
                                "launches_per_step": dom["launches"] // rsteps,
                                "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-                               "gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3)}
+                               "gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
+                               "algorithmic_bytes_per_launch": int(dom["min_bytes"] / dom["launches"])}
             out["kernels"] = {k: {"ms_per_step": round(r["ms"] / rsteps, 3),
                                   "tflops": round(r["flop"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flop"] else None,
                                   "launches_per_step": r["launches"] // rsteps} for k, r in ktime.items()}

@@ -1,0 +1,141 @@
+"""Annotation side of the data pipeline: COCO json -> per-image records restricted to the
+configured classes, the empty/min-size filter, aspect-ratio batching, category slicing for the 40+40 protocol.
+Host-side integer / dictionary work only (the reference does this in Python too); pixels are decoded and resized
+elsewhere -- this module never touches image data.
+
+Reference: mmdet/datasets/coco.py:59-100 (load_data_list), :102-170 (parse_data_info), :172-212 (filter_data);
+mmdet/datasets/samplers/batch_sampler.py:11-68; scripts/select_categories.py:21-64; pycocotools' COCO index
+(getCatIds / getImgIds / getAnnIds semantics restated: dataset order everywhere).
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import defaultdict
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence
+
+import torch
+
+from .structures import DetDataSample, InstanceData
+
+
+def select_categories(dataset: dict, start: int, end: int) -> dict:
+    """scripts/select_categories.py:31-60: sort categories by id, keep those at positions [start, end), then the
+    annotations of those categories and the images that still have at least one annotation (original order kept)."""
+    cats = sorted(dataset["categories"], key=lambda c: c["id"])[start:end]
+    ids = {c["id"] for c in cats}
+    annos = [a for a in dataset["annotations"] if a["category_id"] in ids]
+    img_ids = {a["image_id"] for a in annos}
+    return dict(categories=cats, annotations=annos, images=[im for im in dataset["images"] if im["id"] in img_ids])
+
+
+class CocoAnnotations:
+    """what the reference keeps of a COCO annotation file after load_data_list + filter_data"""
+
+    def __init__(self, ann_file, classes: Sequence[str], data_prefix: str = "", filter_empty_gt: bool = True,
+                 min_size: int = 32, test_mode: bool = False):
+        ds = json.load(open(ann_file)) if isinstance(ann_file, (str, os.PathLike)) else ann_file
+        names = set(classes)
+        # getCatIds(catNms=classes): ids in the FILE's category order, not in `classes` order (coco.py:69-72)
+        self.cat_ids = [c["id"] for c in ds["categories"] if c["name"] in names]
+        self.cat2label = {cid: i for i, cid in enumerate(self.cat_ids)}
+        self.classes = tuple(classes)
+        anns_of = defaultdict(list)
+        cat_img_map = defaultdict(list)
+        seen = set()
+        for a in ds["annotations"]:
+            if a["id"] in seen:
+                raise AssertionError(f"Annotation ids in '{ann_file}' are not unique!")
+            seen.add(a["id"])
+            anns_of[a["image_id"]].append(a)
+            cat_img_map[a["category_id"]].append(a["image_id"])
+        self.data_list = [self._parse(im, anns_of.get(im["id"], []), data_prefix) for im in ds["images"]]
+        if not test_mode:
+            in_cat = set()
+            for cid in self.cat_ids:
+                in_cat |= set(cat_img_map.get(cid, []))
+            self.data_list = [d for d in self.data_list
+                              if not (filter_empty_gt and d["img_id"] not in in_cat) and
+                              min(d["width"], d["height"]) >= min_size]
+
+    def _parse(self, img: dict, anns: Iterable[dict], prefix: str) -> dict:
+        W, H = img["width"], img["height"]
+        inst = []
+        for a in anns:
+            if a.get("ignore", False):
+                continue
+            x1, y1, w, h = a["bbox"]
+            iw = max(0, min(x1 + w, W) - max(x1, 0))
+            ih = max(0, min(y1 + h, H) - max(y1, 0))
+            if iw * ih == 0 or a["area"] <= 0 or w < 1 or h < 1 or a["category_id"] not in self.cat2label:
+                continue
+            inst.append(dict(bbox=[x1, y1, x1 + w, y1 + h], bbox_label=self.cat2label[a["category_id"]],
+                             ignore_flag=1 if a.get("iscrowd", False) else 0))
+        return dict(img_path=os.path.join(prefix, img["file_name"]), img_id=img["id"], height=H, width=W, instances=inst)
+
+    def __len__(self):
+        return len(self.data_list)
+
+    def get_data_info(self, idx: int) -> dict:
+        return self.data_list[idx]
+
+    def data_sample(self, idx: int, scale_factor=(1.0, 1.0), flip: bool = False, img_shape=None) -> DetDataSample:
+        """PackDetInputs for the annotation half: boxes of non-ignored instances scaled by (w_scale, h_scale) and
+        optionally flipped horizontally inside img_shape (RandomFlip), ignored ones in `ignored_instances`."""
+        d = self.data_list[idx]
+        sw, sh = scale_factor
+        shape = img_shape or (int(d["height"] * sh + 0.5), int(d["width"] * sw + 0.5))
+        boxes = torch.tensor([i["bbox"] for i in d["instances"]], dtype=torch.float32).reshape(-1, 4)
+        boxes = boxes * torch.tensor([sw, sh, sw, sh])
+        if flip:
+            x1 = shape[1] - boxes[:, 2]
+            x2 = shape[1] - boxes[:, 0]
+            boxes = torch.stack([x1, boxes[:, 1], x2, boxes[:, 3]], 1)
+        labels = torch.tensor([i["bbox_label"] for i in d["instances"]], dtype=torch.int64)
+        ign = torch.tensor([i["ignore_flag"] for i in d["instances"]], dtype=torch.bool)
+        s = DetDataSample(metainfo=dict(img_id=d["img_id"], img_path=d["img_path"], ori_shape=(d["height"], d["width"]),
+                                        img_shape=shape, scale_factor=(sw, sh), flip=flip))
+        s.gt_instances = InstanceData(bboxes=boxes[~ign], labels=labels[~ign])
+        s.ignored_instances = InstanceData(bboxes=boxes[ign], labels=labels[ign])
+        return s
+
+
+def rescale_size(old_wh, scale) -> tuple:
+    """mmcv.image.rescale_size for a (long, short) target such as (1333, 800) with keep_ratio: the largest factor
+    that keeps the long edge <= max(scale) and the short edge <= min(scale); new size = int(x * f + 0.5)."""
+    w, h = old_wh
+    f = min(max(scale) / max(h, w), min(scale) / min(h, w))
+    return int(w * float(f) + 0.5), int(h * float(f) + 0.5)
+
+
+class AspectRatioBatchSampler:
+    """batch_sampler.py:11-68: indices from `sampler` are bucketed by (width < height); a bucket is emitted when it
+    reaches batch_size; leftovers of both buckets are concatenated (portrait first) and chunked at the end."""
+
+    def __init__(self, sampler: Iterable[int], dataset: CocoAnnotations, batch_size: int, drop_last: bool = False):
+        if not isinstance(batch_size, int) or batch_size <= 0:
+            raise ValueError(f"batch_size should be a positive integer value, but got batch_size={batch_size}")
+        self.sampler, self.dataset, self.batch_size, self.drop_last = sampler, dataset, batch_size, drop_last
+
+    def __iter__(self) -> Iterator[List[int]]:
+        buckets = [[], []]
+        for idx in self.sampler:
+            d = self.dataset.get_data_info(idx)
+            b = buckets[0 if d["width"] < d["height"] else 1]
+            b.append(idx)
+            if len(b) == self.batch_size:
+                yield b[:]
+                del b[:]
+        left = buckets[0] + buckets[1]
+        while left:
+            if len(left) <= self.batch_size:
+                if not self.drop_last:
+                    yield left[:]
+                left = []
+            else:
+                yield left[:self.batch_size]
+                left = left[self.batch_size:]
+
+    def __len__(self) -> int:
+        n = len(self.sampler)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size

@@ -47,12 +47,14 @@ def timing_end():
     torch.cuda.synchronize()
     out = {}
     for name, evs in (rec or {}).items():
-        ms = sum(s.elapsed_time(e) for s, e, _ in evs)
-        out[name] = dict(kernel=name, ms=ms, flop=float(sum(f for _, _, f in evs)), launches=len(evs))
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in evs)
+        out[name] = dict(kernel=name, ms=ms, flop=float(sum(f for _, _, f, _ in evs)), launches=len(evs),
+                         min_bytes=float(sum(b for _, _, _, b in evs)))
     return out
 
 
-def _timed_call(kname: str, flop: float, cname: str, *args) -> None:
+def _timed_call(kname: str, flop: float, cname: str, *args, nbytes: float = 0.0) -> None:
+    """nbytes: the launch's algorithmic HBM bytes (every operand read once, the result written once)"""
     if _TIMING is None:
         call(cname, *args)
         return
@@ -60,7 +62,7 @@ def _timed_call(kname: str, flop: float, cname: str, *args) -> None:
     s.record()
     call(cname, *args)
     e.record()
-    _TIMING.setdefault(kname, []).append((s, e, flop))
+    _TIMING.setdefault(kname, []).append((s, e, flop, nbytes))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -225,7 +227,8 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     d.colsum = 0
     _attach_sk_ws(d, w.device)
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
-    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream())
+    nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel()) if _TIMING is not None else 0.0
+    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes)
 
 
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
@@ -282,7 +285,10 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.colsum = 0 if colsum is None else colsum.data_ptr()
         _attach_sk_ws(d, wt.device)
         flop = 2.0 * sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg)) * Cin * len(taps) * Cout
-        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream())
+        # (stride 2: each parity class reads dz once and writes a quarter of dx)
+        nbytes = 4.0 * (sum(t.numel() for t in dzs) + sum(t.numel() for t in dxs) / (stride * stride) + wt.numel() /
+                        (stride * stride)) if _TIMING is not None else 0.0
+        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes)
 
 
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
@@ -334,7 +340,8 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     d.part = part.data_ptr()
     d.nsplit = S
     flop = 2.0 * npix * Cout * Cin * k * k
-    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream())
+    nbytes = 4.0 * (sum(t.numel() for t in xs) + sum(t.numel() for t in dzs) + part.numel()) if _TIMING is not None else 0.0
+    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes)
     return part, S
 
 
