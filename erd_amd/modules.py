@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 from collections import OrderedDict
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple, Union
@@ -834,7 +835,7 @@ class GFLIncrementERD(GFL):
         load_checkpoint(ori_model, ori_setting["ori_checkpoint_file"], strict=True)
         self.ori_num_classes = ori_setting["ori_num_classes"]
         self._load_checkpoint_for_new_model(ori_setting["ori_checkpoint_file"])
-        print("======> load base checkpoint for new model from {}".format(ori_setting["ori_checkpoint_file"]))
+        print("======> load base checkpoint for new model from {}".format(ori_setting["ori_checkpoint_file"]), file=sys.stderr)
         self.attach_teacher(ori_model, self.ori_num_classes)
 
     def attach_teacher(self, ori_model: nn.Module, ori_num_classes: int) -> None:
