@@ -382,7 +382,27 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             const int c4 = tid % C4N;
             const int co = n0 + c4 * 4;
             float4 csum_keep = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < p.Cout) {
+            if (co < p.Cout && (p.Cout & 3) != 0) {
+                // Cout not a multiple of 4 (e.g. a 70-class teacher head): rows are not 16-B aligned -> scalar stores
+                float csum[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int rr = tid / C4N; rr < FM * 32; rr += RPS) {
+                    const int oo = rows[half * FM * 32 + rr].out_off;
+                    if (oo < 0) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= p.Cout) break;
+                        float x = stage[rr * SLD + c4 * 4 + e];
+                        x = x * (p.scale ? p.scale[co + e] : 1.f) + (p.shift ? p.shift[co + e] : 0.f);
+                        if (has_alpha) x *= alpha;
+                        if (res) x += res[oo + co + e];
+                        if (p.relu) x = fmaxf(x, 0.f);
+                        if (msk) x = msk[oo + co + e] > 0.f ? x : 0.f;
+                        out[oo + co + e] = x;
+                        csum[e] += x;
+                    }
+                }
+                if (p.colsum) csum_keep = make_float4(csum[0], csum[1], csum[2], csum[3]);
+            } else if (co < p.Cout) {
                 float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
                 if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
@@ -421,9 +441,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
                     }
                     atomicAdd(p.colsum + co + 0, t.x);
-                    atomicAdd(p.colsum + co + 1, t.y);
-                    atomicAdd(p.colsum + co + 2, t.z);
-                    atomicAdd(p.colsum + co + 3, t.w);
+                    if (co + 1 < p.Cout) atomicAdd(p.colsum + co + 1, t.y);
+                    if (co + 2 < p.Cout) atomicAdd(p.colsum + co + 2, t.z);
+                    if (co + 3 < p.Cout) atomicAdd(p.colsum + co + 3, t.w);
                 }
             }
         }

@@ -62,6 +62,21 @@ __global__ __launch_bounds__(256) void ers_rowmax_kernel(const float* __restrict
     }
 }
 
+// the same for a channel count that is not a multiple of 4 (e.g. 70 old classes): one thread per row
+template <bool SIGMOID>
+__global__ __launch_bounds__(256) void ers_rowmax_generic_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                                  float* __restrict__ m, int64_t A,
+                                                                  double* __restrict__ sums, int which) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* z = x + r * C;
+    float mv = z[0];
+    for (int i = 1; i < C; ++i) mv = fmaxf(mv, z[i]);
+    if (SIGMOID) mv = sigmoidf_(mv);
+    m[r] = mv;
+    atomicAdd(sums + (r / A) * 4 + which, (double)mv);
+}
+
 // stage 2: sum of squared deviations from the (f64) mean
 __global__ __launch_bounds__(256) void ers_var_kernel(const float* __restrict__ m, int64_t A, double* __restrict__ sums,
                                                        int which) {
@@ -737,7 +752,7 @@ extern "C" int erd_ers_select(const float* cls, const float* bbox, int N, int64_
                               uint8_t* mask_cls, uint8_t* mask_bbox, int64_t* idx_cls, int64_t* idx_bbox,
                               int32_t* counts, float* thr, double* ws, erd_stream_t stream) {
     ERD_REQUIRE(cls && bbox && mask_cls && mask_bbox && idx_cls && idx_bbox && counts && thr && ws, "ers: null");
-    ERD_REQUIRE(Ccls % 4 == 0 && Cbox % 4 == 0 && N > 0 && A > 0, "ers: channels must be multiples of 4");
+    ERD_REQUIRE(Ccls > 0 && Cbox > 0 && N > 0 && A > 0, "ers: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     // ws: double sums[N][4] | float m_c[N*A] | float m_b[N*A]
     double* sums = ws;
@@ -746,10 +761,16 @@ extern "C" int erd_ers_select(const float* cls, const float* bbox, int N, int64_
     hipMemsetAsync(sums, 0, sizeof(double) * 4 * N, st);
     const int64_t rows = (int64_t)N * A;
     const unsigned nb = (unsigned)((rows + 255) / 256);
-    hipLaunchKernelGGL(ers_rowmax_kernel<true>, dim3(nb), dim3(256), 256 * (Ccls / 4) * sizeof(float), st, cls, rows,
-                       Ccls, m_c, A, sums, 0);
-    hipLaunchKernelGGL(ers_rowmax_kernel<false>, dim3(nb), dim3(256), 256 * (Cbox / 4) * sizeof(float), st, bbox, rows,
-                       Cbox, m_b, A, sums, 1);
+    if (Ccls % 4 == 0)
+        hipLaunchKernelGGL(ers_rowmax_kernel<true>, dim3(nb), dim3(256), 256 * (Ccls / 4) * sizeof(float), st, cls, rows,
+                           Ccls, m_c, A, sums, 0);
+    else
+        hipLaunchKernelGGL(ers_rowmax_generic_kernel<true>, dim3(nb), dim3(256), 0, st, cls, rows, Ccls, m_c, A, sums, 0);
+    if (Cbox % 4 == 0)
+        hipLaunchKernelGGL(ers_rowmax_kernel<false>, dim3(nb), dim3(256), 256 * (Cbox / 4) * sizeof(float), st, bbox,
+                           rows, Cbox, m_b, A, sums, 1);
+    else
+        hipLaunchKernelGGL(ers_rowmax_generic_kernel<false>, dim3(nb), dim3(256), 0, st, bbox, rows, Cbox, m_b, A, sums, 1);
     const unsigned vb = (unsigned)std::min<int64_t>(64, (A + 255) / 256);
     hipLaunchKernelGGL(ers_var_kernel, dim3(vb, N), dim3(256), 0, st, m_c, A, sums, 0);
     hipLaunchKernelGGL(ers_var_kernel, dim3(vb, N), dim3(256), 0, st, m_b, A, sums, 1);

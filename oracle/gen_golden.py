@@ -184,19 +184,19 @@ def gen_f6(ref):
     np.savez_compressed(os.path.join(OUT, "f6_head.npz"), **out)
 
 
-def gen_f7(ref):
-    """tiny end-to-end: real ResNet-50/FPN/GFL teacher+student at 128x160, procedural weights."""
-    teacher, student = ref_stub.build_reference_erd()
-    tsd = O.procedural_state_dict(40, seed=0)
-    ssd = O.student_state_from_teacher(tsd, 80, seed=1)
+def _tiny_e2e(ref, fname, c_old, c_all, depth):
+    """tiny end-to-end: real ResNet/FPN/GFL teacher+student at 128x160, procedural weights."""
+    teacher, student = ref_stub.build_reference_erd(c_old, c_all, depth)
+    tsd = O.procedural_state_dict(c_old, depth=depth, seed=0)
+    ssd = O.student_state_from_teacher(tsd, c_all, seed=1)
     for k in sorted(ssd):
         if O.trainable(k) and ssd[k].dim() == 4:       # move the student off the teacher
             ssd[k] = ssd[k] + 0.02 * ssd[k].abs().mean() * G.randn(700 + len(k), *ssd[k].shape)
     teacher.load_state_dict(tsd, strict=True)
     student.load_state_dict(ssd, strict=True)
-    ref_stub.attach_teacher(student, teacher, 40)
+    ref_stub.attach_teacher(student, teacher, c_old)
     student.train()
-    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=0)
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, c_all - c_old, seed=0)
     x, metas = O.preprocess(imgs)
     losses = student.loss(x, _samples(ref, boxes, labels, metas))
     total = O.parse_losses(losses)
@@ -220,7 +220,16 @@ def gen_f7(ref):
     t_cls, t_bbox = teacher(x)
     out["teacher_cls0_sample"] = npy(t_cls[0][0, :, ::4, ::4])
     out["teacher_bbox4"] = npy(t_bbox[4])
-    np.savez_compressed(os.path.join(OUT, "f7_tiny_e2e.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_f7(ref):
+    _tiny_e2e(ref, "f7_tiny_e2e.npz", 40, 80, 50)
+
+
+def gen_f9(ref):
+    """BASELINE.json configs[3]: ResNet-101, 70 old + 10 new classes"""
+    _tiny_e2e(ref, "f9_tiny_e2e_r101_70_10.npz", 70, 80, 101)
 
 
 def gen_f8(ref):
@@ -252,7 +261,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_stub.load_reference()
-    for fn in (gen_f1, gen_f2, gen_f3, gen_f4, gen_f5, gen_f6, gen_f7, gen_f8):
+    for fn in (gen_f1, gen_f2, gen_f3, gen_f4, gen_f5, gen_f6, gen_f7, gen_f8, gen_f9):
         fn(ref)
         print("wrote", fn.__name__)
 

@@ -27,12 +27,16 @@ def _lossdict_to_np(d):
     return {k: np.array([float(v) for v in vs], dtype=np.float64) for k, vs in d.items()}
 
 
-def test_f7_reference_fixture_losses_and_grads(golden):
+@pytest.mark.parametrize("fixture,c_old,depth", [("f7_tiny_e2e.npz", 40, 50), ("f9_tiny_e2e_r101_70_10.npz", 70, 101)])
+def test_f7_reference_fixture_losses_and_grads(golden, fixture, c_old, depth):
+    """F7: GFL-R50 40+40 (BASELINE configs[1]); F9: GFL-R101 70+10 (configs[3]: deeper backbone, a 70-channel teacher
+    head -- rows that are not 16-B aligned -- and only 10 new classes)."""
     from erd_amd import parse_losses
-    g = golden("f7_tiny_e2e.npz")
-    tsd, ssd = f7_state_dicts()
-    model = build_erd(tsd, ssd)
-    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=0)
+    import e2e_util as U
+    g = golden(fixture)
+    tsd, ssd = f7_state_dicts(c_old, 80, depth)
+    model = build_erd(tsd, ssd) if depth == 50 else build_erd(tsd, ssd, cfg_first=U.CFG_FIRST70, cfg_incre=U.CFG_INCRE10)
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 80 - c_old, seed=0)
     x, metas = O.preprocess(imgs)
     # teacher outputs (mode='tensor' API, NCHW views)
     t_cls, t_bbox = model.ori_model(x.cuda(), mode="tensor")
@@ -59,7 +63,10 @@ def test_f7_reference_fixture_losses_and_grads(golden):
             continue
         errs.append(abs(float(gr.double().norm()) - ref) / ref)
         assert errs[-1] < 5e-2, (k, float(gr.double().norm()), ref)
-    assert float(np.median(errs)) < 1e-4, float(np.median(errs))
+    # the R101 70+10 step is ~16x worse conditioned than R50 40+40 (twice the ReLUs, 10 new classes, few positives):
+    # the oracle itself moves by 2.7e-4 (median grad-norm) under a 2e-6 input perturbation, 1.7e-5 for R50
+    # (tests/test_oracle_sensitivity.py)
+    assert float(np.median(errs)) < (1e-4 if depth == 50 else 2e-3), float(np.median(errs))
     print("grad-norm rel err: median %.2e max %.2e" % (float(np.median(errs)), max(errs)))
     # teacher is frozen
     assert all(p.grad is None for k, p in params.items() if k.startswith("ori_model."))

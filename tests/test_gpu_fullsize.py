@@ -54,3 +54,24 @@ def test_streamk_equals_tile_parallel_and_step_is_sane():
     kc = t.keep_count.cpu()
     assert (kc > 0).all() and (kc <= cnt[:, 1]).all()
     assert 1.0 < logs_a[0]["loss"] < 10.0
+
+
+def test_r101_70_plus_10_full_size_step_is_sane():
+    """BASELINE.json configs[3] at full size: GFL-R101, 70 old + 10 new classes, 2 images of 800x1344."""
+    import bench
+    import e2e_util as U
+    from erd_amd.engine import ERDTrainer
+    tsd, ssd = f7_state_dicts(70, 80, 101)
+    model = build_erd(tsd, ssd, cfg_first=U.CFG_FIRST70, cfg_incre=U.CFG_INCRE10)
+    tr = ERDTrainer(model, lr=0.01, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0)
+    batches = [bench.synthetic_gpu_batch(2, seed=20 + i, device=torch.device("cuda", 0), num_new=10) for i in range(2)]
+    logs = [{k: float(v.detach()) for k, v in tr.train_step(*batches[i % 2]).items()} for i in range(3)]
+    tr.flush()
+    torch.cuda.synchronize()
+    assert all(0.5 < l["loss"] < 20.0 for l in logs), logs
+    assert len([k for k in logs[0] if k.startswith("loss_dist")]) == 2
+    t = model.teacher_pass(batches[0][0])
+    assert t.t_cls.shape == (2, 22400, 70)
+    cnt = t.ers["counts"].cpu()
+    assert ((cnt > 0.001 * 22400) & (cnt < 0.12 * 22400)).all(), cnt
+    assert all(torch.isfinite(p).all() for p in model.parameters())

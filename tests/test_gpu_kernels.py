@@ -242,3 +242,22 @@ def test_data_preprocessor_bit_exact_vs_oracle():
     ref = torch.full((1, 3, 32, 48), 7.0)
     ref[0, :, :20, :33] = (f[0] - torch.tensor([1.5, 2.5, 3.5]).view(3, 1, 1)) / torch.tensor([2.0, 3.0, 7.0]).view(3, 1, 1)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("Cout", [70, 10, 2, 129])
+def test_conv_forward_cout_not_multiple_of_4(K, Cout):
+    """a 70-class teacher head (BASELINE configs[3]): output rows are not 16-B aligned -> the scalar epilogue"""
+    N, Cin, H, W = 2, 256, 13, 21
+    x = G.randn(31, N, Cin, H, W)
+    w = G.randn(32, Cout, Cin, 3, 3, scale=(2.0 / (Cin * 9)) ** 0.5)
+    b = G.randn(33, Cout, scale=0.1)
+    ref = F.conv2d(x, w, b, 1, 1)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    K.conv_forward([nhwc(x)], w.permute(0, 2, 3, 1).contiguous().cuda(), [out], 3, 1, 1, shift=b.cuda())
+    assert relerr(to_nchw(out), ref) < 2e-5
+    res = G.randn(34, N, Cout, H, W)
+    out2 = torch.empty_like(out)
+    K.conv_forward([nhwc(x)], w.permute(0, 2, 3, 1).contiguous().cuda(), [out2], 3, 1, 1, scale=(0.5 + G.rand(35, Cout)).cuda(),
+                   shift=b.cuda(), res=[nhwc(res)], relu=True)
+    assert relerr(to_nchw(out2), F.relu(F.conv2d(x, w, None, 1, 1) * (0.5 + G.rand(35, Cout)).view(1, -1, 1, 1) +
+                                        b.view(1, -1, 1, 1) + res)) < 2e-5

@@ -198,3 +198,15 @@ def test_leaf_values_vs_reference_fixture(K, golden):
     cnt = torch.tensor([[a.shape[1], 0]], dtype=torch.int32)
     s = K.l2_distill(a.cuda(), b.cuda(), idx.cuda(), cnt.cuda(), 40)
     assert float(s[0]) / a[0].numel() == pytest.approx(float(g["l2"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("C", [70, 10, 37])
+def test_ers_channel_count_not_multiple_of_4(K, C):
+    """70 old classes (BASELINE configs[3]): the per-row kernel instead of the float4 slab one, same index sets"""
+    cls = torch.stack([G.ers_inputs(420 + n, A=3000, C=C)[0] for n in range(2)])
+    bbox = torch.stack([G.ers_inputs(420 + n, A=3000, C=C)[1] for n in range(2)])
+    r = K.ers_select(cls.cuda(), bbox.cuda())
+    for n in range(2):
+        ic, ib, _, _ = O.ers_select_single(cls[n], bbox[n])
+        kc, kb = [int(v) for v in r["counts"][n].cpu()]
+        assert torch.equal(r["idx_cls"][n, :kc].cpu(), ic) and torch.equal(r["idx_bbox"][n, :kb].cpu(), ib)

@@ -183,28 +183,30 @@ def test_f6_head_losses_and_grads(golden):
         assert np.array_equal(aux["ers_bbox"][i].numpy(), g[f"ers_bbox{i}"])
 
 
-def test_f7_tiny_end_to_end(golden):
-    g = golden("f7_tiny_e2e.npz")
-    tsd = O.procedural_state_dict(40, seed=0)
+@pytest.mark.parametrize("fixture,c_old,depth,nparam", [("f7_tiny_e2e.npz", 40, 50, 32215193),
+                                                        ("f9_tiny_e2e_r101_70_10.npz", 70, 101, 51207321)])
+def test_f7_tiny_end_to_end(golden, fixture, c_old, depth, nparam):
+    g = golden(fixture)
+    tsd = O.procedural_state_dict(c_old, depth=depth, seed=0)
     ssd = O.student_state_from_teacher(tsd, 80, seed=1)
     for k in sorted(ssd):
         if O.trainable(k) and ssd[k].dim() == 4:
             ssd[k] = ssd[k] + 0.02 * ssd[k].abs().mean() * G.randn(700 + len(k), *ssd[k].shape)
     sd = {k: (v.clone().requires_grad_(True) if O.trainable(k) and v.dtype == torch.float32 else v)
           for k, v in ssd.items()}
-    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=0)
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 80 - c_old, seed=0)
     x, metas = O.preprocess(imgs)
-    t_cls, t_bbox = O.gfl_forward(tsd, x)
+    t_cls, t_bbox = O.gfl_forward(tsd, x, depth)
     close(t_cls[0][0, :, ::4, ::4], g["teacher_cls0_sample"], rtol=1e-4, atol=1e-5)
     close(t_bbox[4], g["teacher_bbox4"], rtol=1e-4, atol=1e-5)
-    losses = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80)
+    losses = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, c_old, 80, depth=depth)
     for k in ("loss_cls", "loss_bbox", "loss_dfl", "loss_dist_cls", "loss_dist_bbox"):
         close(torch.stack([v.detach() for v in losses[k]]), g[k], rtol=1e-4, atol=1e-7)
     total = O.parse_losses(losses)
     total.backward()
     names = [str(n) for n in g["grad_names"]]
-    assert sorted(names) == sorted(k for k in sd if O.trainable(k))      # same trainable set (32 215 193)
-    assert sum(sd[k].numel() for k in names) == 32215193
+    assert sorted(names) == sorted(k for k in sd if O.trainable(k))      # same trainable set
+    assert sum(sd[k].numel() for k in names) == nparam, sum(sd[k].numel() for k in names)
     for i, k in enumerate(names):
         gr = sd[k].grad
         assert float(gr.double().norm()) == pytest.approx(float(g["grad_norms"][i]), rel=1e-3, abs=1e-9), k
