@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--teacher-graph", action="store_true",
+                    help="replay the frozen teacher's pass from a hipGraph (BASELINE configs[4]); same arithmetic")
     ap.add_argument("--serial", action="store_true",
                     help="no stream concurrency in the timed region either (the rocprofv3 companion run)")
     args = ap.parse_args()
@@ -145,7 +147,7 @@ def main():
     opt = cfg.optim_wrapper.optimizer
     trainer = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
                          base_batch_size=cfg.auto_scale_lr.base_batch_size, batch_size_per_gpu=args.batch,
-                         auto_scale_lr=cfg.auto_scale_lr.enable)
+                         auto_scale_lr=cfg.auto_scale_lr.enable, teacher_graph=args.teacher_graph)
     batches = [synthetic_gpu_batch(args.batch, seed=rank * 1000 + i, device=device) for i in range(2)]
 
     def set_serial(flag: bool):
@@ -204,6 +206,7 @@ def main():
                                    "800x1344, fp32, procedural weights", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
+            "teacher": "hipGraph replay" if args.teacher_graph else "eager launches",
         }
         if ktime:
             dom = max(ktime.values(), key=lambda r: r["ms"])

@@ -190,3 +190,47 @@ def test_trainer_three_steps_follow_oracle_sgd_trajectory():
     for k, v in ssd.items():
         if k not in names and v.dtype == torch.float32:
             assert torch.equal(dict(model.state_dict())[k].cpu(), v), k
+
+
+def test_teacher_hipgraph_replay_equals_eager_on_mixed_resolutions():
+    """BASELINE.json configs[4]: the frozen teacher's pass captured into a hipGraph per padded shape; replays on new
+    pixels give bit-identical teacher logits, ERS index lists and NMS masks; a trainer using it logs the same losses."""
+    from erd_amd.engine import ERDTrainer, TeacherGraphs
+    tsd, ssd = f7_state_dicts()
+    model = build_erd(tsd, ssd)
+    tg = TeacherGraphs(model)
+    side = torch.cuda.Stream()
+    rng = np.random.RandomState(3)
+    shapes = [(2, 3, 128, 160), (2, 3, 96, 224), (2, 3, 128, 160), (2, 3, 96, 224), (2, 3, 128, 160)]
+    for i, shp in enumerate(shapes):
+        x = torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda()
+        with torch.no_grad():
+            ref = model.teacher_pass(x)
+        want = [t.clone() for t in ref.tensors()]
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            got = tg.run(x)
+        torch.cuda.current_stream().wait_stream(side)
+        assert got.sizes == ref.sizes
+        for a, b in zip(got.tensors(), want):
+            if a.dtype == torch.int64 and a.dim() == 2:       # ERS index lists: only the first count entries are defined
+                continue
+            assert torch.equal(a, b), (i, shp)
+        cnt = got.ers["counts"].cpu()
+        for n in range(shp[0]):
+            for k, name in enumerate(("idx_cls", "idx_bbox")):
+                assert torch.equal(got.ers[name][n, :int(cnt[n, k])], ref.ers[name][n, :int(cnt[n, k])])
+    assert len(tg.graphs) == 2
+    # trainer equivalence (two steps, alternating shapes)
+    logs = {}
+    for use_graph in (False, True):
+        m = build_erd(tsd, ssd)
+        tr = ERDTrainer(m, lr=0.01, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0, teacher_graph=use_graph)
+        out = []
+        for s in (0, 1, 0):
+            imgs, boxes, labels = O.synthetic_batch(2, 123 if s == 0 else 90, 153 if s == 0 else 220, 40, seed=s)
+            x, metas = O.preprocess(imgs)
+            out.append(float(tr.train_step(x.cuda(), make_samples(boxes, labels, metas))["loss"].detach()))
+        tr.flush()
+        logs[use_graph] = out
+    assert np.allclose(logs[True], logs[False], rtol=1e-5), logs
