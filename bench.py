@@ -29,6 +29,7 @@ import torch.distributed as dist
 
 H, W = 800, 1333
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = f32 vector rate
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -122,6 +123,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--teacher-graph", action="store_true",
                     help="replay the frozen teacher's pass from a hipGraph (BASELINE configs[4]); same arithmetic")
+    ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
+                    help="f32: fp32 matrix cores (BASELINE configs[1], the headline).  bf16: the 1x1/3x3 convolutions on the "
+                         "bf16 matrix cores, fp32 accumulation and storage (BASELINE configs[2])")
     ap.add_argument("--serial", action="store_true",
                     help="no stream concurrency in the timed region either (the rocprofv3 companion run)")
     args = ap.parse_args()
@@ -143,6 +147,7 @@ def main():
     from erd_amd import functional as Fn
     from erd_amd import kernels as K
     from erd_amd.engine import ERDTrainer
+    K.set_compute(args.compute)
     model, cfg = build_model(device, rank)
     opt = cfg.optim_wrapper.optimizer
     trainer = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
@@ -201,20 +206,22 @@ def main():
             "metric": "images/sec GFL-R50 40+40 incre step @1333x800",
             "value": round(images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
             "config": {"workload": "gfl_r50_fpn first_40_incre_last_40 ERD (BASELINE configs[1]), 1333x800 padded to "
-                                   "800x1344, fp32, procedural weights", "batch_per_gpu": args.batch,
+                                   "800x1344, " + ("fp32" if args.compute == "f32" else "bf16 multiplicands / fp32 accumulate+storage") +
+                                   ", procedural weights", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
             "teacher": "hipGraph replay" if args.teacher_graph else "eager launches",
         }
         if ktime:
             dom = max(ktime.values(), key=lambda r: r["ms"])
+            peak_tf = FP32_MFMA_PEAK_TFLOPS if (args.compute == "f32" or dom["kernel"] == "conv_wgrad") else BF16_MFMA_PEAK_TFLOPS
             traffic, traffic_src = pmc_traffic_per_launch("conv_wgrad" if dom["kernel"] == "conv_wgrad" else "conv_igemm")
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"],
                                "achieved": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
-                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "peak": peak_tf, "unit": "TFLOP/s",
+                               "frac": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12 / peak_tf, 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, PMC)",
                                "traffic_source": traffic_src, "pass": f"{rsteps} extra steps, streams serialized",
                                "launches_per_step": dom["launches"] // rsteps,

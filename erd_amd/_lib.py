@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS), ("wk", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32), ("colsum", C.c_void_p),
-                ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t)]
+                ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("w_bf16", C.c_void_p)]
 
 
 class WgradSeg(C.Structure):
@@ -47,7 +47,7 @@ class WgradDesc(C.Structure):
                 ("Cin", i32), ("Cout", i32), ("ntaps", i32),
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
-                ("part", C.c_void_p), ("nsplit", i32)]
+                ("part", C.c_void_p), ("nsplit", i32), ("bf16_multiplicands", i32)]
 
 
 class Levels(C.Structure):
@@ -59,6 +59,7 @@ _SIGNATURES = {
     # name: argtypes (restype is always int unless noted)
     "erd_conv_igemm": [C.POINTER(ConvDesc), P],
     "erd_conv_igemm_ws_bytes": [i32],
+    "erd_to_bf16": [P, P, i64, P],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
     "erd_weight_transpose": [P, P, P, i32, i32, i32, i32, P],

@@ -26,6 +26,15 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// two fp32 -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float pack_bf16(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(float, __builtin_convertvector(v, bf16x2v));
+}
 
 constexpr int NTHREADS = 256;
 
@@ -65,7 +74,11 @@ int xcd_order_enabled() {
     return v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW>
+// BF = true: the same kernel on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): a 16-B LDS chunk holds 8 bf16
+// k-values instead of 4 floats (a K-slice is CH*8 values), activations are read as fp32 (two 16-B loads per chunk)
+// and rounded to bf16 on their way into LDS, weights come pre-rounded (erd_conv_desc::w_bf16); accumulation, the
+// stream-K hand-over and the epilogue stay fp32.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false>
 __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
                                                                      const SkWs ws) {
     constexpr int FM = BM / (WAVES_M * 32);
@@ -74,7 +87,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     constexpr int RPP = NTHREADS / CH;       // rows staged per pass
     constexpr int AJ = BM / RPP;             // float4 loads per thread for A
     constexpr int BJ = BN / RPP;
-    constexpr int BK = BKT;
+    constexpr int KPC = BF ? 8 : 4;          // k-values per 16-B chunk
+    constexpr int BK = CH * KPC;             // k-values per K-slice
     constexpr bool SGB = ERD_SGB;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const RowInfo ri = rows[r0 + RPP * j];
-            a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk * 4) * 4u;
+            a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk * KPC) * 4u;
             unsigned m = 0;
             for (int t = 0; t < p.ntaps; ++t) {
                 const int ih = ri.ih0 + p.dy[t], iw = ri.iw0 + p.dx[t];
@@ -179,29 +193,33 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int co = n0 + r0 + RPP * j;
-            b_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunk * 4) * 4u : OOB;
+            b_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunk * KPC) * (BF ? 2u : 4u) : OOB;
         }
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(w), 0, (int)((long long)p.Cout * p.wrow * 4), 0x00020000);
+            BF ? const_cast<void*>(p.w_bf16) : (void*)const_cast<float*>(w), 0,
+            (int)((long long)p.Cout * p.wrow * (BF ? 2 : 4)), 0x00020000);
 
         float4 ra[AJ], rb[BJ];
+        float4 ra1[BF ? AJ : 1];     // bf16 mode: the second half (k+4..k+7) of each 8-value chunk
         int tap = ks / cpt, cc = ks - tap * cpt;
         // wave-uniform description of the K-slice being fetched
         int adelta = 0, bdelta = 0, ctap = 0;
-        bool cok = false;
+        bool cok = false, cok1 = false;
         auto slice_begin = [&]() {
             const int cb = cc * BK;
             ctap = tap;
             adelta = ((p.dy[tap] * IW + p.dx[tap]) * Cin + cb) * 4;    // bytes, relative to tap (0,0)
-            bdelta = (p.wk[tap] + cb) * 4;
-            cok = cb + chunk * 4 < Cin;   // Cin % 4 == 0: a 16-B chunk is all-in or all-out
+            bdelta = (p.wk[tap] + cb) * (BF ? 2 : 4);
+            cok = cb + chunk * KPC < Cin;   // Cin % 4 == 0: a 4-value group is all-in or all-out
+            cok1 = BF && cb + chunk * KPC + 4 < Cin;
             if (++cc == cpt) { cc = 0; ++tap; }
         };
         auto load_a = [&](int j) {
             const bool ok = cok && ((a_mask[j] >> ctap) & 1u);
             ra[j] = buf_load16(rs_in, ok ? a_base[j] + (unsigned)adelta : OOB);
+            if (BF) ra1[j] = buf_load16(rs_in, (ok && cok1) ? a_base[j] + (unsigned)adelta + 16u : OOB);
         };
         auto load_b = [&](int j) {
             rb[j] = buf_load16(rs_w, cok ? b_base[j] + (unsigned)bdelta : OOB);
@@ -210,7 +228,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const int row = r0 + RPP * j;
-                As[buf * BM * CH + row * CH + swzc(row, chunk)] = ra[j];
+                if (BF)      // (weights past Cin inside the chunk meet zeros here, so partial chunks are exact)
+                    As[buf * BM * CH + row * CH + swzc(row, chunk)] =
+                        make_float4(pack_bf16(ra[j].x, ra[j].y), pack_bf16(ra[j].z, ra[j].w),
+                                    pack_bf16(ra1[j].x, ra1[j].y), pack_bf16(ra1[j].z, ra1[j].w));
+                else
+                    As[buf * BM * CH + row * CH + swzc(row, chunk)] = ra[j];
             }
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         store_lds(0);
         __syncthreads();
 
-        constexpr int KSTEPS = BK / 8;
+        constexpr int KSTEPS = CH / 2;      // one k-step = the two chunks (h = 0 / 1) a wave's lanes read
         constexpr int APS = (AJ + KSTEPS - 1) / KSTEPS, BPS = (BJ + KSTEPS - 1) / KSTEPS;   // loads per k-step
         for (int kt = ks; kt < ke; ++kt) {
             const int buf = (kt - ks) & 1;
@@ -276,6 +299,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
+                        if (BF) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, fa[cur][i]), __builtin_bit_cast(bf16x8, fb[cur][j]),
+                                acc[i][j], 0, 0, 0);
+                            continue;
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
@@ -611,6 +640,167 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wg
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// weight gradient on the bf16 matrix cores (erd_wgrad_desc::bf16_multiplicands): same GEMM over pixels, but the MFMA
+// wants 8 consecutive K values (pixels) of ONE channel per lane while memory is pixel-major.  Each thread therefore
+// loads an 8-pixel x 4-channel micro-tile (8 coalesced 16-B loads), rounds to bf16 and transposes it in registers
+// into four 16-B vectors (one channel, 8 pixels each) that go to channel-major LDS rows [128 ch][64 px] with the
+// 128-B-row XOR swizzle; fragments are then single ds_read_b128s and one v_mfma_f32_32x32x16_bf16 covers 16 pixels.
+// Partial slabs, split-K and the reduce kernel are shared with the fp32 path.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(const erd_wgrad_desc p) {
+    constexpr int BM = 128, BN = 128, BK = 64;          // BK pixels per K-slice = 8 chunks of 8 pixels
+    constexpr int FM = 2, FN = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* As = reinterpret_cast<float4*>(smem);          // [2][BM rows][8 chunks]
+    float4* Bs = As + 2 * BM * 8;                          // [2][BN rows][8 chunks]
+    int2* offs = reinterpret_cast<int2*>(Bs + 2 * BN * 8); // [2][BK]
+
+    const int tid = threadIdx.x;
+    const int nci = (p.Cin + BN - 1) / BN;
+    const int wg = blockIdx.x;
+    const int nxb = nci * p.ntaps, nyb = (p.Cout + BM - 1) / BM;
+    const int bx = wg % nxb, by = (wg / nxb) % nyb, bz = wg / (nxb * nyb);
+    const int tap = bx / nci;
+    const int ci0 = (bx % nci) * BN;
+    const int co0 = by * BM;
+    int P = 0;
+    for (int l = 0; l < p.nseg; ++l) P += p.seg[l].N * p.seg[l].GH * p.seg[l].GW;
+    const int nkt_total = (P + BK - 1) / BK;
+    const int per = (nkt_total + p.nsplit - 1) / p.nsplit;
+    const int kt_begin = bz * per;
+    const int kt_end = min(nkt_total, kt_begin + per);
+    const int dyt = p.dy[tap], dxt = p.dx[tap];
+
+    const int cc = tid & 31, pg = tid >> 5;               // 4-channel group, 8-pixel group of this thread's micro-tiles
+    const bool a_cok = co0 + cc * 4 < p.Cout;
+    const bool b_cok = ci0 + cc * 4 < p.Cin;
+    const int a_col = co0 + cc * 4, b_col = ci0 + cc * 4;
+
+    auto compute_offsets = [&](int kt, int slot) {
+        if (tid < BK) {
+            int pp = kt * BK + tid;
+            int2 o = make_int2(-1, -1);
+            if (pp < P && kt < kt_end) {
+                int l = 0;
+#pragma unroll 1
+                for (; l < p.nseg - 1; ++l) {
+                    const int pl = p.seg[l].N * p.seg[l].GH * p.seg[l].GW;
+                    if (pp < pl) break;
+                    pp -= pl;
+                }
+                const erd_wgrad_seg& g = p.seg[l];
+                const int GHW = g.GH * g.GW;
+                const int n = pp / GHW;
+                const int rem = pp - n * GHW;
+                const int a = rem / g.GW;
+                const int b = rem - a * g.GW;
+                o.x = (int)(g.dz_off + n * g.dz_nstride) +
+                      ((a * p.out_stride + p.oy) * g.OW + (b * p.out_stride + p.ox)) * p.Cout;
+                const int ih = a * p.in_stride + dyt, iw = b * p.in_stride + dxt;
+                if ((unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW)
+                    o.y = (int)(g.x_off + n * g.x_nstride) + (ih * g.IW + iw) * p.Cin;
+            }
+            offs[slot * BK + tid] = o;
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dz), 0, (int)(p.dz_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)(p.x_elems * 4), 0x00020000);
+    float4 ra[8], rb[8];
+    auto load_global = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int2 o = offs[slot * BK + pg * 8 + i];
+            ra[i] = buf_load16(rs_dz, (o.x >= 0 && a_cok) ? (unsigned)(o.x + a_col) * 4u : OOB);
+            rb[i] = buf_load16(rs_x, (o.y >= 0 && b_cok) ? (unsigned)(o.y + b_col) * 4u : OOB);
+        }
+    };
+    auto swz8 = [](int row, int c) { return c ^ ((row >> 1) & 7); };
+    auto store_lds = [&](int buf) {
+        float4* Ad = As + buf * BM * 8;
+        float4* Bd = Bs + buf * BN * 8;
+#define ERD_T4(v, m) make_float4(pack_bf16(v[0].m, v[1].m), pack_bf16(v[2].m, v[3].m), pack_bf16(v[4].m, v[5].m), \
+                                 pack_bf16(v[6].m, v[7].m))
+        const int r = cc * 4;
+        Ad[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_T4(ra, x);
+        Ad[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_T4(ra, y);
+        Ad[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_T4(ra, z);
+        Ad[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_T4(ra, w);
+        Bd[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_T4(rb, x);
+        Bd[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_T4(rb, y);
+        Bd[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_T4(rb, z);
+        Bd[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_T4(rb, w);
+#undef ERD_T4
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        compute_offsets(kt_begin, 0);
+        __syncthreads();
+        load_global(0);
+        compute_offsets(kt_begin + 1, 1);
+        store_lds(0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            const bool more = kt + 1 < kt_end;
+            if (more) load_global(buf ^ 1);
+            compute_offsets(kt + 2, buf);
+            const float4* Ab = As + buf * BM * 8;
+            const float4* Bb = Bs + buf * BN * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + h;
+                float4 fa[FM], fb[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = (wm * FM + i) * 32 + li;
+                    fa[i] = Ab[row * 8 + swz8(row, c)];
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = (wn * FN + j) * 32 + li;
+                    fb[j] = Bb[row * 8 + swz8(row, c)];
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+            }
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* __restrict__ part = p.part + (int64_t)bz * p.Cout * p.ntaps * p.Cin;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int ci = ci0 + (wn * FN + j) * 32 + li;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout) part[((int64_t)co * p.ntaps + tap) * p.Cin + ci] = acc[i][j][r];
+            }
+    }
+}
+
 // dW[co][k] (+)= rowscale[co] * sum_s part[s][co][k];  rowdot[co] += sum_k w[co][k] * G[co][k]
 // grid (Cout, K/1024): every thread sums one float4 column of the nsplit slabs (coalesced across the block);
 // rowdot is accumulated with one atomic per block (the caller zeroes it).
@@ -695,9 +885,9 @@ int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int MINW>
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
-    constexpr int BK = BKT;
+    constexpr int BK = (BKT / 4) * (BF ? 8 : 4);
     int tiles = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const int64_t M = (int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW;
@@ -709,7 +899,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
     const size_t oper = (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4), stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
     const size_t lds = (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -744,6 +934,7 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d->ntaps >= 1 && d->ntaps <= ERD_MAX_TAPS, "conv: ntaps=%d", d->ntaps);
     ERD_REQUIRE(d->Cin > 0 && d->Cin % 4 == 0, "conv: Cin=%d must be a multiple of 4", d->Cin);
     ERD_REQUIRE(d->Cout > 0 && d->wrow % 4 == 0, "conv: Cout=%d wrow=%d", d->Cout, d->wrow);
+    ERD_REQUIRE(d->w_bf16 || d->w, "conv: no weights");
     for (int s = 0; s < d->nseg; ++s) {
         const erd_conv_seg& g = d->seg[s];
         ERD_REQUIRE(g.in && g.out, "conv: null tensor in segment %d", s);
@@ -755,6 +946,11 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     // kernel; short ones (1x1 convs on <=256 channels) are prologue/epilogue-latency bound and want many small
     // co-resident workgroups (BK=16, half the LDS and staging registers -> 4 workgroups per CU).
     static const int variant = getenv("ERD_IGEMM_VARIANT") ? atoi(getenv("ERD_IGEMM_VARIANT")) : 0;   // tuning aid
+    if (d->w_bf16) {    // bf16 matrix cores: the loaders, not the MFMAs, set the pace -> the plain 2-workgroup variant
+        if (variant == 2) return launch_igemm<128, 128, 2, 2, 16, 4, true>(d, st);
+        if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2, true>(d, st);
+        return launch_igemm<128, 128, 2, 2, 32, 2, true>(d, st);
+    }
     if (variant == 9) return launch_igemm<128, 128, 2, 2, 32, 1>(d, st);
     if (variant == 1) return launch_igemm<128, 128, 2, 2, 16, 3>(d, st);
     if (variant == 2) return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
@@ -803,6 +999,19 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
                 "wgrad: tensors must stay below 2 GiB (32-bit buffer byte offsets)");
     // K-slices of 16 pixels: half the LDS / staging registers of a 32-pixel slice -> four workgroups per CU hide each
     // other's staging and barrier phases (measured +10 % over 32-pixel slices at two per CU, tools/bench_conv.py)
+    if (d->bf16_multiplicands) {
+        const int nci = (d->Cin + 127) / 128, nco = (d->Cout + 127) / 128;
+        const size_t lds = (size_t)2 * (128 + 128) * 8 * sizeof(float4) + 2 * 64 * sizeof(int2);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(nci * d->ntaps * nco * d->nsplit), dim3(NTHREADS), lds,
+                           (hipStream_t)stream, *d);
+        return erd::check_launch("conv_wgrad_bf16");
+    }
     static const int variant = getenv("ERD_WGRAD_VARIANT") ? atoi(getenv("ERD_WGRAD_VARIANT")) : 1;   // tuning aid
     if (variant == 0) return launch_wgrad<32, 2>(d, (hipStream_t)stream);
     return launch_wgrad<16, 4>(d, (hipStream_t)stream);

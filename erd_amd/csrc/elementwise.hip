@@ -591,6 +591,38 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ i
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, int64_t n4,
+                                                      const float* __restrict__ tail_src, unsigned short* __restrict__ tail_dst,
+                                                      int ntail) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = src[i];
+        const f2 a = {v.x, v.y}, b = {v.z, v.w};
+        uint2 o;
+        o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf2));
+        o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf2));
+        dst[i] = o;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) {
+        const f2 a = {tail_src[threadIdx.x], 0.f};
+        tail_dst[threadIdx.x] = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf2)) & 0xffffu);
+    }
+}
+}  // namespace
+
+extern "C" int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream) {
+    ERD_REQUIRE(src && dst && n >= 0, "to_bf16: bad args");
+    if (n == 0) return 0;
+    const int64_t n4 = n / 4;
+    const int ntail = (int)(n - n4 * 4);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(n4 > 0 ? n4 : 1, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<uint2*>(dst), n4, src + n4 * 4,
+                       reinterpret_cast<unsigned short*>(dst) + n4 * 4, ntail);
+    return erd::check_launch("to_bf16");
+}
+
 extern "C" int erd_preprocess_image(const void* img, int is_uint8, int h, int w, float* out, int H, int W,
                                     const float* mean3, const float* std3, int flip_channels, float pad_value,
                                     erd_stream_t stream) {

@@ -4,6 +4,7 @@ launch geometry.  No arithmetic happens here and there is no non-HIP fallback.""
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -150,6 +151,43 @@ def make_levels(sizes: Sequence[Tuple[int, int]]) -> Levels:
 
 
 # ---------------------------------------------------------------------------------------------
+# compute mode of the 1x1 / 3x3 convolutions: "f32" (fp32 matrix cores, the headline configuration) or "bf16"
+# (BASELINE.json configs[2]: both multiplicands rounded to bf16 on their way to the bf16 matrix cores, fp32
+# accumulation, epilogues and storage).  Process-wide switch: set_compute("bf16") / ERD_COMPUTE=bf16.
+# ---------------------------------------------------------------------------------------------
+COMPUTE = _os.environ.get("ERD_COMPUTE", "f32")
+
+
+def set_compute(mode: str) -> None:
+    global COMPUTE
+    if mode not in ("f32", "bf16"):
+        raise ValueError(f"compute mode {mode!r}: 'f32' or 'bf16'")
+    COMPUTE = mode
+
+
+def to_bf16(t: Tensor) -> Tensor:
+    assert t.is_contiguous() and t.dtype == torch.float32
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    call("erd_to_bf16", _p(t), _p(out), t.numel(), _stream())
+    return out
+
+
+def _weights_bf16(w: Tensor) -> Tensor:
+    """bf16 copy of a contiguous OHWI weight view.  Frozen weights (teacher, stem/layer1) are converted once: the copy
+    is cached ON the owning parameter object and validated by storage pointer + in-place version; trainable weights
+    change under the optimizer's raw-pointer update, so they are converted per use (one small launch)."""
+    base = w._base if w._base is not None else w
+    if base.requires_grad or w.requires_grad:
+        return to_bf16(w.detach())
+    ver = (w.data_ptr(), base._version, tuple(w.shape))
+    hit = getattr(base, "_erd_bf16", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, to_bf16(w.detach()))
+        base._erd_bf16 = hit
+    return hit[1]
+
+
+# ---------------------------------------------------------------------------------------------
 # convolution (forward form, input-gradient form, weight gradient)
 # ---------------------------------------------------------------------------------------------
 def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor], alpha: Optional[Tensor],
@@ -176,7 +214,6 @@ def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor
         sg.res_nstride = res.stride(0)
 
 
-import os as _os
 STREAMK = _os.environ.get('ERD_STREAMK', '1') != '0'     # stream-K work decomposition of the implicit-GEMM launches (see conv_mfma.hip)
 _SK_TILES = 1 << 16
 
@@ -225,6 +262,9 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     d.shift = 0 if shift is None else shift.data_ptr()
     d.relu = 1 if relu else 0
     d.colsum = 0
+    if COMPUTE == "bf16":
+        wb = _weights_bf16(w)          # (kept alive by this frame until the launch is queued; stream-ordered free)
+        d.w_bf16 = wb.data_ptr()
     _attach_sk_ws(d, w.device)
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
     nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel()) if _TIMING is not None else 0.0
@@ -248,6 +288,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
     buffer that already holds the other branch's gradient, or zero it first."""
     _require_gpu(wt, *dzs, *dxs)
     Cin, Cout = wt.shape[0], wt.shape[3]       # of the forward conv
+    wtb = to_bf16(wt) if COMPUTE == "bf16" else None
     classes = [(0, 0)] if stride == 1 else [(py, px) for py in range(stride) for px in range(stride)]
     for (py, px) in classes:
         taps = []
@@ -283,6 +324,8 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.shift = 0
         d.relu = 0
         d.colsum = 0 if colsum is None else colsum.data_ptr()
+        if wtb is not None:
+            d.w_bf16 = wtb.data_ptr()
         _attach_sk_ws(d, wt.device)
         flop = 2.0 * sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg)) * Cin * len(taps) * Cout
         # (stride 2: each parity class reads dz once and writes a quarter of dx)
@@ -339,6 +382,7 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
     d.part = part.data_ptr()
     d.nsplit = S
+    d.bf16_multiplicands = 1 if COMPUTE == "bf16" else 0
     flop = 2.0 * npix * Cout * Cin * k * k
     nbytes = 4.0 * (sum(t.numel() for t in xs) + sum(t.numel() for t in dzs) + part.numel()) if _TIMING is not None else 0.0
     _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes)

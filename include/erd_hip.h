@@ -75,6 +75,10 @@ typedef struct {
      * The ticket area (the last max_tiles*4 bytes) must be ZERO on entry; the kernel leaves it zero. */
     void* sk_ws;
     size_t sk_ws_bytes;
+    /* optional: the same weights rounded to bf16, [Cout][wrow] (erd_to_bf16).  When set the launch runs on the
+     * bf16 matrix cores (v_mfma_f32_32x32x16_bf16): activations are rounded to bf16 as they are staged, products
+     * are exact, accumulation / epilogue / output stay fp32 (BASELINE.json configs[2]; `w` is then unused). */
+    const void* w_bf16;
 } erd_conv_desc;
 
 /* replaces: F.conv2d dispatches at resnet.py:268-283, res_layer.py:57-63, fpn.py:196,215-220,
@@ -82,6 +86,8 @@ typedef struct {
  * and, run on dz with transformed weights, their convolution_backward (input grad). */
 int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream);
 size_t erd_conv_igemm_ws_bytes(int max_tiles);
+/* dst[i] = bf16(src[i]) (round to nearest even), n elements */
+int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
@@ -106,6 +112,7 @@ typedef struct {
     int in_stride, out_stride, oy, ox;
     float* part;         /* [nsplit][Cout][ntaps][Cin] */
     int nsplit;
+    int bf16_multiplicands; /* 1: round dz and x to bf16 as they are staged and use the bf16 matrix cores (fp32 partials) */
 } erd_wgrad_desc;
 int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream);
 

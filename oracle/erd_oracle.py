@@ -163,6 +163,29 @@ def student_state_from_teacher(teacher_sd: Dict[str, Tensor], num_classes: int, 
 # ----------------------------------------------------------------------------
 # network forward (functional)
 # ----------------------------------------------------------------------------
+# BASELINE.json configs[2] ("bf16"): the HIP path can run every 1x1 / 3x3 convolution on the bf16 matrix cores --
+# both multiplicands rounded to bf16 (round-to-nearest-even), products exact, accumulation / normalisation /
+# losses / storage in fp32; the 7x7 stem stays fp32.  `with bf16_multiplicands():` makes the restatement do the
+# same, so the forward pass can be compared as tightly as in fp32 (only the summation order differs).
+_BF16_MULTIPLICANDS = False
+
+
+class bf16_multiplicands:
+    def __enter__(self):
+        global _BF16_MULTIPLICANDS
+        self.prev, _BF16_MULTIPLICANDS = _BF16_MULTIPLICANDS, True
+
+    def __exit__(self, *exc):
+        global _BF16_MULTIPLICANDS
+        _BF16_MULTIPLICANDS = self.prev
+
+
+def _conv2d(x, w, b=None, stride=1, padding=0):
+    if _BF16_MULTIPLICANDS:
+        x, w = x.to(torch.bfloat16).to(torch.float32), w.to(torch.bfloat16).to(torch.float32)
+    return F.conv2d(x, w, b, stride, padding)
+
+
 def _bn_eval(x, sd, p):
     """Frozen-statistics BN: every BN runs in eval mode (norm_eval=True, resnet.py:648-657)."""
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
@@ -182,11 +205,11 @@ def resnet_forward(sd: Dict[str, Tensor], x: Tensor, depth: int = 50, prefix: st
             p = f"layer{li + 1}.{b}"
             stride = 2 if (b == 0 and li > 0) else 1
             identity = x
-            out = F.relu(_bn_eval(F.conv2d(x, sub[p + ".conv1.weight"]), sub, p + ".bn1"))
-            out = F.relu(_bn_eval(F.conv2d(out, sub[p + ".conv2.weight"], None, stride, 1), sub, p + ".bn2"))
-            out = _bn_eval(F.conv2d(out, sub[p + ".conv3.weight"]), sub, p + ".bn3")
+            out = F.relu(_bn_eval(_conv2d(x, sub[p + ".conv1.weight"]), sub, p + ".bn1"))
+            out = F.relu(_bn_eval(_conv2d(out, sub[p + ".conv2.weight"], None, stride, 1), sub, p + ".bn2"))
+            out = _bn_eval(_conv2d(out, sub[p + ".conv3.weight"]), sub, p + ".bn3")
             if b == 0:
-                identity = _bn_eval(F.conv2d(x, sub[p + ".downsample.0.weight"], None, stride), sub,
+                identity = _bn_eval(_conv2d(x, sub[p + ".downsample.0.weight"], None, stride), sub,
                                     p + ".downsample.1")
             x = F.relu(out + identity)
         outs.append(x)
@@ -198,14 +221,14 @@ def fpn_forward(sd: Dict[str, Tensor], feats: Sequence[Tensor], prefix: str = "n
     no norm / no activation, nearest top-down with size= (fpn.py:181-191)."""
     g = lambda k: sd[prefix + k]
     ins = feats[1:]
-    lats = [F.conv2d(ins[i], g(f"lateral_convs.{i}.conv.weight"), g(f"lateral_convs.{i}.conv.bias"))
+    lats = [_conv2d(ins[i], g(f"lateral_convs.{i}.conv.weight"), g(f"lateral_convs.{i}.conv.bias"))
             for i in range(3)]
     for i in range(2, 0, -1):
         lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode="nearest")
-    outs = [F.conv2d(lats[i], g(f"fpn_convs.{i}.conv.weight"), g(f"fpn_convs.{i}.conv.bias"), 1, 1)
+    outs = [_conv2d(lats[i], g(f"fpn_convs.{i}.conv.weight"), g(f"fpn_convs.{i}.conv.bias"), 1, 1)
             for i in range(3)]
-    outs.append(F.conv2d(outs[-1], g("fpn_convs.3.conv.weight"), g("fpn_convs.3.conv.bias"), 2, 1))
-    outs.append(F.conv2d(outs[-1], g("fpn_convs.4.conv.weight"), g("fpn_convs.4.conv.bias"), 2, 1))
+    outs.append(_conv2d(outs[-1], g("fpn_convs.3.conv.weight"), g("fpn_convs.3.conv.bias"), 2, 1))
+    outs.append(_conv2d(outs[-1], g("fpn_convs.4.conv.weight"), g("fpn_convs.4.conv.bias"), 2, 1))
     return outs
 
 
@@ -218,12 +241,12 @@ def gfl_head_forward(sd: Dict[str, Tensor], feats: Sequence[Tensor], prefix: str
     for l, x in enumerate(feats):
         c, r = x, x
         for i in range(4):
-            c = F.relu(F.group_norm(F.conv2d(c, g(f"cls_convs.{i}.conv.weight"), None, 1, 1), 32,
+            c = F.relu(F.group_norm(_conv2d(c, g(f"cls_convs.{i}.conv.weight"), None, 1, 1), 32,
                                     g(f"cls_convs.{i}.gn.weight"), g(f"cls_convs.{i}.gn.bias"), 1e-5))
-            r = F.relu(F.group_norm(F.conv2d(r, g(f"reg_convs.{i}.conv.weight"), None, 1, 1), 32,
+            r = F.relu(F.group_norm(_conv2d(r, g(f"reg_convs.{i}.conv.weight"), None, 1, 1), 32,
                                     g(f"reg_convs.{i}.gn.weight"), g(f"reg_convs.{i}.gn.bias"), 1e-5))
-        cls_scores.append(F.conv2d(c, g("gfl_cls.weight"), g("gfl_cls.bias"), 1, 1))
-        bbox_preds.append((F.conv2d(r, g("gfl_reg.weight"), g("gfl_reg.bias"), 1, 1)
+        cls_scores.append(_conv2d(c, g("gfl_cls.weight"), g("gfl_cls.bias"), 1, 1))
+        bbox_preds.append((_conv2d(r, g("gfl_reg.weight"), g("gfl_reg.bias"), 1, 1)
                            * g(f"scales.{l}.scale")).float())
     return cls_scores, bbox_preds
 

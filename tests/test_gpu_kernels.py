@@ -261,3 +261,84 @@ def test_conv_forward_cout_not_multiple_of_4(K, Cout):
                    shift=b.cuda(), res=[nhwc(res)], relu=True)
     assert relerr(to_nchw(out2), F.relu(F.conv2d(x, w, None, 1, 1) * (0.5 + G.rand(35, Cout)).view(1, -1, 1, 1) +
                                         b.view(1, -1, 1, 1) + res)) < 2e-5
+
+
+@pytest.fixture
+def bf16_mode(K):
+    K.set_compute("bf16")
+    yield
+    K.set_compute("f32")
+
+
+def _r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p", CONV_CASES + [(1, 256, 70, 13, 21, 3, 1, 1)])
+def test_conv_forward_bf16_matrix_cores(K, bf16_mode, N, Cin, Cout, H, W, k, s, p):
+    """BASELINE configs[2]: multiplicands rounded to bf16 (exact products), fp32 accumulate/epilogue/output -- must agree
+    with conv(bf16(x), bf16(w)) evaluated in fp32 as tightly as the fp32 path agrees with conv(x, w)."""
+    x = G.randn(1, N, Cin, H, W)
+    w = G.randn(2, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    scale = 0.5 + G.rand(3, Cout)
+    shift = G.randn(4, Cout, scale=0.1)
+    ref = F.conv2d(_r(x), _r(w), None, s, p)
+    OH, OW = ref.shape[2:]
+    res = G.randn(5, N, Cout, OH, OW)
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.empty((N, OH, OW, Cout), device="cuda")
+    K.conv_forward([nhwc(x)], wg, [out], k, s, p)
+    assert relerr(to_nchw(out), ref) < 2e-5
+    assert relerr(to_nchw(out), F.conv2d(x, w, None, s, p)) > 1e-4        # it really is the bf16 product
+    out2 = torch.empty_like(out)
+    K.conv_forward([nhwc(x)], wg, [out2], k, s, p, scale=scale.cuda(), shift=shift.cuda(), res=[nhwc(res)], relu=True)
+    assert relerr(to_nchw(out2), F.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p", [c for c in CONV_CASES if c[2] % 4 == 0])
+def test_conv_dgrad_bf16_matrix_cores(K, bf16_mode, N, Cin, Cout, H, W, k, s, p):
+    x = G.randn(11, N, Cin, H, W).requires_grad_(True)
+    w = G.randn(12, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    y = F.conv2d(x, _r(w), None, s, p)
+    dy = G.randn(13, *y.shape)
+    xr = torch.autograd.grad(y, x, _r(dy))[0]                 # conv_transpose(bf16(dy), bf16(w)) in fp32
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wt = K.weight_transpose(wg, None)
+    dx = torch.zeros((N, H, W, Cin), device="cuda")
+    K.conv_dgrad([nhwc(dy)], wt, [dx], k, s, p)
+    assert relerr(to_nchw(dx), xr) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p", [c for c in CONV_CASES if c[2] % 4 == 0])
+def test_conv_wgrad_bf16_matrix_cores(K, bf16_mode, N, Cin, Cout, H, W, k, s, p):
+    x = G.randn(11, N, Cin, H, W)
+    w = G.randn(12, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5).requires_grad_(True)
+    dy = G.randn(13, *F.conv2d(x, w, None, s, p).shape)
+    gw = torch.autograd.grad(F.conv2d(_r(x), w, None, s, p), w, _r(dy))[0].permute(0, 2, 3, 1)
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    part, S = K.conv_wgrad_partials([nhwc(x)], [nhwc(dy)], k, s, p)
+    dW = torch.empty_like(wg)
+    K.wgrad_reduce(part, S, wg, None, dW, False, None)
+    assert relerr(dW.cpu(), gw) < 2e-5
+
+
+def test_conv_wgrad_bf16_multilevel(K, bf16_mode):
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    N, Cc, Co = 2, 256, 80
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(21, N, A, Cc)
+    dz = G.randn(23, N, A, Co)
+    xs, dzs, ref, off = [], [], 0, 0
+    xg, dg = x.cuda(), dz.cuda()
+    for (h, w) in sizes:
+        xl = x[:, off:off + h * w].reshape(N, h, w, Cc).permute(0, 3, 1, 2)
+        dl = dz[:, off:off + h * w].reshape(N, h, w, Co).permute(0, 3, 1, 2)
+        wz = torch.zeros(Co, Cc, 3, 3, requires_grad=True)
+        ref = ref + torch.autograd.grad(F.conv2d(_r(xl), wz, None, 1, 1), wz, _r(dl))[0]
+        xs.append(xg[:, off:off + h * w].unflatten(1, (h, w)))
+        dzs.append(dg[:, off:off + h * w].unflatten(1, (h, w)))
+        off += h * w
+    part, S = K.conv_wgrad_partials(xs, dzs, 3, 1, 1)
+    dW = torch.empty((Co, 3, 3, Cc), device="cuda")
+    K.wgrad_reduce(part, S, dW, None, dW, False, None)
+    assert relerr(dW.cpu(), ref.permute(0, 2, 3, 1)) < 2e-5
