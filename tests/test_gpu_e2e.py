@@ -234,3 +234,69 @@ def test_teacher_hipgraph_replay_equals_eager_on_mixed_resolutions():
         tr.flush()
         logs[use_graph] = out
     assert np.allclose(logs[True], logs[False], rtol=1e-5), logs
+
+
+def test_bf16_matrix_core_mode_vs_oracle_bf16_multiplicands():
+    """BASELINE.json configs[2]: every 1x1/3x3 convolution on the bf16 matrix cores (multiplicands rounded to bf16,
+    exact products, fp32 accumulation / normalisation / losses / storage), against the oracle in its bf16-multiplicand
+    mode.  A single convolution agrees to 2e-5 (test_gpu_kernels.py: exact products, only the summation order
+    differs); through ~60 layers the two sides round activations that differ by 1e-7 to DIFFERENT bf16 neighbours now
+    and then, each such flip is a 0.4 % perturbation that makes further flips likelier, and the difference settles at
+    the bf16 quantisation-noise floor (tools/debug_bf16.py: 2e-4 after layer1, 5e-3 from C4 on; 3e-7 in fp32 mode).
+    Whole-network quantities therefore agree at bf16 resolution, not fp32: logits 0.1 abs (observed 0.03), losses
+    2e-2 rel (distillation terms 1e-1), ERS index sets >= 75 % overlap.  Gradients at this tiny image size sit on a
+    high noise floor in ANY bf16-multiplicand implementation: the oracle's own bf16-mode gradients move by 0.20 (median
+    per-tensor rel L2; max 0.38) under a 2e-6 input perturbation, so the bounds here are 0.6 per tensor (>= 4096 elements), 0.3 median, 0.35 global.  (It must also differ measurably
+    from the fp32 result -- the mode is really on.)"""
+    from erd_amd import kernels as K, parse_losses
+    tsd, ssd = f7_state_dicts()
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=0)
+    x, metas = O.preprocess(imgs)
+    sd = {k: (v.clone().requires_grad_(True) if O.trainable(k) and v.dtype == torch.float32 else v) for k, v in ssd.items()}
+    with O.bf16_multiplicands():
+        t_cls_ref, t_bbox_ref = O.gfl_forward(tsd, x)
+        ref_losses, aux = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80, return_aux=True)
+        O.parse_losses(ref_losses).backward()
+    f32_losses = O.erd_step_loss(tsd, ssd, x, boxes, labels, metas, 40, 80)
+    K.set_compute("bf16")
+    try:
+        model = build_erd(tsd, ssd)
+        t_cls, t_bbox = model.ori_model(x.cuda(), mode="tensor")
+        dmax = max(float((a.cpu() - b).abs().max()) for a, b in zip(t_cls, t_cls_ref))
+        assert dmax < 0.1, dmax
+        losses = model(x.cuda(), make_samples(boxes, labels, metas), mode="loss")
+        L = _lossdict_to_np(losses)
+        lerr = 0.0
+        for k, vs in ref_losses.items():
+            r = np.array([float(v) for v in vs])
+            # the distillation terms are differences of two nearly equal (teacher / student) noisy responses
+            assert np.allclose(L[k], r, rtol=1e-1 if k.startswith("loss_dist") else 2e-2, atol=1e-6), (k, L[k], r)
+            lerr = max(lerr, float(np.max(np.abs(L[k] - r) / np.maximum(np.abs(r), 1e-6))))
+        assert abs(float(sum(L["loss_cls"])) - float(sum(float(v) for v in f32_losses["loss_cls"]))) > 1e-6
+        total, _ = parse_losses(losses)
+        total.backward()
+        tc, tb, sizes = model.ori_model._forward_cat(x.cuda())
+        ers = model.sel_pos_cat(tc, tb)
+        cnt = ers["counts"].cpu()
+        jac = []
+        for i in range(2):
+            for name, key, col in (("idx_cls", "ers_cls", 0), ("idx_bbox", "ers_bbox", 1)):
+                a = set(ers[name][i, :int(cnt[i, col])].cpu().tolist())
+                b = set(aux[key][i].tolist())
+                jac.append(len(a & b) / max(len(a | b), 1))
+        assert min(jac) > 0.75, jac          # (sets of ~10 anchors at this image size: one borderline anchor = 0.1)
+        params = dict(model.named_parameters())
+        errs, num, den = [], 0.0, 0.0
+        for k, v in sd.items():
+            if not (O.trainable(k) and v.dtype == torch.float32) or float(v.grad.norm()) < 1e-12:
+                continue
+            a, b = params[k].grad.cpu().double(), v.grad.double()
+            errs.append(float((a - b).norm() / b.norm()))
+            num += float((a - b).pow(2).sum()); den += float(b.pow(2).sum())
+            if b.numel() >= 4096:        # (scalars / short vectors are sums with heavy cancellation: no per-tensor bound)
+                assert errs[-1] < 0.6, (k, errs[-1])
+        assert float(np.median(errs)) < 0.3 and (num / den) ** 0.5 < 0.35, (float(np.median(errs)), (num / den) ** 0.5)
+        print("bf16 mode vs oracle(bf16 multiplicands): logits max abs %.2e, losses max rel %.2e, ERS Jaccard min %.3f, "
+              "grad rel L2 median %.2e max %.2e" % (dmax, lerr, min(jac), float(np.median(errs)), max(errs)))
+    finally:
+        K.set_compute("f32")

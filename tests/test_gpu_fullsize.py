@@ -75,3 +75,20 @@ def test_r101_70_plus_10_full_size_step_is_sane():
     cnt = t.ers["counts"].cpu()
     assert ((cnt > 0.001 * 22400) & (cnt < 0.12 * 22400)).all(), cnt
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_bf16_mode_full_size_tracks_fp32():
+    """BASELINE.json configs[2] at full size: three optimisation steps on the bf16 matrix cores stay within 2 % of the
+    fp32 path's losses step by step (same batches, same initial weights), and every parameter stays finite."""
+    from erd_amd import kernels as K
+    logs = {}
+    for mode in ("f32", "bf16"):
+        K.set_compute(mode)
+        try:
+            logs[mode], model, _ = _run(True, steps=3, bs=2)
+            assert all(torch.isfinite(p).all() for p in model.parameters())
+        finally:
+            K.set_compute("f32")
+    for a, b in zip(logs["bf16"], logs["f32"]):
+        assert a["loss"] == pytest.approx(b["loss"], rel=2e-2), (a, b)
+        assert a["loss"] != b["loss"]
