@@ -63,6 +63,7 @@ _SIGNATURES = {
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
     "erd_weight_transpose": [P, P, P, i32, i32, i32, i32, P],
+    "erd_weight_transpose_bf16": [P, P, P, i32, i32, i32, i32, P],
     "erd_stem_conv7x7_bn_relu": [P, P, P, P, P, i32, i32, i32, P],
     "erd_maxpool3x3s2": [P, P, i32, i32, i32, i32, P],
     "erd_bn_fold": [P, P, P, P, f32, P, P, i64, P],

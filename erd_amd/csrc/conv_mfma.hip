@@ -851,9 +851,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // dst[ci][t'][co] = rowscale[co] * w[co][t][ci]
+template <typename OutT>
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w,
                                                                 const float* __restrict__ rowscale,
-                                                                float* __restrict__ dst, int Cout, int ntaps, int Cin,
+                                                                OutT* __restrict__ dst, int Cout, int ntaps, int Cin,
                                                                 int flip) {
     __shared__ float tile[32][33];
     const int t = blockIdx.z;
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + tx;
-        if (co < Cout && ci < Cin) dst[((int64_t)ci * ntaps + td) * Cout + co] = tile[tx][r];
+        if (co < Cout && ci < Cin) dst[((int64_t)ci * ntaps + td) * Cout + co] = (OutT)tile[tx][r];
     }
 }
 
@@ -915,7 +916,10 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     const size_t need = slab_bytes + (size_t)tiles * sizeof(int);
     const bool ragged = tiles < 8 * slots && (tiles % slots) != 0;
     // short K loops (1x1 convs on few channels) are latency/HBM-bound: they want many independent workgroups
-    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && nkt * BKT >= 512 && (int64_t)tiles * nkt >= slots) {
+    // bf16 matrix cores: the K loop is 8x shorter, the fix-up is not -> split K only when the tiles cannot fill the
+    // resident slots at all (measured: whole step 105 -> 118 img/s with tile-parallel launches everywhere else)
+    const bool sk_pays = BF ? tiles < slots : true;
+    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && nkt * BKT >= 512 && (int64_t)tiles * nkt >= slots) {
         G = slots;
         ws.slabs = reinterpret_cast<float*>(d->sk_ws);
         ws.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(d->sk_ws) + slab_bytes);
@@ -1031,7 +1035,15 @@ extern "C" int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, 
 extern "C" int erd_weight_transpose(const float* w, const float* rowscale, float* dst, int Cout, int ntaps,
                                     int Cin, int flip, erd_stream_t stream) {
     ERD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && ntaps > 0, "weight_transpose: bad args");
-    hipLaunchKernelGGL(weight_transpose_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, ntaps), dim3(256), 0,
+    hipLaunchKernelGGL(weight_transpose_kernel<float>, dim3((Cin + 31) / 32, (Cout + 31) / 32, ntaps), dim3(256), 0,
                        (hipStream_t)stream, w, rowscale, dst, Cout, ntaps, Cin, flip);
     return erd::check_launch("weight_transpose");
+}
+
+extern "C" int erd_weight_transpose_bf16(const float* w, const float* rowscale, void* dst, int Cout, int ntaps,
+                                         int Cin, int flip, erd_stream_t stream) {
+    ERD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && ntaps > 0, "weight_transpose_bf16: bad args");
+    hipLaunchKernelGGL(weight_transpose_kernel<__bf16>, dim3((Cin + 31) / 32, (Cout + 31) / 32, ntaps), dim3(256), 0,
+                       (hipStream_t)stream, w, rowscale, reinterpret_cast<__bf16*>(dst), Cout, ntaps, Cin, flip);
+    return erd::check_launch("weight_transpose_bf16");
 }

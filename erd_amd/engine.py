@@ -57,6 +57,7 @@ class FlatParams:
             v.copy_(p.detach())
             p.data = v
             p.grad = _storage_view(self.grad, off, p)
+        self.data_bf16: Optional[Tensor] = None      # bf16 shadow of `data` (bf16 matrix-core mode), see refresh_shadow
         # buckets over the flat range, in layout order (= backward order)
         self.buckets: List[tuple] = []
         start, members = 0, []
@@ -73,6 +74,19 @@ class FlatParams:
 
     def zero_grad(self) -> None:
         self.grad.zero_()
+
+    def refresh_shadow(self) -> None:
+        """bf16 matrix-core mode: ONE conversion launch over the flat parameter buffer after each update instead of one
+        per convolution; every 4-d parameter gets a bf16 twin view (same shape and strides) that the conv wrappers pick
+        up as long as the parameter's version counter has not moved since."""
+        if K.COMPUTE != "bf16":
+            return
+        if self.data_bf16 is None:
+            self.data_bf16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.data.device)
+        K.to_bf16_into(self.data, self.data_bf16)
+        for p, off in zip(self.params, self.offsets):
+            if p.dim() == 4:
+                p._erd_shadow = (_storage_view(self.data_bf16, off, p), p._version)
 
 
 class BucketedGradSync:
@@ -162,6 +176,7 @@ class ERDTrainer:
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith("ori_model.")]
         named.reverse()                      # backward order: head first, layer2 last
         self.flat = FlatParams(named, dev, bucket_mb << 20)
+        self.flat.refresh_shadow()
         self.base_lr = lr * (self.world * batch_size_per_gpu / base_batch_size
                              if (auto_scale_lr and batch_size_per_gpu) else 1.0)   # auto_scale_lr (config :116)
         self.momentum, self.weight_decay = momentum, weight_decay
@@ -200,6 +215,7 @@ class ERDTrainer:
                         self.weight_decay, 1.0 / self.world, self._first)
         self._first = False
         self._pending = False
+        self.flat.refresh_shadow()
 
     def flush(self) -> None:
         self._apply_pending()

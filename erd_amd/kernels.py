@@ -172,11 +172,21 @@ def to_bf16(t: Tensor) -> Tensor:
     return out
 
 
+def to_bf16_into(src: Tensor, dst: Tensor) -> None:
+    assert src.is_contiguous() and dst.is_contiguous() and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    call("erd_to_bf16", _p(src), _p(dst), src.numel(), _stream())
+
+
 def _weights_bf16(w: Tensor) -> Tensor:
     """bf16 copy of a contiguous OHWI weight view.  Frozen weights (teacher, stem/layer1) are converted once: the copy
     is cached ON the owning parameter object and validated by storage pointer + in-place version; trainable weights
     change under the optimizer's raw-pointer update, so they are converted per use (one small launch)."""
     base = w._base if w._base is not None else w
+    sh = getattr(base, "_erd_shadow", None)      # (bf16 view into the trainer's flat shadow buffer, version when refreshed)
+    if sh is not None and sh[1] == base._version:
+        v = sh[0].permute(0, 2, 3, 1)
+        if v.shape == w.shape and v.is_contiguous():
+            return v
     if base.requires_grad or w.requires_grad:
         return to_bf16(w.detach())
     ver = (w.data_ptr(), base._version, tuple(w.shape))
@@ -274,6 +284,10 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
     """[Cout,k,k,Cin] -> [Cin,k,k,Cout] (* rowscale[co]): weights of the input-gradient convolution."""
     Cout, k, _, Cin = w.shape
+    if COMPUTE == "bf16":      # rounded on the way out: conv_dgrad hands it to the bf16 matrix cores as is
+        wt = torch.empty((Cin, k, k, Cout), dtype=torch.bfloat16, device=w.device)
+        call("erd_weight_transpose_bf16", _p(w), _p(rowscale), _p(wt), Cout, k * k, Cin, 0, _stream())
+        return wt
     wt = torch.empty((Cin, k, k, Cout), dtype=torch.float32, device=w.device)
     call("erd_weight_transpose", _p(w), _p(rowscale), _p(wt), Cout, k * k, Cin, 0, _stream())
     return wt
@@ -288,7 +302,11 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
     buffer that already holds the other branch's gradient, or zero it first."""
     _require_gpu(wt, *dzs, *dxs)
     Cin, Cout = wt.shape[0], wt.shape[3]       # of the forward conv
-    wtb = to_bf16(wt) if COMPUTE == "bf16" else None
+    wtb = None
+    if COMPUTE == "bf16":
+        wtb = wt if wt.dtype == torch.bfloat16 else to_bf16(wt)
+    elif wt.dtype != torch.float32:
+        raise ValueError("conv_dgrad: bf16 weights in f32 compute mode")
     classes = [(0, 0)] if stride == 1 else [(py, px) for py in range(stride) for px in range(stride)]
     for (py, px) in classes:
         taps = []
@@ -314,7 +332,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
             _fill_seg(d.seg[i], dz, dx, max(GH, 0), max(GW, 0), r, None, None if relu_mask is None else relu_mask[i])
         if skip and len(dzs) == 1:
             continue
-        d.w = wt.data_ptr()
+        d.w = wt.data_ptr() if wtb is None else 0
         d.Cin, d.Cout, d.wrow = Cout, Cin, k * k * Cout     # roles swap: contraction over Cout
         d.ntaps = len(taps)
         for t, (dy, dx_, wk) in enumerate(taps):

@@ -127,6 +127,9 @@ int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, const float
  * input-gradient convolution. */
 int erd_weight_transpose(const float* w, const float* rowscale, float* dst, int Cout, int ntaps,
                          int Cin, int flip, erd_stream_t stream);
+/* the same, rounded to bf16 (round to nearest even) for erd_conv_desc::w_bf16 */
+int erd_weight_transpose_bf16(const float* w, const float* rowscale, void* dst, int Cout, int ntaps,
+                              int Cin, int flip, erd_stream_t stream);
 
 /* ---- stem (resnet.py:636-639): conv7x7/2 (3->64) + frozen BN + ReLU, then maxpool 3x3/2 ---- */
 int erd_stem_conv7x7_bn_relu(const float* x_nchw, const float* w_ohwi, const float* scale,
