@@ -57,6 +57,7 @@ class FlatParams:
             v.copy_(p.detach())
             p.data = v
             p.grad = _storage_view(self.grad, off, p)
+            p._erd_sink = True        # backward kernels may write this slot directly (functional._sink)
         self.data_bf16: Optional[Tensor] = None      # bf16 shadow of `data` (bf16 matrix-core mode), see refresh_shadow
         # buckets over the flat range, in layout order (= backward order)
         self.buckets: List[tuple] = []
@@ -100,7 +101,9 @@ class BucketedGradSync:
         self._works: List = []
         self._remaining: List[int] = []
         for i, p in enumerate(flat.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+            hook = self._make_hook(i)
+            p.register_post_accumulate_grad_hook(hook)
+            p._erd_sink_notify = hook      # gradients written straight into the flat slot bypass AccumulateGrad
 
     def arm(self) -> None:
         self._remaining = [len(m) for (_, _, m) in self.flat.buckets]

@@ -76,6 +76,37 @@ class _Fork:
             self.cur.wait_stream(self.aux)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# gradient sinks: under ERDTrainer every trainable parameter's .grad is a view into ONE flat, per-step zeroed buffer
+# (engine.FlatParams marks them `_erd_sink`).  The backward kernels then write the gradient straight into that slot
+# and return None to autograd: no temporary, no AccumulateGrad add launch (~160 per step).  The data-parallel bucket
+# hooks are told by hand (`_erd_sink_notify`).  Contract: the slot is zero when backward starts and each parameter is
+# used by one node per step -- ERDTrainer.zero_grad() every step guarantees both.
+# ---------------------------------------------------------------------------------------------------------
+def _sink(p: Optional[Tensor]) -> Optional[Tensor]:
+    if p is not None and getattr(p, "_erd_sink", False) and p.grad is not None:
+        return p.grad
+    return None
+
+
+def _sunk(p: Tensor) -> None:
+    n = getattr(p, "_erd_sink_notify", None)
+    if n is not None:
+        n(p)
+
+
+def _emit_wgrad(w: Tensor, part: Tensor, S: int, wk: Tensor, scale: Optional[Tensor], rowdot: Optional[Tensor]):
+    """reduce the split-K partial slabs into the weight gradient: into the flat slot (returns None) or a new tensor"""
+    sink = _sink(w)
+    if sink is not None:
+        K.wgrad_reduce(part, S, wk, scale, ohwi(sink), True, rowdot)
+        _sunk(w)
+        return None
+    dWk = torch.empty_like(wk)
+    K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
+    return _to_oihw(dWk)
+
+
 def _bn_fold_cached(gamma, beta, mean, var, eps):
     """folded (scale, shift) of a frozen-statistics BN; cached while gamma/beta are frozen too (teacher, stem,
     layer1).  The cache lives ON the parameter object (dies with it -- a pointer-keyed table would hand a stale
@@ -121,15 +152,13 @@ class ConvBNAct(Function):
         dW = dgamma = None
         fork = _Fork(x.device)
         if need_w or need_g:
-            dWk = torch.empty_like(wk)
             rowdot = torch.empty_like(scale) if need_g else None
             dgamma = torch.empty_like(scale) if need_g else None
             with fork:
                 part, S = K.conv_wgrad_partials([x], [dz], k, stride, pad)
-                K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
+                dW = _emit_wgrad(w, part, S, wk, scale, rowdot)
                 if need_g:
                     K.bn_dgamma(rowdot, dbeta, mean, var, eps, out=dgamma)
-            dW = _to_oihw(dWk)
         dx = None
         if need_x:
             wt = K.weight_transpose(wk, scale)
@@ -203,24 +232,37 @@ class BottleneckFn(Function):
                 return
             wk = ohwi(w)
             part, S = K.conv_wgrad_partials([xin], [dz], k, s, pad)
-            dWk = torch.empty_like(wk)
             rowdot = torch.empty_like(scale) if need[base + 1] else None
-            K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
-            if need[base]:
-                grads[5 * idx] = _to_oihw(dWk)
+            grads[5 * idx] = _emit_wgrad(w, part, S, wk, scale, rowdot)
             if need[base + 1]:
-                grads[5 * idx + 1] = K.bn_dgamma(rowdot, dbeta, m, v, eps)
+                gs = _sink(g)
+                if gs is not None:                      # the slot is zero: plain store == accumulation
+                    K.bn_dgamma(rowdot, dbeta, m, v, eps, out=gs)
+                    _sunk(g)
+                else:
+                    grads[5 * idx + 1] = K.bn_dgamma(rowdot, dbeta, m, v, eps)
             if need[base + 2]:
-                grads[5 * idx + 2] = dbeta
+                bs = _sink(b)
+                if bs is None:
+                    grads[5 * idx + 2] = dbeta
+                else:
+                    if dbeta.data_ptr() != bs.data_ptr():   # (the projection shortcut shares conv3's column sums)
+                        bs.add_(dbeta)
+                    _sunk(b)
 
-        dz3, db3 = K.relu_bwd_colsum(y, dy.contiguous(), True)
+        def beta_slot(idx, n):
+            """column sums of dz go straight into d beta's flat slot when it has one (zero at this point)"""
+            s_ = _sink(P[idx][2]) if need[3 + 5 * idx + 2] else None
+            return s_ if s_ is not None else K.zeros_f32(n, dev)
+
+        dz3, db3 = K.relu_bwd_colsum(y, dy.contiguous(), True, colsum_into=beta_slot(2, y.shape[3]))
         wgrad(2, o2, dz3, 1, 1, 0, s3, db3)
         dz2 = torch.empty_like(o2)
-        db2 = K.zeros_f32(o2.shape[3], dev)
+        db2 = beta_slot(1, o2.shape[3])
         K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[2][0]), s3), [dz2], 1, 1, 0, relu_mask=[o2], colsum=db2)
         wgrad(1, o1, dz2, 3, stride, 1, s2, db2)
         dz1 = torch.empty_like(o1)
-        db1 = K.zeros_f32(o1.shape[3], dev)
+        db1 = beta_slot(0, o1.shape[3])
         K.conv_dgrad([dz2], K.weight_transpose(ohwi(P[1][0]), s2), [dz1], 3, stride, 1, relu_mask=[o1], colsum=db1)
         wgrad(0, x, dz1, 1, 1, 0, s1, db1)
         dx = None
@@ -260,11 +302,9 @@ class ConvBias(Function):
         dW = db = dx = None
         fork = _Fork(x.device)
         if ctx.needs_input_grad[1]:
-            dWk = torch.empty_like(wk)
             with fork:
                 part, S = K.conv_wgrad_partials([x], [dy], k, stride, pad)
-                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
-            dW = _to_oihw(dWk)
+                dW = _emit_wgrad(w, part, S, wk, None, None)
         if ctx.needs_input_grad[2]:
             db = K.colsum(dy)
         if ctx.needs_input_grad[0]:
@@ -337,9 +377,7 @@ class FPNOutputs(Function):
             wk = ohwi(ws[i])
             if ctx.needs_input_grad[3 + i]:
                 part, S = K.conv_wgrad_partials([xin], [dz], 3, stride, 1)
-                dWk = torch.empty_like(wk)
-                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
-                grads_w[i] = _to_oihw(dWk)
+                grads_w[i] = _emit_wgrad(ws[i], part, S, wk, None, None)
             if ctx.needs_input_grad[8 + i]:
                 grads_b[i] = K.relu_bwd_colsum(None, dz, False)[1]
             return wk
@@ -382,11 +420,9 @@ class HeadConvGN(Function):
         xv, dv = K.level_views(x_cat, sizes), K.level_views(dc, sizes)
         fork = _Fork(x_cat.device)
         if ctx.needs_input_grad[1]:
-            dWk = torch.empty_like(wk)
             with fork:
                 part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
-                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
-            dW = _to_oihw(dWk)
+                dW = _emit_wgrad(w, part, S, wk, None, None)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x_cat)
             K.conv_dgrad(dv, K.weight_transpose(wk), K.level_views(dx, sizes), 3, 1, 1)
@@ -416,11 +452,9 @@ class HeadConvBias(Function):
         xv, dv = K.level_views(x_cat, sizes), K.level_views(dy, sizes)
         fork = _Fork(x_cat.device)
         if ctx.needs_input_grad[1]:
-            dWk = torch.empty_like(wk)
             with fork:
                 part, S = K.conv_wgrad_partials(xv, dv, 3, 1, 1)
-                K.wgrad_reduce(part, S, wk, None, dWk, False, None)
-            dW = _to_oihw(dWk)
+                dW = _emit_wgrad(w, part, S, wk, None, None)
         if ctx.needs_input_grad[2]:
             db = K.colsum(dy)
         if ctx.needs_input_grad[0]:

@@ -450,11 +450,13 @@ def bn_fold(gamma: Tensor, beta: Tensor, mean: Tensor, var: Tensor, eps: float =
     return scale, shift
 
 
-def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum: bool = True):
-    """(dz, colsum): dz = dy*(y>0) (new buffer) or dy itself; colsum[c] = sum over pixels of dz."""
+def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum: bool = True,
+                    colsum_into: Optional[Tensor] = None):
+    """(dz, colsum): dz = dy*(y>0) (new buffer) or dy itself; colsum[c] = sum over pixels of dz (accumulated into
+    `colsum_into` when given -- it must hold zeros or a partial sum of the same quantity)."""
     _check_map(dy)
     N, H, W, Cc = dy.shape
-    colsum = zeros_f32(Cc, dy.device) if want_colsum else None
+    colsum = colsum_into if colsum_into is not None else (zeros_f32(Cc, dy.device) if want_colsum else None)
     dz = dy
     if use_relu:
         _check_map(y)
