@@ -20,7 +20,10 @@ Tensor = torch.Tensor
 def ohwi(w: Tensor) -> Tensor:
     """OIHW parameter -> [O,H,W,I] contiguous view (copy only if the parameter is not channels_last)."""
     v = w.detach().permute(0, 2, 3, 1)
-    return v if v.is_contiguous() else v.contiguous()
+    if not v.is_contiguous():
+        return v.contiguous()
+    v._erd_owner = w      # lets the conv wrappers find per-parameter caches (bf16 twins) without guessing from ._base
+    return v
 
 
 def _to_oihw(dw_ohwi: Tensor) -> Tensor:

@@ -181,7 +181,9 @@ def _weights_bf16(w: Tensor) -> Tensor:
     """bf16 copy of a contiguous OHWI weight view.  Frozen weights (teacher, stem/layer1) are converted once: the copy
     is cached ON the owning parameter object and validated by storage pointer + in-place version; trainable weights
     change under the optimizer's raw-pointer update, so they are converted per use (one small launch)."""
-    base = w._base if w._base is not None else w
+    base = getattr(w, "_erd_owner", None)
+    if base is None:
+        base = w._base if w._base is not None else w
     sh = getattr(base, "_erd_shadow", None)      # (bf16 view into the trainer's flat shadow buffer, version when refreshed)
     if sh is not None and sh[1] == base._version:
         v = sh[0].permute(0, 2, 3, 1)
