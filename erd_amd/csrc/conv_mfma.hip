@@ -916,9 +916,10 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     const size_t need = slab_bytes + (size_t)tiles * sizeof(int);
     const bool ragged = tiles < 8 * slots && (tiles % slots) != 0;
     // short K loops (1x1 convs on few channels) are latency/HBM-bound: they want many independent workgroups
-    // bf16 matrix cores: the K loop is 8x shorter, the fix-up is not -> split K only when the tiles cannot fill the
-    // resident slots at all (measured: whole step 105 -> 118 img/s with tile-parallel launches everywhere else)
-    const bool sk_pays = BF ? tiles < slots : true;
+    // bf16 matrix cores: the K loop is 8x shorter, the fix-up is not -> split K only when the tiles fill at most half
+    // of the resident slots (measured: whole step 105 -> 118 img/s with tile-parallel launches everywhere else;
+    // 264-tile layers 64 -> 41 us without the split, 132-tile 3x3 layers 134 -> 80 us with it)
+    const bool sk_pays = BF ? tiles * 2 <= slots : true;
     if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && nkt * BKT >= 512 && (int64_t)tiles * nkt >= slots) {
         G = slots;
         ws.slabs = reinterpret_cast<float*>(d->sk_ws);
