@@ -217,7 +217,8 @@ def main():
         if ktime:
             dom = max(ktime.values(), key=lambda r: r["ms"])
             peak_tf = FP32_MFMA_PEAK_TFLOPS if (args.compute == "f32" or dom["kernel"] == "conv_wgrad") else BF16_MFMA_PEAK_TFLOPS
-            traffic, traffic_src = pmc_traffic_per_launch("conv_wgrad" if dom["kernel"] == "conv_wgrad" else "conv_igemm")
+            traffic, traffic_src = pmc_traffic_per_launch({"conv_wgrad": "conv_wgrad", "conv_wino_fwd": "wino_conv",
+                                                           "conv_wino_dgrad": "wino_conv"}.get(dom["kernel"], "conv_igemm"))
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"],
                                "achieved": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
                                "peak": peak_tf, "unit": "TFLOP/s",

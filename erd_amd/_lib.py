@@ -60,6 +60,9 @@ _SIGNATURES = {
     "erd_conv_igemm": [C.POINTER(ConvDesc), P],
     "erd_conv_igemm_ws_bytes": [i32],
     "erd_to_bf16": [P, P, i64, P],
+    "erd_wino_weights_elems": [i32, i32],
+    "erd_wino_weights": [P, P, i32, i32, i32, P],
+    "erd_wino_conv3x3": [P, i32, P, i32, i32, P, P, i32, P, P],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
     "erd_weight_transpose": [P, P, P, i32, i32, i32, i32, P],
@@ -120,7 +123,7 @@ def load():
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_size_t if name.endswith("_ws_bytes") else C.c_int
+        fn.restype = C.c_size_t if name.endswith(("_ws_bytes", "_elems")) else C.c_int
     if lib.erd_abi_version() != 1:
         raise ErdHipError("liberd_hip.so ABI version mismatch")
     _lib = lib

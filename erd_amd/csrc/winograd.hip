@@ -1,0 +1,402 @@
+// Winograd F(2x2, 3x3) convolution for the stride-1 3x3 layers, fp32 on the gfx950 matrix cores.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray 2016; 2.25x fewer multiplications than direct)
+//
+// The 16 transform positions xi = (i, j) are 16 independent GEMMs  M_xi[tile][cout] = sum_cin V_xi[tile][cin] U_xi[cout][cin].
+// One workgroup (256 threads, 4 waves) owns 32 output tiles (4 x 8 tiles = 8 x 16 output pixels of one image of one
+// level) x 64 output channels; wave w owns the four positions of transform row i = w.  Per 16-channel K slice:
+//   global -> LDS   : the raw 10 x 18 pixel patch (zeros outside the image come from the buffer out-of-range rule)
+//   LDS -> LDS      : B^T d B per (tile, 4 channels) into V[xi][tile][16 cin] rows (64 B, XOR swizzle)
+//   MFMA            : A fragments from V (ds_read_b128), B fragments straight from global: U is stored pre-tiled
+//                     [xi][cout/32][cin/4][32][4] so that a wave's fragment load is one contiguous 1 KB
+// and after the K loop the accumulators go through LDS once more for A^T M A, the optional scale/shift/ReLU epilogue
+// and coalesced stores.  The input gradient of the same layers is this kernel run on dz with the flipped, transposed
+// weights.  (The weight gradient stays a direct GEMM over pixels.)
+#include "erd_common.h"
+#include <type_traits>
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x7fffffffu;
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+constexpr int TBH = 4, TBW = 8;               // tiles per workgroup: 4 rows x 8 cols = 32 (one MFMA M-tile)
+constexpr int PR = 2 * TBH + 2, PC = 2 * TBW + 2;   // raw patch 10 x 18 pixels
+constexpr int KS = 16;                        // input channels per K slice
+constexpr int BN = 64;                        // output channels per workgroup
+constexpr int RAW_F4 = PR * PC * (KS / 4);    // float4s of the raw patch
+constexpr int RCS = 6;                        // LDS chunks per raw pixel: 4 data + 2 pad -> the strided 4x4-patch reads of the
+                                              // transform are bank-conflict free (4 would be 8-way)
+constexpr int RAW_LDS_F4 = PR * PC * RCS;
+constexpr int V_F4 = 16 * 32 * (KS / 4);      // float4s of the 16 transformed tiles
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// U[xi][cout/32][cin/4][cout%32][cin%4] = (G g G^T)[xi] ; g = w[cout][kh][kw][cin]
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
+                                                          int Cin, int flip) {
+    const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
+    if (idx >= (int64_t)Cout * Cin) return;
+    const int co = (int)(idx / Cin), ci = (int)(idx % Cin);
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = w[((int64_t)co * 9 + (flip ? 8 - (a * 3 + b) : a * 3 + b)) * Cin + ci];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int cob = Cout / 32 + (Cout % 32 ? 1 : 0);
+    const int64_t per_xi = (int64_t)cob * (Cin / 4) * 128;
+    const int64_t base = ((int64_t)(co / 32) * (Cin / 4) + ci / 4) * 128 + (co % 32) * 4 + (ci % 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]),
+                    u3 = t[i][2];
+        U[(i * 4 + 0) * per_xi + base] = u0;
+        U[(i * 4 + 1) * per_xi + base] = u1;
+        U[(i * 4 + 2) * per_xi + base] = u2;
+        U[(i * 4 + 3) * per_xi + base] = u3;
+    }
+}
+
+struct WinoSeg {
+    const float* in;
+    float* out;
+    const float* res;        // optional, geometry of out: added before ReLU / mask (may alias out)
+    const float* mask;       // optional, geometry of out: result zeroed where mask <= 0
+    int N, H, W;
+    int tbh, tbw;            // workgroup grid of one image: ceil(ceil(H/2)/4) x ceil(ceil(W/2)/8)
+    int64_t in_nstride, out_nstride;
+    int block0;              // first workgroup (per cout block) of this segment
+};
+struct WinoDesc {
+    int nseg;
+    WinoSeg seg[ERD_MAX_SEG];
+    const float* U;
+    int Cin, Cout;
+    const float* scale;
+    const float* shift;
+    int relu;
+    float* colsum;           // optional [Cout]: += column sums of the stored result
+    int blocks_per_nb;       // workgroups per cout block
+    int dbg;                 // ablation switches (ERD_WINO_DBG): 1 no transform, 2 no weight loads, 4 no MFMA, 8 no raw loads
+};
+
+__global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* raw0 = reinterpret_cast<float4*>(smem);         // 2 x [PR][PC][KS/4]
+    float4* raw1 = raw0 + RAW_LDS_F4;
+    float4* Vs0 = raw1 + RAW_LDS_F4;                             // 2 x [16][32 tiles][KS/4] swizzled
+    float4* Vs1 = Vs0 + V_F4;
+    float* Ms = reinterpret_cast<float*>(smem);              // output staging [16][32][16] floats (32 KB), after the K loop
+
+    const int tid = threadIdx.x;
+    const int nb = blockIdx.x / p.blocks_per_nb;             // cout block
+    int b = blockIdx.x % p.blocks_per_nb;
+    int s = 0;
+    while (s + 1 < p.nseg && b >= p.seg[s + 1].block0) ++s;
+    const WinoSeg& sg = p.seg[s];
+    b -= sg.block0;
+    const int per_img = sg.tbh * sg.tbw;
+    const int n = b / per_img;
+    const int rem = b - n * per_img;
+    const int tyb = rem / sg.tbw, txb = rem - tyb * sg.tbw;
+    const int y0 = tyb * 2 * TBH, x0 = txb * 2 * TBW;       // first output pixel of the block
+    const int H = sg.H, W = sg.W, Cin = p.Cin;
+    const int cout0 = nb * BN;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+
+    // Wave specialisation: waves 0-3 only issue MFMAs (wave w owns transform row i = w), waves 4-7 only move and
+    // transform data.  Every SIMD hosts one wave of each kind, so the hardware interleaves the matrix pipe with the
+    // VALU / LDS / VMEM work of the transform without any help from the instruction scheduler; one barrier per slice.
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool is_mma = wave < 4;
+    const int li = lane & 31, h = lane >> 5;
+    // ---- data-wave state ------------------------------------------------------------------------------------
+    const int dt = tid & 255;
+    constexpr int NRAW = (RAW_F4 + 255) / 256;
+    unsigned roff[NRAW];
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) {
+        const int it = dt + 256 * i;
+        roff[i] = OOB;
+        if (it < RAW_F4) {
+            const int chunk = it & 3, pix = it >> 2;
+            const int pr = pix / PC, pc = pix - pr * PC;
+            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                roff[i] = (unsigned)(n * sg.in_nstride + ((int64_t)iy * W + ix) * Cin + chunk * 4) * 4u;
+        }
+    }
+    const int t_chunk = dt & 3, t_tile = (dt >> 2) & 31, t_half = dt >> 7;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    auto vswz = [](int row, int c) { return c ^ ((row >> 2) & 3); };
+
+    const int cob_all = (p.Cout + 31) / 32;
+    const int64_t per_xi = (int64_t)cob_all * (Cin / 4) * 128;            // floats per transform position of U
+    const float4* U4 = reinterpret_cast<const float4*>(p.U);
+    const int nks = Cin / KS;
+
+    auto issue_raw = [&](int ks_, float4* dst) {
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i)
+            dst[i] = (ks_ < nks && roff[i] != OOB) ? buf_load16(rs_in, roff[i] + (unsigned)(ks_ * KS * 4))
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_raw = [&](const float4* src, float4* rawbuf) {
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) {
+            const int it = dt + 256 * i;
+            if (it < RAW_F4) rawbuf[(it >> 2) * RCS + (it & 3)] = src[i];
+        }
+    };
+    // rows (2*HALF, 2*HALF+1) of B^T d B for this thread's (tile, 4 channels); waves 4,5 do HALF 0, waves 6,7 HALF 1
+    // (one wave-uniform branch per slice, straight-line code inside)
+    auto transform_half = [&](const float4* rawbuf, float4* V, auto half_tag) {
+        constexpr int HALF = decltype(half_tag)::value;
+        // HALF 0 needs patch rows 0,1,2 (r0 = d0 - d2, r1 = d1 + d2); HALF 1 rows 1,2,3 (r2 = d2 - d1, r3 = d1 - d3)
+        float4 rr[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 d0 = rawbuf[((2 * t_ty + 0 + HALF) * PC + (2 * t_tx + c)) * RCS + t_chunk];
+            const float4 d1 = rawbuf[((2 * t_ty + 1 + HALF) * PC + (2 * t_tx + c)) * RCS + t_chunk];
+            const float4 d2 = rawbuf[((2 * t_ty + 2 + HALF) * PC + (2 * t_tx + c)) * RCS + t_chunk];
+            if (HALF == 0) { rr[0][c] = f4sub(d0, d2); rr[1][c] = f4add(d1, d2); }
+            else           { rr[0][c] = f4sub(d1, d0); rr[1][c] = f4sub(d0, d2); }
+        }
+        const int col = vswz(t_tile, t_chunk);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int i = 2 * HALF + a;
+            V[((i * 4 + 0) * 32 + t_tile) * 4 + col] = f4sub(rr[a][0], rr[a][2]);
+            V[((i * 4 + 1) * 32 + t_tile) * 4 + col] = f4add(rr[a][1], rr[a][2]);
+            V[((i * 4 + 2) * 32 + t_tile) * 4 + col] = f4sub(rr[a][2], rr[a][1]);
+            V[((i * 4 + 3) * 32 + t_tile) * 4 + col] = f4sub(rr[a][1], rr[a][3]);
+        }
+    };
+    auto transform = [&](const float4* rawbuf, float4* V) {
+        if (t_half == 0) transform_half(rawbuf, V, std::integral_constant<int, 0>{});
+        else transform_half(rawbuf, V, std::integral_constant<int, 1>{});
+    };
+    // ---- MFMA-wave state: weight fragments of one k-step (4 positions x 2 cout sub-tiles) ------------------------
+    // (unconditional loads from clamped addresses -> straight-line code, so the compiler can wait for the OLDER of the
+    // two fragment sets only; channels past Cout compute garbage that the output stage never stores)
+    const int cb0 = min(cout0 >> 5, cob_all - 1), cb1 = min((cout0 >> 5) + 1, cob_all - 1);
+    auto load_fb = [&](int ks_, int kk, float4 (&f)[4][2]) {
+        const int kc = min(ks_, nks - 1) * (KS / 4) + 2 * kk + h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4* Ub = U4 + ((wave * 4 + j) * per_xi) / 4;
+            f[j][0] = Ub[((int64_t)cb0 * (Cin / 4) + kc) * 32 + li];
+            f[j][1] = Ub[((int64_t)cb1 * (Cin / 4) + kc) * 32 + li];
+        }
+    };
+
+    // output stage shared by both roles: A^T M A of 16 channels x 32 tiles staged in Ms, epilogue, stores
+    const int o_c = tid & 15, o_tile = tid >> 4;
+    auto emit = [&](int pass) {
+        const int co = cout0 + pass * 16 + o_c;
+        if (cout0 + pass * 16 >= p.Cout) return;                 // whole pass past the end (uniform)
+        if (co >= p.Cout) return;                                 // Cout is a multiple of 4 wherever colsum is used
+        const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
+        float m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) m[i][jj] = Ms[((i * 4 + jj) * 32 + o_tile) * 16 + o_c];
+        float s0[4], s1[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            s0[jj] = m[0][jj] + m[1][jj] + m[2][jj];
+            s1[jj] = m[1][jj] - m[2][jj] - m[3][jj];
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+        const int ty = o_tile >> 3, tx = o_tile & 7;
+        float csum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int oy = y0 + 2 * ty + a, ox = x0 + 2 * tx + c;
+                if (oy < H && ox < W) {
+                    const int64_t o = n * sg.out_nstride + ((int64_t)oy * W + ox) * p.Cout + co;
+                    float v = y[a][c] * sc + sh;
+                    if (sg.res) v += sg.res[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (sg.mask) v = sg.mask[o] > 0.f ? v : 0.f;
+                    sg.out[o] = v;
+                    csum += v;
+                }
+            }
+        if (p.colsum) {      // the four lanes of a wave that share this channel, then one atomic per wave
+            csum += __shfl_xor(csum, 16, 64);
+            csum += __shfl_xor(csum, 32, 64);
+            if ((tid & 63) < 16) atomicAdd(p.colsum + co, csum);
+        }
+    };
+
+    // The two roles run separate code paths with the SAME barrier sequence (2 + nks + 8); keeping them apart lets the
+    // register allocator give the 128 accumulator registers to the MFMA waves only.
+    if (is_mma) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][q][r] = 0.f;
+        float4 fb0[4][2], fb1[4][2];
+        load_fb(0, 0, fb0);
+        load_fb(0, 1, fb1);
+        __syncthreads();
+        __syncthreads();
+        for (int ks = 0; ks < nks; ++ks) {
+            const float4* Vc = (ks & 1) ? Vs1 : Vs0;
+#define ERD_WMFMA(F, m)                                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)              \
+                acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].m, F[j][q].m, acc[j][q], 0, 0, 0);
+            {
+                float4 fa[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, h)];
+                if (!(p.dbg & 4)) { ERD_WMFMA(fb0, x) ERD_WMFMA(fb0, y) ERD_WMFMA(fb0, z) ERD_WMFMA(fb0, w) }
+            }
+            if (!(p.dbg & 2)) load_fb(ks + 1, 0, fb0);        // lands under the second k-step's MFMAs and the barrier
+            {
+                float4 fa[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, 2 + h)];
+                if (!(p.dbg & 4)) { ERD_WMFMA(fb1, x) ERD_WMFMA(fb1, y) ERD_WMFMA(fb1, z) ERD_WMFMA(fb1, w) }
+            }
+            if (!(p.dbg & 2)) load_fb(ks + 1, 1, fb1);
+#undef ERD_WMFMA
+            __syncthreads();
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {              // channels [pass*16, pass*16+16) of the 64
+            const int q = pass >> 1, cbase = (pass & 1) * 16;
+            __syncthreads();
+            if (li >= cbase && li < cbase + 16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        Ms[((wave * 4 + j) * 32 + row) * 16 + (li - cbase)] = acc[j][q][r];
+                    }
+            }
+            __syncthreads();
+            emit(pass);
+        }
+    } else {
+        float4 rv[NRAW];
+        issue_raw(0, rv);
+        store_raw(rv, raw0);
+        issue_raw(1, rv);
+        __syncthreads();
+        transform(raw0, Vs0);
+        store_raw(rv, raw1);
+        issue_raw(2, rv);
+        __syncthreads();
+        // state: V[0] = V(0), raw1 = raw(1), rv = raw(2) in flight
+        for (int ks = 0; ks < nks; ++ks) {
+            const int cur = ks & 1;
+            float4* Vn = cur ? Vs0 : Vs1;
+            float4* rawc = cur ? raw1 : raw0;      // held raw(ks): consumed before the last barrier -> receives raw(ks+2)
+            float4* rawn = cur ? raw0 : raw1;      // raw(ks+1)
+            store_raw(rv, rawc);
+            if (!(p.dbg & 8)) issue_raw(ks + 3, rv);
+            if (!(p.dbg & 1)) transform(rawn, Vn);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            __syncthreads();
+            __syncthreads();
+            emit(pass);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int erd_wino_weights(const float* w_ohwi, float* U, int Cout, int Cin, int flip, erd_stream_t stream) {
+    ERD_REQUIRE(w_ohwi && U && Cout > 0 && Cin > 0 && Cin % 4 == 0, "wino_weights: bad args");
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ohwi, U,
+                       Cout, Cin, flip);
+    return erd::check_launch("wino_weights");
+}
+
+extern "C" size_t erd_wino_weights_elems(int Cout, int Cin) {
+    return (size_t)16 * ((Cout + 31) / 32) * (Cin / 4) * 128;
+}
+
+extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout,
+                                const float* scale, const float* shift, int relu, float* colsum, erd_stream_t stream) {
+    ERD_REQUIRE(segs && U && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
+    ERD_REQUIRE(Cin % KS == 0 && Cout > 0, "wino: Cin=%d must be a multiple of %d", Cin, KS);
+    WinoDesc d;
+    d.nseg = nseg;
+    d.U = U;
+    d.Cin = Cin;
+    d.Cout = Cout;
+    d.scale = scale;
+    d.shift = shift;
+    d.relu = relu;
+    d.colsum = colsum;
+    ERD_REQUIRE(!colsum || Cout % 16 == 0, "wino: colsum needs Cout %% 16 == 0");
+    static const int dbg = getenv("ERD_WINO_DBG") ? atoi(getenv("ERD_WINO_DBG")) : 0;
+    d.dbg = dbg;
+    int blocks = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const erd_conv_seg& g = segs[s];
+        ERD_REQUIRE(g.in && g.out && g.IH == g.OH && g.IW == g.OW, "wino: segment %d is not a stride-1 same-size map", s);
+        ERD_REQUIRE((int64_t)g.N * g.in_nstride < (1ll << 29), "wino: segment %d too large", s);
+        WinoSeg& w = d.seg[s];
+        w.in = g.in;
+        w.out = g.out;
+        w.res = g.res;
+        w.mask = g.mask;
+        ERD_REQUIRE(!g.alpha, "wino: per-level scalars are not supported");
+        w.N = g.N;
+        w.H = g.IH;
+        w.W = g.IW;
+        w.tbh = ((g.IH + 1) / 2 + TBH - 1) / TBH;
+        w.tbw = ((g.IW + 1) / 2 + TBW - 1) / TBW;
+        w.in_nstride = g.in_nstride;
+        w.out_nstride = g.out_nstride;
+        w.block0 = blocks;
+        blocks += g.N * w.tbh * w.tbw;
+    }
+    d.blocks_per_nb = blocks;
+    const int ncb = (Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (RAW_LDS_F4 + V_F4) * sizeof(float4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)(blocks * ncb)), dim3(512), lds, (hipStream_t)stream, d);
+    return erd::check_launch("wino_conv3x3");
+}

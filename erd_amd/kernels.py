@@ -254,6 +254,9 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     """outs[i] = epi(conv(xs[i], w)); w is [Cout,k,k,Cin] contiguous (OHWI).  All segments share w."""
     _require_gpu(w, *xs, *outs)
     Cout, Cin = w.shape[0], w.shape[3]
+    if alphas is None and wino_ok(Cin, k, stride, pad) and w.shape[1] == 3:
+        wino_conv3x3(xs, _wino_weights_cached(w), outs, Cout, scale=scale, shift=shift, relu=relu, res=res)
+        return
     assert w.is_contiguous() and w.shape[1] == k and w.shape[2] == k
     d = ConvDesc()
     d.nseg = len(xs)
@@ -283,6 +286,55 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes)
 
 
+WINOGRAD = _os.environ.get("ERD_WINO", "1") != "0"     # F(2x2,3x3) for the fp32 3x3 stride-1 convolutions (winograd.hip)
+
+
+def wino_weights(w_ohwi: Tensor, flip: bool = False) -> Tensor:
+    """U = G g G^T of a [Cout,3,3,Cin] weight in the layout erd_wino_conv3x3 streams (flip: taps reversed, for the
+    input-gradient form on transposed weights)"""
+    Cout, kh, kw, Cin = w_ohwi.shape
+    assert kh == 3 and kw == 3 and w_ohwi.is_contiguous() and w_ohwi.dtype == torch.float32
+    U = torch.empty(int(_lib.load().erd_wino_weights_elems(Cout, Cin)), dtype=torch.float32, device=w_ohwi.device)
+    call("erd_wino_weights", _p(w_ohwi), _p(U), Cout, Cin, 1 if flip else 0, _stream())
+    return U
+
+
+def _wino_weights_cached(w: Tensor) -> Tensor:
+    """frozen weights: transformed once (cached on the owning parameter, validated by pointer + version);
+    trainable ones per use (a 5 us launch)."""
+    base = getattr(w, "_erd_owner", None)
+    if base is None or base.requires_grad:
+        return wino_weights(w)
+    ver = (w.data_ptr(), base._version, tuple(w.shape))
+    hit = getattr(base, "_erd_wino", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, wino_weights(w))
+        base._erd_wino = hit
+    return hit[1]
+
+
+def wino_ok(Cin: int, k: int, stride: int, pad: int) -> bool:
+    return WINOGRAD and COMPUTE == "f32" and k == 3 and stride == 1 and pad == 1 and Cin % 16 == 0
+
+
+def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: int, scale: Optional[Tensor] = None,
+                 shift: Optional[Tensor] = None, relu: bool = False, res: Optional[Sequence[Optional[Tensor]]] = None,
+                 mask: Optional[Sequence[Tensor]] = None, colsum: Optional[Tensor] = None, kname: str = "conv_wino_fwd") -> None:
+    """outs[i] = epi(conv3x3 stride 1 pad 1 of xs[i]) by Winograd F(2x2,3x3); U = wino_weights(w)"""
+    _require_gpu(U, *xs, *outs)
+    from ._lib import ConvSeg
+    segs = (ConvSeg * len(xs))()
+    Cin = xs[0].shape[3]
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        assert x.shape[:3] == o.shape[:3] and o.shape[3] == Cout and x.shape[3] == Cin
+        _fill_seg(segs[i], x, o, x.shape[1], x.shape[2], None if res is None else res[i], None,
+                  None if mask is None else mask[i])
+    flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * 9 * Cin
+    nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U.numel()) if _TIMING is not None else 0.0
+    _timed_call(kname, flop, "erd_wino_conv3x3", segs, len(xs), _p(U), Cin, Cout, _p(scale), _p(shift),
+                1 if relu else 0, _p(colsum), _stream(), nbytes=nbytes)
+
+
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
     """[Cout,k,k,Cin] -> [Cin,k,k,Cout] (* rowscale[co]): weights of the input-gradient convolution."""
     Cout, k, _, Cin = w.shape
@@ -304,6 +356,11 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
     buffer that already holds the other branch's gradient, or zero it first."""
     _require_gpu(wt, *dzs, *dxs)
     Cin, Cout = wt.shape[0], wt.shape[3]       # of the forward conv
+    if wt.dtype == torch.float32 and wino_ok(Cout, k, stride, pad):
+        # the input gradient of a 3x3 stride-1 conv is a 3x3 stride-1 conv of dz with the flipped transposed weights
+        wino_conv3x3(dzs, wino_weights(wt, flip=True), dxs, Cin, res=(dxs if accumulate else res), mask=relu_mask,
+                     colsum=colsum, kname="conv_wino_dgrad")
+        return
     wtb = None
     if COMPUTE == "bf16":
         wtb = wt if wt.dtype == torch.bfloat16 else to_bf16(wt)

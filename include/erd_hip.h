@@ -89,6 +89,20 @@ size_t erd_conv_igemm_ws_bytes(int max_tiles);
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements */
 int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
 
+/* ---- Winograd F(2x2,3x3) for the stride-1 3x3 convolutions (fp32 matrix cores, 2.25x fewer multiplications) ----
+ * erd_wino_weights: U = G g G^T of w [Cout][3][3][Cin] in the tiled layout the kernel streams
+ * ([16][ceil(Cout/32)][Cin/4][32][4], erd_wino_weights_elems floats).  erd_wino_conv3x3: out = epi(conv3x3(in)),
+ * stride 1, padding 1, over up to ERD_MAX_SEG maps sharing U (segments as in erd_conv_desc: in/out/N/IH/IW/
+ * in_nstride/out_nstride; OH == IH, OW == IW).  Cin % 16 == 0.  The input gradient of such a layer is the same
+ * call on dz with U built from the transposed weights ([Cin][3][3][Cout]) with flip = 1.
+ * replaces: the F.conv2d dispatches of gfl_head.py:219-229 (towers), fpn.py:215 (outputs), resnet.py:270-274 (conv2). */
+size_t erd_wino_weights_elems(int Cout, int Cin);
+int erd_wino_weights(const float* w_ohwi, float* U, int Cout, int Cin, int flip /* reverse the 9 taps */,
+                     erd_stream_t stream);
+/* epilogue: v = acc*scale + shift (+ seg.res) ; ReLU ; zero where seg.mask <= 0 ; colsum[co] += v (atomic) */
+int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout, const float* scale,
+                     const float* shift, int relu, float* colsum, erd_stream_t stream);
+
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
  * Up to ERD_MAX_SEG feature maps that share the weights (the head's five levels) are summed in ONE

@@ -342,3 +342,51 @@ def test_conv_wgrad_bf16_multilevel(K, bf16_mode):
     dW = torch.empty((Co, 3, 3, Cc), device="cuda")
     K.wgrad_reduce(part, S, dW, None, dW, False, None)
     assert relerr(dW.cpu(), ref.permute(0, 2, 3, 1)) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 256, 256, 26, 30), (1, 64, 64, 20, 28), (2, 128, 128, 25, 42), (1, 256, 80, 13, 21),
+                                            (1, 512, 512, 7, 11), (1, 256, 68, 8, 16), (1, 16, 32, 5, 3)])
+def test_winograd_conv3x3_forward(K, N, Cin, Cout, H, W):
+    """Winograd F(2x2,3x3) == direct 3x3 stride-1 convolution (odd sizes: partial tiles; Cout not a multiple of 64)"""
+    x = G.randn(41, N, Cin, H, W)
+    w = G.randn(42, Cout, Cin, 3, 3, scale=(2.0 / (Cin * 9)) ** 0.5)
+    scale = 0.5 + G.rand(43, Cout)
+    shift = G.randn(44, Cout, scale=0.1)
+    ref = F.conv2d(x, w, None, 1, 1)
+    U = K.wino_weights(w.permute(0, 2, 3, 1).contiguous().cuda())
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    K.wino_conv3x3([nhwc(x)], U, [out], Cout)
+    assert relerr(to_nchw(out), ref) < 5e-5
+    out2 = torch.empty_like(out)
+    K.wino_conv3x3([nhwc(x)], U, [out2], Cout, scale=scale.cuda(), shift=shift.cuda(), relu=True)
+    assert relerr(to_nchw(out2), F.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))) < 5e-5
+
+
+def test_winograd_conv3x3_multilevel_and_input_gradient(K):
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    N, Cc = 2, 256
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(51, N, A, Cc)
+    w = G.randn(52, Cc, Cc, 3, 3, scale=(2.0 / (Cc * 9)) ** 0.5)
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xg = x.cuda()
+    out = torch.empty((N, A, Cc), device="cuda")
+    from erd_amd.kernels import level_views
+    K.wino_conv3x3(level_views(xg, sizes), K.wino_weights(wg), level_views(out, sizes), Cc)
+    off = 0
+    for (h, ww) in sizes:
+        xl = x[:, off:off + h * ww].reshape(N, h, ww, Cc).permute(0, 3, 1, 2)
+        ref = F.conv2d(xl, w, None, 1, 1)
+        got = out[:, off:off + h * ww].reshape(N, h, ww, Cc).permute(0, 3, 1, 2).cpu()
+        assert relerr(got, ref) < 5e-5, (h, ww)
+        off += h * ww
+    # input gradient = the same kernel on dz with the flipped, transposed weights
+    xr = G.randn(53, 1, Cc, 13, 21).requires_grad_(True)
+    dy = G.randn(54, 1, Cc, 13, 21)
+    gx = torch.autograd.grad(F.conv2d(xr, w, None, 1, 1), xr, dy)[0]
+    wt = torch.empty((Cc, 3, 3, Cc), device="cuda")
+    from erd_amd._lib import call
+    call("erd_weight_transpose", wg.data_ptr(), None, wt.data_ptr(), Cc, 9, Cc, 1, torch.cuda.current_stream().cuda_stream)
+    dx = torch.empty((1, 13, 21, Cc), device="cuda")
+    K.wino_conv3x3([nhwc(dy)], K.wino_weights(wt), [dx], Cc)
+    assert relerr(to_nchw(dx), gx) < 5e-5
