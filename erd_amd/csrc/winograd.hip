@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     float4* raw1 = raw0 + RAW_LDS_F4;
     float4* Vs0 = raw1 + RAW_LDS_F4;                             // 2 x [16][32 tiles][KS/4] swizzled
     float4* Vs1 = Vs0 + V_F4;
-    float* Ms = reinterpret_cast<float*>(smem);              // output staging [16][32][16] floats (32 KB), after the K loop
+    float* Ms = reinterpret_cast<float*>(smem);              // output staging [16][32 tiles][32 couts] floats (64 KB), after the K loop
 
     const int tid = threadIdx.x;
     const int nb = blockIdx.x / p.blocks_per_nb;             // cout block
@@ -198,28 +198,26 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     // (unconditional loads from clamped addresses -> straight-line code, so the compiler can wait for the OLDER of the
     // two fragment sets only; channels past Cout compute garbage that the output stage never stores)
     const int cb0 = min(cout0 >> 5, cob_all - 1), cb1 = min((cout0 >> 5) + 1, cob_all - 1);
-    auto load_fb = [&](int ks_, int kk, float4 (&f)[4][2]) {
+    auto load_fb = [&](int ks_, int kk, int j, float4 (&f)[2]) {
         const int kc = min(ks_, nks - 1) * (KS / 4) + 2 * kk + h;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4* Ub = U4 + ((wave * 4 + j) * per_xi) / 4;
-            f[j][0] = Ub[((int64_t)cb0 * (Cin / 4) + kc) * 32 + li];
-            f[j][1] = Ub[((int64_t)cb1 * (Cin / 4) + kc) * 32 + li];
-        }
+        const float4* Ub = U4 + ((wave * 4 + j) * per_xi) / 4;
+        f[0] = Ub[((int64_t)cb0 * (Cin / 4) + kc) * 32 + li];
+        f[1] = Ub[((int64_t)cb1 * (Cin / 4) + kc) * 32 + li];
     };
 
     // output stage shared by both roles: A^T M A of 16 channels x 32 tiles staged in Ms, epilogue, stores
-    const int o_c = tid & 15, o_tile = tid >> 4;
-    auto emit = [&](int pass) {
-        const int co = cout0 + pass * 16 + o_c;
-        if (cout0 + pass * 16 >= p.Cout) return;                 // whole pass past the end (uniform)
-        if (co >= p.Cout) return;                                 // Cout is a multiple of 4 wherever colsum is used
+    const int o_c = tid & 31;
+    auto emit = [&](int pass, int rep) {
+        const int o_tile = (tid >> 5) + 16 * rep;
+        const int co = cout0 + pass * 32 + o_c;
+        if (cout0 + pass * 32 >= p.Cout) return;                 // whole pass past the end (uniform)
+        if (co >= p.Cout) return;                                 // (Cout % 32 == 0 wherever colsum is used)
         const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
         float m[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) m[i][jj] = Ms[((i * 4 + jj) * 32 + o_tile) * 16 + o_c];
+            for (int jj = 0; jj < 4; ++jj) m[i][jj] = Ms[((i * 4 + jj) * 32 + o_tile) * 32 + o_c];
         float s0[4], s1[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -246,10 +244,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
                     csum += v;
                 }
             }
-        if (p.colsum) {      // the four lanes of a wave that share this channel, then one atomic per wave
-            csum += __shfl_xor(csum, 16, 64);
+        if (p.colsum) {      // the two lanes of a wave that share this channel, then one atomic per wave
             csum += __shfl_xor(csum, 32, 64);
-            if ((tid & 63) < 16) atomicAdd(p.colsum + co, csum);
+            if ((tid & 63) < 32) atomicAdd(p.colsum + co, csum);
         }
     };
 
@@ -263,48 +260,52 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][q][r] = 0.f;
-        float4 fb0[4][2], fb1[4][2];
-        load_fb(0, 0, fb0);
-        load_fb(0, 1, fb1);
+        float4 fb[2][4][2];                                 // [k-step][position][cout sub-tile]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_fb(0, kk, j, fb[kk][j]);
         __syncthreads();
         __syncthreads();
         for (int ks = 0; ks < nks; ++ks) {
             const float4* Vc = (ks & 1) ? Vs1 : Vs0;
-#define ERD_WMFMA(F, m)                                                                                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)              \
-                acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].m, F[j][q].m, acc[j][q], 0, 0, 0);
-            {
-                float4 fa[4];
+            float4 fa[2][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fa[j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, h)];
-                if (!(p.dbg & 4)) { ERD_WMFMA(fb0, x) ERD_WMFMA(fb0, y) ERD_WMFMA(fb0, z) ERD_WMFMA(fb0, w) }
-            }
-            if (!(p.dbg & 2)) load_fb(ks + 1, 0, fb0);        // lands under the second k-step's MFMAs and the barrier
-            {
-                float4 fa[4];
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fa[j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, 2 + h)];
-                if (!(p.dbg & 4)) { ERD_WMFMA(fb1, x) ERD_WMFMA(fb1, y) ERD_WMFMA(fb1, z) ERD_WMFMA(fb1, w) }
-            }
-            if (!(p.dbg & 2)) load_fb(ks + 1, 1, fb1);
+                for (int j = 0; j < 4; ++j) fa[kk][j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, 2 * kk + h)];
+            // k-step 0, then its weight fragments are re-loaded for the next slice (they land under k-step 1 and the
+            // barrier); same for k-step 1.  (Re-loading each position right after its own MFMAs measured 45 % SLOWER:
+            // the load's write-after-read hazard on the fragment registers stalls the matrix pipe.)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (!(p.dbg & 4)) {
+#define ERD_WMFMA(m)                                                                                              \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)      \
+                        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][j].m, fb[kk][j][q].m, acc[j][q], 0, 0, 0);
+                    ERD_WMFMA(x) ERD_WMFMA(y) ERD_WMFMA(z) ERD_WMFMA(w)
 #undef ERD_WMFMA
+                }
+                if (!(p.dbg & 2)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) load_fb(ks + 1, kk, j, fb[kk][j]);
+                }
+            }
             __syncthreads();
         }
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {              // channels [pass*16, pass*16+16) of the 64
-            const int q = pass >> 1, cbase = (pass & 1) * 16;
+        for (int pass = 0; pass < 2; ++pass) {              // channels [pass*32, pass*32+32) of the 64
             __syncthreads();
-            if (li >= cbase && li < cbase + 16) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        Ms[((wave * 4 + j) * 32 + row) * 16 + (li - cbase)] = acc[j][q][r];
-                    }
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    Ms[((wave * 4 + j) * 32 + row) * 32 + li] = acc[j][pass][r];
+                }
             __syncthreads();
-            emit(pass);
+            emit(pass, 0);
+            emit(pass, 1);
         }
     } else {
         float4 rv[NRAW];
@@ -328,10 +329,11 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             __syncthreads();
         }
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < 2; ++pass) {
             __syncthreads();
             __syncthreads();
-            emit(pass);
+            emit(pass, 0);
+            emit(pass, 1);
         }
     }
 }
@@ -363,7 +365,7 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     d.shift = shift;
     d.relu = relu;
     d.colsum = colsum;
-    ERD_REQUIRE(!colsum || Cout % 16 == 0, "wino: colsum needs Cout %% 16 == 0");
+    ERD_REQUIRE(!colsum || Cout % 32 == 0, "wino: colsum needs Cout %% 32 == 0");
     static const int dbg = getenv("ERD_WINO_DBG") ? atoi(getenv("ERD_WINO_DBG")) : 0;
     d.dbg = dbg;
     int blocks = 0;

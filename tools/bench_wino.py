@@ -37,7 +37,9 @@ for name, Cin, Cout, sizes in CASES:
     xs, ys = K.level_views(x, sizes), K.level_views(y, sizes)
     U = K.wino_weights(w)
     fl = 2.0 * N * A * Cout * Cin * 9
+    K.WINOGRAD = False
     t_d = timeit(lambda: K.conv_forward(xs, w, ys, 3, 1, 1))
+    K.WINOGRAD = True
     ref = y.clone()
     t_w = timeit(lambda: K.wino_conv3x3(xs, U, ys, Cout))
     err = float((y - ref).norm() / ref.norm())
