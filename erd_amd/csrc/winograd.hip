@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     float4* raw1 = raw0 + RAW_LDS_F4;
     float4* Vs0 = raw1 + RAW_LDS_F4;                             // 2 x [16][32 tiles][KS/4] swizzled
     float4* Vs1 = Vs0 + V_F4;
-    float* Ms = reinterpret_cast<float*>(smem);              // output staging [16][32 tiles][32 couts] floats (64 KB), after the K loop
+    float* Ms = reinterpret_cast<float*>(smem);              // output staging Z[4][2][32 tiles][64 couts] floats (64 KB), after the K loop
 
     const int tid = threadIdx.x;
     const int nb = blockIdx.x / p.blocks_per_nb;             // cout block
@@ -205,28 +205,26 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         f[1] = Ub[((int64_t)cb1 * (Cin / 4) + kc) * 32 + li];
     };
 
-    // output stage shared by both roles: A^T M A of 16 channels x 32 tiles staged in Ms, epilogue, stores
-    const int o_c = tid & 31;
-    auto emit = [&](int pass, int rep) {
-        const int o_tile = (tid >> 5) + 16 * rep;
-        const int co = cout0 + pass * 32 + o_c;
-        if (cout0 + pass * 32 >= p.Cout) return;                 // whole pass past the end (uniform)
-        if (co >= p.Cout) return;                                 // (Cout % 32 == 0 wherever colsum is used)
+    // Output stage.  Wave w holds M[i = w][j = 0..3]; the column half of A^T M A, z_q = sum_j M[w][j] A[j][q], is taken in
+    // registers, so only Z[i][q] (2 instead of 4 values per position row) goes through LDS: Zs[4 i][2 q][32 tiles][64 couts]
+    // = 64 KB, ONE pass.  All 512 threads then finish y[p][q] = sum_i A^T[p][i] Z[i][q], the epilogue and the stores.
+    const int o_c = tid & 63;
+    auto emit = [&](int rep) -> float {
+        const int o_tile = (tid >> 6) + 8 * rep;
+        const int co = cout0 + o_c;
+        if (co >= p.Cout) return 0.f;                             // (Cout % 64 == 0 wherever colsum is used)
         const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
-        float m[4][4];
+        float z[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) m[i][jj] = Ms[((i * 4 + jj) * 32 + o_tile) * 32 + o_c];
-        float s0[4], s1[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            s0[jj] = m[0][jj] + m[1][jj] + m[2][jj];
-            s1[jj] = m[1][jj] - m[2][jj] - m[3][jj];
-        }
+            for (int q = 0; q < 2; ++q) z[i][q] = Ms[((i * 2 + q) * 32 + o_tile) * 64 + o_c];
         float y[2][2];
-        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
-        y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            y[0][q] = z[0][q] + z[1][q] + z[2][q];
+            y[1][q] = z[1][q] - z[2][q] - z[3][q];
+        }
         const int ty = o_tile >> 3, tx = o_tile & 7;
         float csum = 0.f;
 #pragma unroll
@@ -244,13 +242,16 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
                     csum += v;
                 }
             }
-        if (p.colsum) {      // the two lanes of a wave that share this channel, then one atomic per wave
-            csum += __shfl_xor(csum, 32, 64);
-            if ((tid & 63) < 32) atomicAdd(p.colsum + co, csum);
-        }
+        return csum;
+    };
+    auto emit_all = [&]() {
+        float csum = 0.f;
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) csum += emit(rep);
+        if (p.colsum && cout0 + o_c < p.Cout) atomicAdd(p.colsum + cout0 + o_c, csum);   // one atomic per thread-column
     };
 
-    // The two roles run separate code paths with the SAME barrier sequence (2 + nks + 8); keeping them apart lets the
+    // The two roles run separate code paths with the SAME barrier sequence (2 + nks + 2); keeping them apart lets the
     // register allocator give the 128 accumulator registers to the MFMA waves only.
     if (is_mma) {
         f32x16 acc[4][2];
@@ -293,20 +294,18 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             }
             __syncthreads();
         }
+        __syncthreads();                                    // every wave is done with the operand buffers
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {              // channels [pass*32, pass*32+32) of the 64
-            __syncthreads();
+        for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    Ms[((wave * 4 + j) * 32 + row) * 32 + li] = acc[j][pass][r];
-                }
-            __syncthreads();
-            emit(pass, 0);
-            emit(pass, 1);
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float m0 = acc[0][q2][r], m1 = acc[1][q2][r], m2 = acc[2][q2][r], m3 = acc[3][q2][r];
+                Ms[((wave * 2 + 0) * 32 + row) * 64 + q2 * 32 + li] = m0 + m1 + m2;
+                Ms[((wave * 2 + 1) * 32 + row) * 64 + q2 * 32 + li] = m1 - m2 - m3;
+            }
+        __syncthreads();
+        emit_all();
     } else {
         float4 rv[NRAW];
         issue_raw(0, rv);
@@ -328,13 +327,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             if (!(p.dbg & 1)) transform(rawn, Vn);
             __syncthreads();
         }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            __syncthreads();
-            __syncthreads();
-            emit(pass, 0);
-            emit(pass, 1);
-        }
+        __syncthreads();
+        __syncthreads();
+        emit_all();
     }
 }
 
@@ -365,7 +360,7 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     d.shift = shift;
     d.relu = relu;
     d.colsum = colsum;
-    ERD_REQUIRE(!colsum || Cout % 32 == 0, "wino: colsum needs Cout %% 32 == 0");
+    ERD_REQUIRE(!colsum || Cout % 4 == 0, "wino: colsum needs Cout %% 4 == 0");
     static const int dbg = getenv("ERD_WINO_DBG") ? atoi(getenv("ERD_WINO_DBG")) : 0;
     d.dbg = dbg;
     int blocks = 0;
