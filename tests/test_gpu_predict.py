@@ -142,3 +142,36 @@ def test_detector_predict_mode_matches_oracle_on_its_own_head_outputs():
     for d, w in zip(out, want):
         p = d.pred_instances
         assert_same_detections((p.bboxes, p.scores, p.labels), w)
+
+
+def test_predict_results_feed_the_coco_evaluator():
+    """mode='predict' -> CocoBBoxEval: detections of the model on its own synthetic ground truth boxes flow through the
+    evaluator (old/new split table included); with the teacher's boxes fed back as predictions the metric is 1."""
+    import e2e_util as U
+    from erd_amd.evaluation import CocoBBoxEval, split_map
+    tsd, ssd = U.f7_state_dicts()
+    model = U.build_erd(tsd, ssd).eval()
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=4)
+    x, metas = O.preprocess(imgs)
+    for m in metas:
+        m["scale_factor"] = (1.0, 1.0)
+    cats = [dict(id=10 + k, name=f"class{k}") for k in range(80)]
+    anns, aid = [], 1
+    for i, (b, l) in enumerate(zip(boxes, labels)):
+        for bb, ll in zip(b.tolist(), l.tolist()):
+            anns.append(dict(id=aid, image_id=i, category_id=10 + 40 + ll, bbox=[bb[0], bb[1], bb[2] - bb[0], bb[3] - bb[1]],
+                             area=(bb[2] - bb[0]) * (bb[3] - bb[1]), iscrowd=0))
+            aid += 1
+    gt = dict(images=[dict(id=i, width=153, height=123) for i in range(2)], categories=cats, annotations=anns)
+    out = model(x.cuda(), U.make_samples(boxes, labels, metas), mode="predict")
+    ev = CocoBBoxEval(gt, cat_ids=[c["id"] for c in cats])
+    for i, d in enumerate(out):
+        p = d.pred_instances
+        ev.add_predictions(i, p.bboxes.cpu().numpy(), p.scores.cpu().numpy(), p.labels.cpu().numpy())
+    s = ev.evaluate()
+    assert -1.0 <= s["bbox_mAP"] <= 1.0 and set(split_map(ev, [c["id"] for c in cats[:40]])) == {"old_mAP", "new_mAP", "all_mAP"}
+    ev2 = CocoBBoxEval(gt, cat_ids=[c["id"] for c in cats])
+    for i, (b, l) in enumerate(zip(boxes, labels)):
+        ev2.add_predictions(i, b.numpy(), np.ones(len(b)), (l + 40).numpy())
+    assert ev2.evaluate()["bbox_mAP"] == pytest.approx(1.0)
+    assert split_map(ev2, [c["id"] for c in cats[:40]])["new_mAP"] == pytest.approx(1.0)
