@@ -94,6 +94,7 @@ _SIGNATURES = {
     "erd_loss_avg": [P, i32, P, i32, P, P],
     "erd_loss_finalize": [P, P, P, P, P, i32, i32, i32, f32, f32, f32, f32, f32, P, P, P, P],
     "erd_preprocess_image": [P, i32, i32, i32, P, i32, i32, P, P, i32, f32, P],
+    "erd_resize_normalize": [P, i32, i32, P, P, P, P, i32, i32, P, i32, i32, P, P, i32, i32, f32, P],
     "erd_predict_ws_bytes": [i32, i32, i32],
     "erd_predict_topk": [P, P, P, i32, i64, i32, P, P, P, f32, i32, P, P, P, P, P, C.c_size_t, P],
     "erd_predict_nms": [P, P, P, P, i32, i32, P, f32, f32, i32, P, P, P, P, C.c_size_t, P],

@@ -640,6 +640,57 @@ extern "C" int erd_preprocess_image(const void* img, int is_uint8, int h, int w,
     return erd::check_launch("preprocess");
 }
 
+namespace {
+// Resize(keep_ratio) + RandomFlip + DetDataPreprocessor fused: one thread per OUTPUT pixel of the
+// padded [3][H][W] slot.  The 8-bit bilinear resize follows OpenCV's fixed-point two-pass scheme (coefficient tables are
+// built on the host exactly as the test oracle builds them): rows = S[x0]*a0 + S[x1]*a1 (int, x2048), then
+// u8 = (((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2, and only then float, (v - mean) / std.
+__global__ __launch_bounds__(256) void resize_normalize_kernel(const uint8_t* __restrict__ src, int sh, int sw,
+                                                               const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                               const int* __restrict__ yofs, const short* __restrict__ yco,
+                                                               int nh, int nw, float* __restrict__ out, int H, int W, float m0,
+                                                               float m1, float m2, float s0, float s1, float s2, int flip,
+                                                               int swap_rb, float pad_value) {
+    const int64_t plane = (int64_t)H * W;
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= plane) return;
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    if (y >= nh || x >= nw) {
+        out[i] = pad_value; out[plane + i] = pad_value; out[2 * plane + i] = pad_value;
+        return;
+    }
+    const int xs = flip ? nw - 1 - x : x;                       // flipping the resized image == reading it mirrored
+    const int x0 = xofs[xs], x1 = min(x0 + 1, sw - 1);
+    const int y0 = yofs[y], y1 = min(y0 + 1, sh - 1);
+    const int a0 = xco[2 * xs], a1 = xco[2 * xs + 1], b0 = yco[2 * y], b1 = yco[2 * y + 1];
+    const uint8_t* r0 = src + (int64_t)y0 * sw * 3;
+    const uint8_t* r1 = src + (int64_t)y1 * sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int cs = swap_rb ? 2 - c : c;
+        const int t0 = r0[x0 * 3 + cs] * a0 + r0[x1 * 3 + cs] * a1;
+        const int t1 = r1[x0 * 3 + cs] * a0 + r1[x1 * 3 + cs] * a1;
+        int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        out[c * plane + i] = __fdiv_rn(__fsub_rn((float)v, mean), sd);
+    }
+}
+}  // namespace
+
+extern "C" int erd_resize_normalize(const void* src_hwc_u8, int sh, int sw, const int* xofs, const short* xcoef,
+                                    const int* yofs, const short* ycoef, int nh, int nw, float* out, int H, int W,
+                                    const float* mean3, const float* std3, int flip, int swap_rb, float pad_value,
+                                    erd_stream_t stream) {
+    ERD_REQUIRE(src_hwc_u8 && xofs && xcoef && yofs && ycoef && out && mean3 && std3, "resize_normalize: null");
+    ERD_REQUIRE(sh > 0 && sw > 0 && nh > 0 && nw > 0 && H >= nh && W >= nw, "resize_normalize: bad sizes");
+    const int64_t plane = (int64_t)H * W;
+    hipLaunchKernelGGL(resize_normalize_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint8_t*>(src_hwc_u8), sh, sw, xofs, xcoef, yofs, ycoef, nh, nw, out, H, W,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], flip, swap_rb, pad_value);
+    return erd::check_launch("resize_normalize");
+}
+
 extern "C" int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                            float* scale, float* shift, int64_t n, erd_stream_t stream) {
     ERD_REQUIRE(gamma && beta && mean && var && scale && shift, "bn_fold: null");

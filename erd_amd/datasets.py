@@ -1,7 +1,7 @@
 """Annotation side of the data pipeline: COCO json -> per-image records restricted to the
 configured classes, the empty/min-size filter, aspect-ratio batching, category slicing for the 40+40 protocol.
 Host-side integer / dictionary work only (the reference does this in Python too); pixels are decoded and resized
-elsewhere -- this module never touches image data.
+by `GpuDetPipeline` at the end of this file (decode on the host with PIL, everything else in ONE HIP kernel).
 
 Reference: mmdet/datasets/coco.py:59-100 (load_data_list), :102-170 (parse_data_info), :172-212 (filter_data);
 mmdet/datasets/samplers/batch_sampler.py:11-68; scripts/select_categories.py:21-64; pycocotools' COCO index
@@ -10,10 +10,12 @@ mmdet/datasets/samplers/batch_sampler.py:11-68; scripts/select_categories.py:21-
 from __future__ import annotations
 
 import json
+import math
 import os
 from collections import defaultdict
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from .structures import DetDataSample, InstanceData
@@ -79,14 +81,17 @@ class CocoAnnotations:
     def get_data_info(self, idx: int) -> dict:
         return self.data_list[idx]
 
-    def data_sample(self, idx: int, scale_factor=(1.0, 1.0), flip: bool = False, img_shape=None) -> DetDataSample:
+    def data_sample(self, idx: int, scale_factor=(1.0, 1.0), flip: bool = False, img_shape=None, clip: bool = False) -> DetDataSample:
         """PackDetInputs for the annotation half: boxes of non-ignored instances scaled by (w_scale, h_scale) and
         optionally flipped horizontally inside img_shape (RandomFlip), ignored ones in `ignored_instances`."""
         d = self.data_list[idx]
         sw, sh = scale_factor
         shape = img_shape or (int(d["height"] * sh + 0.5), int(d["width"] * sw + 0.5))
         boxes = torch.tensor([i["bbox"] for i in d["instances"]], dtype=torch.float32).reshape(-1, 4)
-        boxes = boxes * torch.tensor([sw, sh, sw, sh])
+        boxes = boxes * torch.tensor([sw, sh, sw, sh], dtype=torch.float32)
+        if clip:           # Resize(clip_object_border=True): boxes clipped to the resized image
+            boxes[:, 0::2].clamp_(0, shape[1])
+            boxes[:, 1::2].clamp_(0, shape[0])
         if flip:
             x1 = shape[1] - boxes[:, 2]
             x2 = shape[1] - boxes[:, 0]
@@ -139,3 +144,78 @@ class AspectRatioBatchSampler:
     def __len__(self) -> int:
         n = len(self.sampler)
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+
+# ---------------------------------------------------------------------------------------------------------
+# image side: LoadImageFromFile -> Resize(scale=(1333, 800), keep_ratio=True) -> RandomFlip(0.5) -> PackDetInputs ->
+# DetDataPreprocessor (configs/gfl_increment/*:13-19, data_preprocessor.py:110-183).  Decode stays on the host (PIL; the
+# reference decodes with cv2 on the host too); resize + flip + normalise + pad are one kernel over the padded batch slot
+# (erd_resize_normalize).  cv2's 8-bit bilinear resize is restated (resize.cpp: half-pixel centres, 11-bit fixed-point
+# weights, two-pass rounding) -- UNPINNED against cv2, which is not in this image.
+# ---------------------------------------------------------------------------------------------------------
+def linear_coeffs(src: int, dst: int):
+    """per output index along one axis: source index (int32) and the two fixed-point weights (int16, sum 2048)"""
+    scale = 1.0 / (float(dst) / float(src))
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int32)
+    f = f - s.astype(np.float32)
+    lo, hi = s < 0, s >= src - 1
+    f[lo], s[lo] = 0.0, 0
+    f[hi], s[hi] = 0.0, src - 1
+    c1 = np.rint(f.astype(np.float64) * 2048.0)
+    c0 = np.rint((1.0 - f).astype(np.float32).astype(np.float64) * 2048.0)
+    return s, np.stack([c0, c1], 1).astype(np.int16)
+
+
+def load_image_bgr(path: str) -> np.ndarray:
+    """LoadImageFromFile: uint8 [h, w, 3] in BGR order (what cv2.imread hands the reference's pipeline)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+
+
+class GpuDetPipeline:
+    """one training batch from image indices: decoded images -> normalised, padded [N,3,H,W] fp32 on the GPU + data
+    samples with resized / flipped / clipped boxes.  Deterministic given `seed` (flip decisions per (epoch, index))."""
+
+    def __init__(self, annotations: CocoAnnotations, scale=(1333, 800), flip_prob: float = 0.5, mean=(123.675, 116.28, 103.53),
+                 std=(58.395, 57.12, 57.375), bgr_to_rgb: bool = True, pad_size_divisor: int = 32, pad_value: float = 0.0,
+                 seed: int = 0, loader=load_image_bgr, device="cuda"):
+        self.ann, self.scale, self.flip_prob = annotations, tuple(scale), flip_prob
+        self.mean = [float(np.float32(v)) for v in mean]
+        self.std = [float(np.float32(v)) for v in std]
+        self.swap, self.div, self.pad_value, self.seed = bgr_to_rgb, pad_size_divisor, pad_value, seed
+        self.loader, self.device = loader, torch.device(device)
+        self._tables: Dict[tuple, tuple] = {}
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def _table(self, sh, sw, nh, nw):
+        key = (sh, sw, nh, nw)
+        if key not in self._tables:
+            xo, xc = linear_coeffs(sw, nw)
+            yo, yc = linear_coeffs(sh, nh)
+            self._tables[key] = tuple(torch.from_numpy(a).to(self.device) for a in (xo, xc, yo, yc))
+        return self._tables[key]
+
+    def batch(self, indices: Sequence[int]):
+        from . import kernels as K
+        imgs = [self.loader(self.ann.get_data_info(i)["img_path"]) for i in indices]
+        new = [rescale_size((im.shape[1], im.shape[0]), self.scale) for im in imgs]          # (w, h)
+        H = max(int(math.ceil(h / self.div)) * self.div for _, h in new)
+        W = max(int(math.ceil(w / self.div)) * self.div for w, _ in new)
+        out = torch.empty((len(imgs), 3, H, W), dtype=torch.float32, device=self.device)
+        samples = []
+        for k, (i, im, (nw, nh)) in enumerate(zip(indices, imgs, new)):
+            rng = np.random.RandomState((self.seed * 1000003 + self.epoch * 7919 + int(i)) % (2 ** 31 - 1))
+            flip = bool(rng.rand() < self.flip_prob)
+            src = torch.from_numpy(im).to(self.device, non_blocking=True)
+            K.resize_normalize_into(src, self._table(im.shape[0], im.shape[1], nh, nw), (nh, nw), out[k], self.mean, self.std,
+                                    flip, self.swap, self.pad_value)
+            s = self.ann.data_sample(i, scale_factor=(nw / im.shape[1], nh / im.shape[0]), flip=flip, img_shape=(nh, nw),
+                                     clip=True)
+            s.set_metainfo(dict(pad_shape=(H, W), batch_input_shape=(H, W)))
+            samples.append(s)
+        return out, samples

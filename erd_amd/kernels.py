@@ -501,6 +501,20 @@ def preprocess_into(img: Tensor, out_slot: Tensor, mean, std, flip_channels: boo
          out_slot.shape[1], out_slot.shape[2], m, s, int(flip_channels), float(pad_value), _stream())
 
 
+def resize_normalize_into(src_hwc_u8: Tensor, tables, new_hw, out_slot: Tensor, mean, std, flip: bool, swap_rb: bool,
+                          pad_value: float) -> None:
+    """decoded uint8 [h,w,3] image on the GPU -> out_slot [3,H,W]: bilinear resize to new_hw (fixed-point, the tables
+    come from datasets.linear_coeffs), optional horizontal flip / channel swap, (v-mean)/std, pad_value elsewhere."""
+    _require_gpu(src_hwc_u8, out_slot)
+    assert src_hwc_u8.dtype == torch.uint8 and src_hwc_u8.dim() == 3 and src_hwc_u8.shape[2] == 3 and src_hwc_u8.is_contiguous()
+    xo, xc, yo, yc = tables
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    call("erd_resize_normalize", _p(src_hwc_u8), src_hwc_u8.shape[0], src_hwc_u8.shape[1], _p(xo), _p(xc), _p(yo), _p(yc),
+         int(new_hw[0]), int(new_hw[1]), _p(out_slot), out_slot.shape[1], out_slot.shape[2], m, sd, int(flip), int(swap_rb),
+         float(pad_value), _stream())
+
+
 def bn_fold(gamma: Tensor, beta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5):
     _require_gpu(gamma)
     scale = torch.empty_like(gamma)

@@ -158,6 +158,15 @@ int erd_preprocess_image(const void* img, int is_uint8, int h, int w, float* out
                          const float* mean3, const float* std3, int flip_channels, float pad_value,
                          erd_stream_t stream);
 
+/* Resize(keep_ratio, bilinear) + RandomFlip + DetDataPreprocessor in one pass over the padded output slot
+ * (configs/gfl_increment/*:13-19 pipeline; mmcv.imrescale backend cv2, restated and UNPINNED vs cv2): src is the decoded
+ * uint8 image [sh][sw][3] on the device, {x,y}ofs / {x,y}coef the per-output-pixel source index and the two 11-bit
+ * fixed-point weights along each axis (host-built, device arrays), (nh, nw) the resized size inside the (H, W) slot. */
+int erd_resize_normalize(const void* src_hwc_u8, int sh, int sw, const int* xofs, const short* xcoef,
+                         const int* yofs, const short* ycoef, int nh, int nw, float* out, int H, int W,
+                         const float* mean3, const float* std3, int flip, int swap_rb, float pad_value,
+                         erd_stream_t stream);
+
 /* ---- frozen-statistics BN helpers ---------------------------------------------------------- */
 /* scale = gamma*rsqrt(var+eps), shift = beta-mean*scale over n channels (resnet.py:268-300, eval BN) */
 int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,

@@ -129,3 +129,27 @@ def test_aspect_ratio_batch_sampler_equals_reference_class(bs, drop_last):
     assert list(mine) == want
     assert len(mine) == len(mod.AspectRatioBatchSampler(S(order, a), bs, drop_last))
     assert list(mine) == want            # the buckets reset between epochs
+
+
+def test_cv2_style_resize_restatement_known_answers():
+    """oracle/image_ops.py (the checker of the GPU resize kernel): properties that follow from OpenCV's INTER_LINEAR
+    definition; the product's coefficient tables equal the oracle's."""
+    from erd_amd.datasets import linear_coeffs
+    from oracle import image_ops as I
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(I.resize_linear_u8(img, 53, 37), img)                      # same size: identity
+    flat = np.full((20, 30, 3), 177, dtype=np.uint8)
+    assert (I.resize_linear_u8(flat, 77, 41) == 177).all()                           # constants are preserved
+    for src, dst in [(480, 800), (640, 1067), (5, 8), (1333, 97), (7, 7)]:
+        o, c = I.linear_coeffs(src, dst)
+        assert (c.astype(int).sum(1) == 2048).all() and o.min() >= 0 and o.max() <= src - 1
+        o2, c2 = linear_coeffs(src, dst)
+        assert np.array_equal(o, o2) and np.array_equal(c, c2)
+    # exact 2x upscale of a 1-D ramp: centres fall at 1/4 and 3/4 between source pixels; borders are clamped
+    ramp = (np.arange(8, dtype=np.uint8) * 16)[None, :, None].repeat(2, 0).repeat(3, 2)
+    up = I.resize_linear_u8(ramp, 16, 2)[0, :, 0]
+    assert up.tolist() == [0, 4, 12, 20, 28, 36, 44, 52, 60, 68, 76, 84, 92, 100, 108, 112]
+    out, sf = I.resize_flip(img, (133, 80), flip=True)
+    assert out.shape == (80, 115, 3) and sf == (115 / 53, 80 / 37)
+    assert np.array_equal(out, I.resize_linear_u8(img, 115, 80)[:, ::-1])
