@@ -37,6 +37,8 @@ class CocoAnnotations:
     def __init__(self, ann_file, classes: Sequence[str], data_prefix: str = "", filter_empty_gt: bool = True,
                  min_size: int = 32, test_mode: bool = False):
         ds = json.load(open(ann_file)) if isinstance(ann_file, (str, os.PathLike)) else ann_file
+        if classes is None:      # CocoDataset's default METAINFO lists all 80 names: every category of the file matches
+            classes = [c["name"] for c in ds["categories"]]
         names = set(classes)
         # getCatIds(catNms=classes): ids in the FILE's category order, not in `classes` order (coco.py:69-72)
         self.cat_ids = [c["id"] for c in ds["categories"] if c["name"] in names]

@@ -140,6 +140,45 @@ class SyntheticDetData:
             yield dict(inputs=imgs, data_samples=samples)
 
 
+class CocoTrainData:
+    """The real-data source of `train_dataloader` (configs/_base_/datasets/coco_detection.py:37-50): CocoDataset
+    annotations restricted to `metainfo.classes`, DefaultSampler(shuffle=True) sharded over ranks, AspectRatioBatchSampler,
+    and the GPU image pipeline.  Batches arrive normalised and padded (`preprocessed=True`)."""
+
+    def __init__(self, dataset_cfg: dict, batch_size: int, classes=None, scale=(1333, 800), seed: int = 0, rank: int = 0,
+                 world: int = 1, device="cuda"):
+        from .datasets import AspectRatioBatchSampler, CocoAnnotations, GpuDetPipeline
+        root = dataset_cfg.get("data_root", "")
+        classes = classes or (dataset_cfg.get("metainfo") or {}).get("classes")     # None: every category of the file
+        fc = dataset_cfg.get("filter_cfg") or {}
+        self.ann = CocoAnnotations(os.path.join(root, dataset_cfg["ann_file"]), classes,
+                                   data_prefix=os.path.join(root, (dataset_cfg.get("data_prefix") or {}).get("img", "")),
+                                   filter_empty_gt=fc.get("filter_empty_gt", True), min_size=fc.get("min_size", 32))
+        self.pipe = GpuDetPipeline(self.ann, scale=scale, seed=seed, device=device)
+        self.bs, self.seed, self.rank, self.world, self.epoch = batch_size, seed, rank, world, 0
+        self._sampler_cls = AspectRatioBatchSampler
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+        self.pipe.set_epoch(epoch)
+
+    def _indices(self) -> List[int]:
+        g = torch.Generator()
+        g.manual_seed(self.seed + self.epoch)                    # DefaultSampler: randperm per epoch, same on every rank
+        perm = torch.randperm(len(self.ann), generator=g).tolist()
+        total = -(-len(perm) // self.world) * self.world          # padded so that every rank sees the same count
+        perm = (perm * (total // max(len(perm), 1) + 1))[:total]
+        return perm[self.rank::self.world]
+
+    def __len__(self):
+        return -(-len(self._indices()) // self.bs)
+
+    def __iter__(self):
+        for idx in self._sampler_cls(self._indices(), self.ann, self.bs):
+            x, samples = self.pipe.batch(idx)
+            yield dict(inputs=x, data_samples=samples, preprocessed=True)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------------------------------------
@@ -199,7 +238,7 @@ class Runner:
             self.trainer.epoch_factor = self.schedule.epoch_factor(self.epoch)
             t0 = time.perf_counter()
             for i, batch in enumerate(self.data):
-                out = pre(batch, True)
+                out = batch if batch.get("preprocessed") else pre(batch, True)
                 logv = self.trainer.train_step(out["inputs"], out["data_samples"])
                 window.append(logv)
                 done += 1

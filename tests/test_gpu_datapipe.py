@@ -84,3 +84,59 @@ def test_pipeline_feeds_a_training_step(tmp_path):
     log = tr.train_step(x, samples)
     tr.flush()
     assert np.isfinite(float(log["loss"])) and float(log["loss"]) > 0
+
+
+def test_train_py_runs_on_real_files(tmp_path):
+    """tools/train.py with the config's COCO files present: annotations -> shuffled aspect-ratio batches -> GPU pipeline ->
+    trainer (2 iterations), through the CLI."""
+    import subprocess, sys
+    import e2e_util as U
+    (tmp_path / "annotations").mkdir()
+    (tmp_path / "train2017").mkdir()
+    ds = _make_dataset(tmp_path / "train2017", [(120, 150), (140, 100), (100, 160), (150, 120)])
+    for c, k in zip(ds["categories"], (1, 2)):
+        c["name"] = f"cat{k}"
+    json.dump(ds, open(tmp_path / "annotations" / "train.json", "w"))
+    teacher = tmp_path / "teacher.pth"
+    torch.save(dict(state_dict=O.procedural_state_dict(40, seed=0)), teacher)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "train.py"), U.CFG_INCRE, "--work-dir", str(tmp_path / "w"),
+           "--max-iters", "2", "--cfg-options", "train_dataloader.batch_size=2",
+           f"train_dataloader.dataset.data_root={tmp_path}/", "train_dataloader.dataset.ann_file=annotations/train.json",
+           "train_dataloader.dataset.filter_cfg.min_size=0",
+           f"model.ori_setting.ori_checkpoint_file={teacher}", f"model.ori_setting.ori_config_file={U.CFG_FIRST}",
+           "default_hooks.logger.interval=1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "Epoch(train) [1][2/2]" in out.stdout and "loss_dist_bbox" in out.stdout
+
+
+def test_test_py_evaluates_a_checkpoint(tmp_path):
+    """tools/test.py: checkpoint + val images -> predict (rescaled to the original image) -> COCO mAP table with the
+    old / new split.  Procedural weights, so the numbers are ~0; the plumbing (ids, label->category, rescale) is what runs."""
+    import subprocess, sys
+    import e2e_util as U
+    from erd_amd.runner import save_checkpoint
+    (tmp_path / "val").mkdir()
+    ds = _make_dataset(tmp_path / "val", [(120, 150), (140, 100), (100, 160)])
+    ds["categories"] = [dict(id=10 + k, name=f"k{k}") for k in range(80)]
+    for a in ds["annotations"]:
+        a["category_id"] = 10 + 40 + a["category_id"]
+    json.dump(ds, open(tmp_path / "val.json", "w"))
+    tsd, ssd = U.f7_state_dicts()
+    ckpt = tmp_path / "epoch_12.pth"
+    save_checkpoint(str(ckpt), U.build_erd(tsd, ssd), with_teacher=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "test.py"), U.CFG_INCRE, str(ckpt), "--batch-size", "2", "--out",
+           str(tmp_path / "res.json"), "--cfg-options", f"test_dataloader.dataset.data_root={tmp_path}/",
+           "test_dataloader.dataset.ann_file=val.json", "test_dataloader.dataset.data_prefix.img=val/",
+           "model.test_cfg.score_thr=0.001"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "bbox_mAP" in out.stdout and "old_mAP" in out.stdout and "new_mAP" in out.stdout
+    res = json.load(open(tmp_path / "res.json"))
+    assert set(res["stats"]) >= {"bbox_mAP", "bbox_mAP_50", "AR@100", "old_mAP", "new_mAP"} and len(res["classwise"]) == 80
+    for r in res["results"]:                                   # boxes live in ORIGINAL image coordinates
+        im = next(i for i in ds["images"] if i["id"] == r["image_id"])
+        assert r["bbox"][0] >= -1e-3 and r["bbox"][0] + r["bbox"][2] <= im["width"] + 1e-2
+        assert 10 <= r["category_id"] < 90

@@ -6,8 +6,9 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
 
 Same flags as the reference's tools/train.py:15-129 (--work-dir, --amp, --auto-scale-lr, --resume, --cfg-options,
---launcher).  There is no COCO on this machine and no image decoder pipeline yet, so the data source is
-`--synthetic ITERS_PER_EPOCH` (batches shaped like the reference's demo_mm_inputs); `--amp` is refused (fp32 path).
+--launcher).  With the config's COCO annotation file present the real pipeline runs (CocoAnnotations + shuffled,
+rank-sharded aspect-ratio batches + the GPU resize/flip/normalise kernel); otherwise, or with `--synthetic ITERS`,
+batches shaped like the reference's demo_mm_inputs.  `--amp` is refused (the path computes in fp32).
 """
 import argparse
 import ast
@@ -38,7 +39,8 @@ def main(argv=None):
     ap.add_argument("--resume", nargs="?", type=str, const="auto")
     ap.add_argument("--cfg-options", nargs="+")
     ap.add_argument("--launcher", choices=["none", "pytorch"], default="none")
-    ap.add_argument("--synthetic", type=int, default=50, metavar="ITERS", help="synthetic iterations per epoch")
+    ap.add_argument("--synthetic", type=int, default=None, metavar="ITERS",
+                    help="synthetic iterations per epoch instead of the config's COCO files (the default when they are absent)")
     ap.add_argument("--image-size", type=int, nargs=2, default=(800, 1333), metavar=("H", "W"))
     ap.add_argument("--max-iters", type=int, default=None)
     ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
@@ -73,8 +75,16 @@ def main(argv=None):
     head = cfg.model.bbox_head
     ori = cfg.model.get("ori_setting")
     num_new = head.num_classes - (ori.ori_num_classes if ori else 0)
-    data = SyntheticDetData(int(cfg.train_dataloader.batch_size), num_new, args.synthetic, tuple(args.image_size),
-                            seed=rank)
+    dcfg = cfg.train_dataloader.dataset
+    ann_path = os.path.join(dcfg.get("data_root", ""), dcfg.get("ann_file", ""))
+    if args.synthetic is None and os.path.isfile(ann_path):
+        from erd_amd.runner import CocoTrainData
+        scale = next((t["scale"] for t in dcfg.get("pipeline", []) if t.get("type") == "Resize"), (1333, 800))
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        data = CocoTrainData(dcfg, int(cfg.train_dataloader.batch_size), scale=tuple(scale), seed=0, rank=rank, world=world)
+    else:
+        data = SyntheticDetData(int(cfg.train_dataloader.batch_size), num_new, args.synthetic or 50, tuple(args.image_size),
+                                seed=rank)
     runner = Runner.from_cfg(cfg, data=data)
     runner.train(max_iters=args.max_iters)
     if dist.is_initialized():
