@@ -27,6 +27,11 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+__device__ __forceinline__ float4 buf_load16_s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 constexpr int TBH = 4, TBW = 8;               // tiles per workgroup: 4 rows x 8 cols = 32 (one MFMA M-tile)
 constexpr int PR = 2 * TBH + 2, PC = 2 * TBW + 2;   // raw patch 10 x 18 pixels
 constexpr int KS = 16;                        // input channels per K slice
@@ -93,34 +98,54 @@ struct WinoDesc {
     int relu;
     float* colsum;           // optional [Cout]: += column sums of the stored result
     int blocks_per_nb;       // workgroups per cout block
+    int nitems;              // workgroup items = blocks_per_nb * cout blocks
     int dbg;                 // ablation switches (ERD_WINO_DBG): 1 no transform, 2 no weight loads, 4 no MFMA, 8 no raw loads
+};
+
+// One (tile block, cout block) work item: where it lives
+struct WinoItem {           // all fields are wave-uniform; decode() pins them to scalar registers
+    int s, n, y0, x0, cout0, cb0, cb1;
 };
 
 __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* raw0 = reinterpret_cast<float4*>(smem);         // 2 x [PR][PC][KS/4]
+    float4* raw0 = reinterpret_cast<float4*>(smem);         // 2 x [PR][PC][RCS]
     float4* raw1 = raw0 + RAW_LDS_F4;
-    float4* Vs0 = raw1 + RAW_LDS_F4;                             // 2 x [16][32 tiles][KS/4] swizzled
+    float4* Vs0 = raw1 + RAW_LDS_F4;                         // 2 x [16][32 tiles][KS/4] swizzled
     float4* Vs1 = Vs0 + V_F4;
-    float* Ms = reinterpret_cast<float*>(smem);              // output staging Z[4][2][32 tiles][64 couts] floats (64 KB), after the K loop
+    float* Ms = reinterpret_cast<float*>(smem);              // output staging Z[4][2][32 tiles][64 couts] floats (64 KB)
 
     const int tid = threadIdx.x;
-    const int nb = blockIdx.x / p.blocks_per_nb;             // cout block
-    int b = blockIdx.x % p.blocks_per_nb;
-    int s = 0;
-    while (s + 1 < p.nseg && b >= p.seg[s + 1].block0) ++s;
-    const WinoSeg& sg = p.seg[s];
-    b -= sg.block0;
-    const int per_img = sg.tbh * sg.tbw;
-    const int n = b / per_img;
-    const int rem = b - n * per_img;
-    const int tyb = rem / sg.tbw, txb = rem - tyb * sg.tbw;
-    const int y0 = tyb * 2 * TBH, x0 = txb * 2 * TBW;       // first output pixel of the block
-    const int H = sg.H, W = sg.W, Cin = p.Cin;
-    const int cout0 = nb * BN;
+    const int Cin = p.Cin;
+    const int cob_all = (p.Cout + 31) / 32;
+    const int64_t per_xi = (int64_t)cob_all * (Cin / 4) * 128;            // floats per transform position of U
+    const int nks = Cin / KS;
+    const int nitems = p.nitems;
 
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+    // PERSISTENT workgroups (one per CU): item = blockIdx.x, += gridDim.x.  Items are cout-block major, so at any time
+    // the whole chip works on one 64-channel slice of U (L2 resident).  The first two raw slices and the first weight
+    // fragments of the NEXT item are requested before the output stage of the current one: its global latency and the
+    // workgroup launch disappear behind work that exists anyway.
+    auto decode = [&](int item) {
+        WinoItem it;
+        const int nb = item / p.blocks_per_nb;
+        int b = item - nb * p.blocks_per_nb;
+        int s = 0;
+        while (s + 1 < p.nseg && b >= p.seg[s + 1].block0) ++s;
+        b -= p.seg[s].block0;
+        const int per_img = p.seg[s].tbh * p.seg[s].tbw;
+        const int n = b / per_img;
+        const int rem = b - n * per_img;
+        const int tyb = rem / p.seg[s].tbw, txb = rem - tyb * p.seg[s].tbw;
+        it.s = __builtin_amdgcn_readfirstlane(s);
+        it.n = __builtin_amdgcn_readfirstlane(n);
+        it.y0 = __builtin_amdgcn_readfirstlane(tyb * 2 * TBH);
+        it.x0 = __builtin_amdgcn_readfirstlane(txb * 2 * TBW);
+        it.cout0 = __builtin_amdgcn_readfirstlane(nb * BN);
+        it.cb0 = __builtin_amdgcn_readfirstlane(min((nb * BN) >> 5, cob_all - 1));
+        it.cb1 = __builtin_amdgcn_readfirstlane(min(((nb * BN) >> 5) + 1, cob_all - 1));
+        return it;
+    };
 
     // Wave specialisation: waves 0-3 only issue MFMAs (wave w owns transform row i = w), waves 4-7 only move and
     // transform data.  Every SIMD hosts one wave of each kind, so the hardware interleaves the matrix pipe with the
@@ -128,32 +153,29 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     const int wave = tid >> 6, lane = tid & 63;
     const bool is_mma = wave < 4;
     const int li = lane & 31, h = lane >> 5;
-    // ---- data-wave state ------------------------------------------------------------------------------------
     const int dt = tid & 255;
     constexpr int NRAW = (RAW_F4 + 255) / 256;
-    unsigned roff[NRAW];
-#pragma unroll
-    for (int i = 0; i < NRAW; ++i) {
-        const int it = dt + 256 * i;
-        roff[i] = OOB;
-        if (it < RAW_F4) {
-            const int chunk = it & 3, pix = it >> 2;
-            const int pr = pix / PC, pc = pix - pr * PC;
-            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                roff[i] = (unsigned)(n * sg.in_nstride + ((int64_t)iy * W + ix) * Cin + chunk * 4) * 4u;
-        }
-    }
     const int t_chunk = dt & 3, t_tile = (dt >> 2) & 31, t_half = dt >> 7;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
     auto vswz = [](int row, int c) { return c ^ ((row >> 2) & 3); };
 
-    const int cob_all = (p.Cout + 31) / 32;
-    const int64_t per_xi = (int64_t)cob_all * (Cin / 4) * 128;            // floats per transform position of U
-    const float4* U4 = reinterpret_cast<const float4*>(p.U);
-    const int nks = Cin / KS;
-
-    auto issue_raw = [&](int ks_, float4* dst) {
+    auto raw_offsets = [&](const WinoItem& it, unsigned (&roff)[NRAW]) {
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) {
+            const int idx = dt + 256 * i;
+            roff[i] = OOB;
+            if (idx < RAW_F4) {
+                const int chunk = idx & 3, pix = idx >> 2;
+                const int pr = pix / PC, pc = pix - pr * PC;
+                const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
+                if ((unsigned)iy < (unsigned)p.seg[it.s].H && (unsigned)ix < (unsigned)p.seg[it.s].W)
+                    roff[i] = (unsigned)(it.n * p.seg[it.s].in_nstride + ((int64_t)iy * p.seg[it.s].W + ix) * Cin + chunk * 4) * 4u;
+            }
+        }
+    };
+    auto issue_raw = [&](const WinoItem& it, const unsigned (&roff)[NRAW], int ks_, float4* dst) {
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.seg[it.s].in), 0, (int)((long long)p.seg[it.s].N * p.seg[it.s].in_nstride * 4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < NRAW; ++i)
             dst[i] = (ks_ < nks && roff[i] != OOB) ? buf_load16(rs_in, roff[i] + (unsigned)(ks_ * KS * 4))
@@ -162,12 +184,11 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     auto store_raw = [&](const float4* src, float4* rawbuf) {
 #pragma unroll
         for (int i = 0; i < NRAW; ++i) {
-            const int it = dt + 256 * i;
-            if (it < RAW_F4) rawbuf[(it >> 2) * RCS + (it & 3)] = src[i];
+            const int idx = dt + 256 * i;
+            if (idx < RAW_F4) rawbuf[(idx >> 2) * RCS + (idx & 3)] = src[i];
         }
     };
     // rows (2*HALF, 2*HALF+1) of B^T d B for this thread's (tile, 4 channels); waves 4,5 do HALF 0, waves 6,7 HALF 1
-    // (one wave-uniform branch per slice, straight-line code inside)
     auto transform_half = [&](const float4* rawbuf, float4* V, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;
         // HALF 0 needs patch rows 0,1,2 (r0 = d0 - d2, r1 = d1 + d2); HALF 1 rows 1,2,3 (r2 = d2 - d1, r3 = d1 - d3)
@@ -194,25 +215,37 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         if (t_half == 0) transform_half(rawbuf, V, std::integral_constant<int, 0>{});
         else transform_half(rawbuf, V, std::integral_constant<int, 1>{});
     };
-    // ---- MFMA-wave state: weight fragments of one k-step (4 positions x 2 cout sub-tiles) ------------------------
-    // (unconditional loads from clamped addresses -> straight-line code, so the compiler can wait for the OLDER of the
-    // two fragment sets only; channels past Cout compute garbage that the output stage never stores)
-    const int cb0 = min(cout0 >> 5, cob_all - 1), cb1 = min((cout0 >> 5) + 1, cob_all - 1);
-    auto load_fb = [&](int ks_, int kk, int j, float4 (&f)[2]) {
-        const int kc = min(ks_, nks - 1) * (KS / 4) + 2 * kk + h;
-        const float4* Ub = U4 + ((wave * 4 + j) * per_xi) / 4;
-        f[0] = Ub[((int64_t)cb0 * (Cin / 4) + kc) * 32 + li];
-        f[1] = Ub[((int64_t)cb1 * (Cin / 4) + kc) * 32 + li];
+    // Weight fragments: buffer loads with ONE resource, a per-(position, cout sub-tile) 32-bit lane offset that is fixed for
+    // an item, and the slice / k-step as the scalar offset operand -- 8 VGPRs of addressing in the MFMA waves (64-bit
+    // pointer arithmetic per load spilled registers once the kernel became persistent).
+    const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.U), 0, (int)(16 * per_xi * 4), 0x00020000);
+    auto fb_offsets = [&](const WinoItem& it, unsigned (&fbo)[4][2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned base = (unsigned)(((wave & 3) * 4 + j) * (per_xi / 4));
+            fbo[j][0] = (base + (unsigned)(it.cb0 * (Cin / 4) + h) * 32u + (unsigned)li) * 16u;
+            fbo[j][1] = (base + (unsigned)(it.cb1 * (Cin / 4) + h) * 32u + (unsigned)li) * 16u;
+        }
+    };
+    auto load_fb = [&](const unsigned (&fbo)[4][2], int ks_, int kk, float4 (&f)[4][2]) {
+        const unsigned soff = (unsigned)(min(ks_, nks - 1) * (KS / 4) + 2 * kk) * 512u;      // 32 lanes x 16 B per chunk
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[j][0] = buf_load16_s(rs_U, fbo[j][0], soff);
+            f[j][1] = buf_load16_s(rs_U, fbo[j][1], soff);
+        }
     };
 
     // Output stage.  Wave w holds M[i = w][j = 0..3]; the column half of A^T M A, z_q = sum_j M[w][j] A[j][q], is taken in
-    // registers, so only Z[i][q] (2 instead of 4 values per position row) goes through LDS: Zs[4 i][2 q][32 tiles][64 couts]
-    // = 64 KB, ONE pass.  All 512 threads then finish y[p][q] = sum_i A^T[p][i] Z[i][q], the epilogue and the stores.
+    // registers, so only Z[i][q] goes through LDS: Zs[4 i][2 q][32 tiles][64 couts] = 64 KB, ONE pass.  All 512 threads
+    // then finish y[p][q] = sum_i A^T[p][i] Z[i][q], the epilogue and the stores.
     const int o_c = tid & 63;
-    auto emit = [&](int rep) -> float {
+    auto emit = [&](const WinoItem& it, int rep) -> float {
         const int o_tile = (tid >> 6) + 8 * rep;
-        const int co = cout0 + o_c;
-        if (co >= p.Cout) return 0.f;                             // (Cout % 64 == 0 wherever colsum is used)
+        const int co = it.cout0 + o_c;
+        if (co >= p.Cout) return 0.f;
+        const WinoSeg& sg = p.seg[it.s];
         const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
         float z[4][2];
 #pragma unroll
@@ -231,9 +264,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int oy = y0 + 2 * ty + a, ox = x0 + 2 * tx + c;
-                if (oy < H && ox < W) {
-                    const int64_t o = n * sg.out_nstride + ((int64_t)oy * W + ox) * p.Cout + co;
+                const int oy = it.y0 + 2 * ty + a, ox = it.x0 + 2 * tx + c;
+                if (oy < sg.H && ox < sg.W) {
+                    const int64_t o = it.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout + co;
                     float v = y[a][c] * sc + sh;
                     if (sg.res) v += sg.res[o];
                     if (p.relu) v = fmaxf(v, 0.f);
@@ -244,92 +277,124 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             }
         return csum;
     };
-    auto emit_all = [&]() {
+    auto emit_all = [&](const WinoItem& it) {
         float csum = 0.f;
 #pragma unroll
-        for (int rep = 0; rep < 4; ++rep) csum += emit(rep);
-        if (p.colsum && cout0 + o_c < p.Cout) atomicAdd(p.colsum + cout0 + o_c, csum);   // one atomic per thread-column
+        for (int rep = 0; rep < 4; ++rep) csum += emit(it, rep);
+        if (p.colsum && it.cout0 + o_c < p.Cout) atomicAdd(p.colsum + it.cout0 + o_c, csum);
     };
 
-    // The two roles run separate code paths with the SAME barrier sequence (2 + nks + 2); keeping them apart lets the
-    // register allocator give the 128 accumulator registers to the MFMA waves only.
+    // The two roles run separate code paths with the SAME barrier sequence per item (2 + nks + 2); keeping them apart lets
+    // the register allocator give the 128 accumulator registers to the MFMA waves only.
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    WinoItem cur = decode(item);
     if (is_mma) {
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][q][r] = 0.f;
         float4 fb[2][4][2];                                 // [k-step][position][cout sub-tile]
+        unsigned fbo[4][2], nfbo[4][2];
+        fb_offsets(cur, fbo);
+        load_fb(fbo, 0, 0, fb[0]);
+        load_fb(fbo, 0, 1, fb[1]);
+        for (;;) {
+            f32x16 acc[4][2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_fb(0, kk, j, fb[kk][j]);
-        __syncthreads();
-        __syncthreads();
-        for (int ks = 0; ks < nks; ++ks) {
-            const float4* Vc = (ks & 1) ? Vs1 : Vs0;
-            float4 fa[2][4];
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+                    for (int r = 0; r < 16; ++r) acc[j][q][r] = 0.f;
+            __syncthreads();
+            __syncthreads();
+            const int nxt_item = item + gridDim.x;
+            const bool has_next = nxt_item < nitems;
+            const WinoItem nxt = has_next ? decode(nxt_item) : cur;
+            fb_offsets(nxt, nfbo);
+            for (int ks = 0; ks < nks; ++ks) {
+                const float4* Vc = (ks & 1) ? Vs1 : Vs0;
+                const bool last = ks + 1 == nks;
+                // k-step 0, then its weight fragments are re-loaded for the next slice (of this item or, on the last
+                // slice, slice 0 of the NEXT item); same for k-step 1.  (Re-loading each position right after its own
+                // MFMAs, or interleaved one group late, measured 40-45 % slower.)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fa[kk][j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, 2 * kk + h)];
-            // k-step 0, then its weight fragments are re-loaded for the next slice (they land under k-step 1 and the
-            // barrier); same for k-step 1.  (Re-loading each position right after its own MFMAs measured 45 % SLOWER:
-            // the load's write-after-read hazard on the fragment registers stalls the matrix pipe.)
+                for (int kk = 0; kk < 2; ++kk) {
+                    float4 fa[4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (!(p.dbg & 4)) {
+                    for (int j = 0; j < 4; ++j) fa[j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, 2 * kk + h)];
+                    if (!(p.dbg & 4)) {
 #define ERD_WMFMA(m)                                                                                              \
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)      \
-                        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][j].m, fb[kk][j][q].m, acc[j][q], 0, 0, 0);
-                    ERD_WMFMA(x) ERD_WMFMA(y) ERD_WMFMA(z) ERD_WMFMA(w)
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)  \
+                            acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].m, fb[kk][j][q].m, acc[j][q], 0, 0, 0);
+                        ERD_WMFMA(x) ERD_WMFMA(y) ERD_WMFMA(z) ERD_WMFMA(w)
 #undef ERD_WMFMA
+                    }
+                    if (!(p.dbg & 2)) {
+                        if (last) load_fb(nfbo, 0, kk, fb[kk]);
+                        else load_fb(fbo, ks + 1, kk, fb[kk]);
+                    }
                 }
-                if (!(p.dbg & 2)) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) load_fb(ks + 1, kk, j, fb[kk][j]);
-                }
+                __syncthreads();
             }
+            __syncthreads();                                // every wave is done with the operand buffers
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float m0 = acc[0][q2][r], m1 = acc[1][q2][r], m2 = acc[2][q2][r], m3 = acc[3][q2][r];
+                    Ms[((wave * 2 + 0) * 32 + row) * 64 + q2 * 32 + li] = m0 + m1 + m2;
+                    Ms[((wave * 2 + 1) * 32 + row) * 64 + q2 * 32 + li] = m1 - m2 - m3;
+                }
             __syncthreads();
+            emit_all(cur);
+            if (!has_next) break;
+            item = nxt_item;
+            cur = nxt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { fbo[j][0] = nfbo[j][0]; fbo[j][1] = nfbo[j][1]; }
+            __syncthreads();                                // Zs consumed: the operand buffers may be refilled
         }
-        __syncthreads();                                    // every wave is done with the operand buffers
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float m0 = acc[0][q2][r], m1 = acc[1][q2][r], m2 = acc[2][q2][r], m3 = acc[3][q2][r];
-                Ms[((wave * 2 + 0) * 32 + row) * 64 + q2 * 32 + li] = m0 + m1 + m2;
-                Ms[((wave * 2 + 1) * 32 + row) * 64 + q2 * 32 + li] = m1 - m2 - m3;
-            }
-        __syncthreads();
-        emit_all();
     } else {
-        float4 rv[NRAW];
-        issue_raw(0, rv);
-        store_raw(rv, raw0);
-        issue_raw(1, rv);
-        __syncthreads();
-        transform(raw0, Vs0);
-        store_raw(rv, raw1);
-        issue_raw(2, rv);
-        __syncthreads();
-        // state: V[0] = V(0), raw1 = raw(1), rv = raw(2) in flight
-        for (int ks = 0; ks < nks; ++ks) {
-            const int cur = ks & 1;
-            float4* Vn = cur ? Vs0 : Vs1;
-            float4* rawc = cur ? raw1 : raw0;      // held raw(ks): consumed before the last barrier -> receives raw(ks+2)
-            float4* rawn = cur ? raw0 : raw1;      // raw(ks+1)
-            store_raw(rv, rawc);
-            if (!(p.dbg & 8)) issue_raw(ks + 3, rv);
-            if (!(p.dbg & 1)) transform(rawn, Vn);
+        unsigned roff[NRAW], nroff[NRAW];
+        float4 rv[NRAW], rvb[NRAW];
+        raw_offsets(cur, roff);
+        issue_raw(cur, roff, 0, rv);
+        issue_raw(cur, roff, 1, rvb);
+        for (;;) {
+            store_raw(rv, raw0);
+            __syncthreads();
+            transform(raw0, Vs0);
+            store_raw(rvb, raw1);
+            issue_raw(cur, roff, 2, rv);
+            __syncthreads();
+            const int nxt_item = item + gridDim.x;
+            const bool has_next = nxt_item < nitems;
+            const WinoItem nxt = has_next ? decode(nxt_item) : cur;
+            // state: V[0] = V(0), raw1 = raw(1), rv = raw(2) in flight
+            for (int ks = 0; ks < nks; ++ks) {
+                const int c = ks & 1;
+                float4* Vn = c ? Vs0 : Vs1;
+                float4* rawc = c ? raw1 : raw0;      // held raw(ks): consumed before the last barrier -> receives raw(ks+2)
+                float4* rawn = c ? raw0 : raw1;      // raw(ks+1)
+                store_raw(rv, rawc);
+                if (!(p.dbg & 8)) issue_raw(cur, roff, ks + 3, rv);
+                if (!(p.dbg & 1)) transform(rawn, Vn);
+                __syncthreads();
+            }
+            if (has_next) {                          // the next item's first two raw slices travel during the output stage
+                raw_offsets(nxt, nroff);
+                issue_raw(nxt, nroff, 0, rv);
+                issue_raw(nxt, nroff, 1, rvb);
+            }
+            __syncthreads();
+            __syncthreads();
+            emit_all(cur);
+            if (!has_next) break;
+            item = nxt_item;
+            cur = nxt;
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) roff[i] = nroff[i];
             __syncthreads();
         }
-        __syncthreads();
-        __syncthreads();
-        emit_all();
     }
 }
 
@@ -394,6 +459,18 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
         attr_done = true;
     }
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)(blocks * ncb)), dim3(512), lds, (hipStream_t)stream, d);
+    d.nitems = blocks * ncb;
+    int ncu = 0;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        static int cached = 0;
+        if (cached == 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cached = prop.multiProcessorCount;
+        ncu = cached > 0 ? cached : 256;
+    }
+    static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
+    const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
+    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, d);
     return erd::check_launch("wino_conv3x3");
 }
