@@ -315,15 +315,17 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
                 // k-step 0, then its weight fragments are re-loaded for the next slice (of this item or, on the last
                 // slice, slice 0 of the NEXT item); same for k-step 1.  (Re-loading each position right after its own
                 // MFMAs, or interleaved one group late, measured 40-45 % slower.)
+                float4 fa[2][4];                     // both k-steps' tile fragments up front: one LDS latency per slice
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[kk][j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, 2 * kk + h)];
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    float4 fa[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) fa[j] = Vc[((wave * 4 + j) * 32 + li) * 4 + vswz(li, 2 * kk + h)];
                     if (!(p.dbg & 4)) {
 #define ERD_WMFMA(m)                                                                                              \
                         _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)  \
-                            acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].m, fb[kk][j][q].m, acc[j][q], 0, 0, 0);
+                            acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][j].m, fb[kk][j][q].m, acc[j][q], 0, 0, 0);
                         ERD_WMFMA(x) ERD_WMFMA(y) ERD_WMFMA(z) ERD_WMFMA(w)
 #undef ERD_WMFMA
                     }
