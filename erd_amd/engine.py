@@ -96,8 +96,9 @@ class BucketedGradSync:
     backward).  Device-agnostic (RCCL on GPUs, gloo in the CPU tests); the 1/world scaling is folded into the SGD
     kernel's `grad_scale`."""
 
-    def __init__(self, flat: FlatParams):
+    def __init__(self, flat: FlatParams, streams: Sequence = ()):
         self.flat = flat
+        self.streams = list(streams)     # HIP streams that may hold gradient-producing kernels of one backward pass
         self._works: List = []
         self._remaining: List[int] = []
         for i, p in enumerate(flat.params):
@@ -117,6 +118,13 @@ class BucketedGradSync:
             self._remaining[b] -= 1
             if self._remaining[b] == 0:
                 s, e, _ = self.flat.buckets[b]
+                # a bucket's gradients may come from kernels on different streams (the two head towers run their
+                # backward on two streams): the collective is ordered behind ALL of them, not only the reporting one
+                if self.streams:
+                    cs = torch.cuda.current_stream(self.flat.grad.device)
+                    for st in self.streams:
+                        if st != cs:
+                            cs.wait_stream(st)
                 self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
         return hook
 
@@ -191,7 +199,10 @@ class ERDTrainer:
         self._pending_lr = self.base_lr
         self._first = True
         self._pending = False                # an un-applied gradient sits in flat.grad
-        self.sync = BucketedGradSync(self.flat) if self.distributed else None
+        self.sync = None
+        if self.distributed:
+            from . import functional as Fn
+            self.sync = BucketedGradSync(self.flat, streams=[torch.cuda.current_stream(dev), Fn.aux_stream(dev)])
         self.is_erd = isinstance(model, GFLIncrementERD)
         self.overlap_teacher = overlap_teacher and self.is_erd
         self.side = torch.cuda.Stream(device=dev) if self.overlap_teacher else None
