@@ -130,3 +130,25 @@ def test_mixed_resolution_winograd_equals_direct(hw):
         for k in a:
             assert a[k] == pytest.approx(b[k], rel=(1e-3 if k.startswith("loss_dist") else 2e-4) * (1 + 2 * i), abs=1e-6), \
                 (i, k, a[k], b[k])
+
+
+def test_full_size_teacher_logits_and_ers_sets_vs_oracle():
+    """BASELINE size, one image: the teacher's head outputs against the CPU oracle (1e-3; observed ~1e-5) and the ERS
+    index sets bit-exact -- through the Winograd + direct kernels at the real level sizes (100x168 ... 7x11)."""
+    import bench
+    from oracle import erd_oracle as O
+    tsd, ssd = f7_state_dicts()
+    model = build_erd(tsd, ssd).eval()
+    x, _ = bench.synthetic_gpu_batch(1, seed=40, device=torch.device("cuda", 0))
+    with torch.no_grad():
+        t = model.teacher_pass(x)
+        ref_cls, ref_bbox = O.gfl_forward(tsd, x.cpu())
+    rc, rb = O.flatten_levels(ref_cls), O.flatten_levels(ref_bbox)
+    assert float((t.t_cls.cpu() - rc).abs().max()) < 1e-3 * float(rc.abs().max())
+    assert float((t.t_bbox.cpu() - rb).abs().max()) < 1e-3 * float(rb.abs().max())
+    ic, ib, thr_c, thr_b = O.ers_select_single(rc[0], rb[0])
+    cnt = t.ers["counts"].cpu()
+    assert torch.equal(t.ers["idx_cls"][0, :int(cnt[0, 0])].cpu(), ic)
+    assert torch.equal(t.ers["idx_bbox"][0, :int(cnt[0, 1])].cpu(), ib)
+    print("full-size teacher: max |dlogit| %.2e, ERS sets %d / %d anchors identical" %
+          (float((t.t_cls.cpu() - rc).abs().max()), len(ic), len(ib)))
