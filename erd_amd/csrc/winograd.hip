@@ -99,6 +99,7 @@ struct WinoDesc {
     float* colsum;           // optional [Cout]: += column sums of the stored result
     int blocks_per_nb;       // workgroups per cout block
     int nitems;              // workgroup items = blocks_per_nb * cout blocks
+    int* sched;              // optional {next-item counter, finished-workgroup counter}, zero on entry and on exit
     int dbg;                 // ablation switches (ERD_WINO_DBG): 1 no transform, 2 no weight loads, 4 no MFMA, 8 no raw loads
 };
 
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     float4* Vs0 = raw1 + RAW_LDS_F4;                         // 2 x [16][32 tiles][KS/4] swizzled
     float4* Vs1 = Vs0 + V_F4;
     float* Ms = reinterpret_cast<float*>(smem);              // output staging Z[4][2][32 tiles][64 couts] floats (64 KB)
+    int* sh_next = reinterpret_cast<int*>(Vs1 + V_F4);       // next item of this workgroup (dynamic scheduling)
 
     const int tid = threadIdx.x;
     const int Cin = p.Cin;
@@ -122,7 +124,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     const int nks = Cin / KS;
     const int nitems = p.nitems;
 
-    // PERSISTENT workgroups (one per CU): item = blockIdx.x, += gridDim.x.  Items are cout-block major, so at any time
+    // PERSISTENT workgroups (one per CU): the first item is blockIdx.x, further ones are claimed from a global counter (a
+    // workgroup that starts late -- its CU was busy with another stream's kernel or an RCCL channel -- simply claims
+    // fewer; with a static item += gridDim.x split it would hold the whole launch back).  Items are cout-block major, so at any time
     // the whole chip works on one 64-channel slice of U (L2 resident).  The first two raw slices and the first weight
     // fragments of the NEXT item are requested before the output stage of the current one: its global latency and the
     // workgroup launch disappear behind work that exists anyway.
@@ -303,9 +307,10 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][q][r] = 0.f;
+            if (tid == 0) *sh_next = p.sched ? (int)gridDim.x + atomicAdd(p.sched, 1) : item + (int)gridDim.x;
             __syncthreads();
             __syncthreads();
-            const int nxt_item = item + gridDim.x;
+            const int nxt_item = __builtin_amdgcn_readfirstlane(*sh_next);
             const bool has_next = nxt_item < nitems;
             const WinoItem nxt = has_next ? decode(nxt_item) : cur;
             fb_offsets(nxt, nfbo);
@@ -348,7 +353,12 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
                 }
             __syncthreads();
             emit_all(cur);
-            if (!has_next) break;
+            if (!has_next) {
+                if (tid == 0 && p.sched) {                   // the last workgroup to leave re-arms the counters
+                    if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
+                }
+                break;
+            }
             item = nxt_item;
             cur = nxt;
 #pragma unroll
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             store_raw(rvb, raw1);
             issue_raw(cur, roff, 2, rv);
             __syncthreads();
-            const int nxt_item = item + gridDim.x;
+            const int nxt_item = __builtin_amdgcn_readfirstlane(*sh_next);
             const bool has_next = nxt_item < nitems;
             const WinoItem nxt = has_next ? decode(nxt_item) : cur;
             // state: V[0] = V(0), raw1 = raw(1), rv = raw(2) in flight
@@ -415,7 +425,8 @@ extern "C" size_t erd_wino_weights_elems(int Cout, int Cin) {
 }
 
 extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout,
-                                const float* scale, const float* shift, int relu, float* colsum, erd_stream_t stream) {
+                                const float* scale, const float* shift, int relu, float* colsum, int* sched,
+                                erd_stream_t stream) {
     ERD_REQUIRE(segs && U && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
     ERD_REQUIRE(Cin % KS == 0 && Cout > 0, "wino: Cin=%d must be a multiple of %d", Cin, KS);
     WinoDesc d;
@@ -427,6 +438,7 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     d.shift = shift;
     d.relu = relu;
     d.colsum = colsum;
+    d.sched = sched;
     ERD_REQUIRE(!colsum || Cout % 4 == 0, "wino: colsum needs Cout %% 4 == 0");
     static const int dbg = getenv("ERD_WINO_DBG") ? atoi(getenv("ERD_WINO_DBG")) : 0;
     d.dbg = dbg;
@@ -453,7 +465,7 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     }
     d.blocks_per_nb = blocks;
     const int ncb = (Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (RAW_LDS_F4 + V_F4) * sizeof(float4);
+    const size_t lds = (size_t)2 * (RAW_LDS_F4 + V_F4) * sizeof(float4) + 16;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -473,6 +485,7 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     }
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
+    if (!persist) d.sched = nullptr;
     hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, d);
     return erd::check_launch("wino_conv3x3");
 }

@@ -230,8 +230,16 @@ STREAMK = _os.environ.get('ERD_STREAMK', '1') != '0'     # stream-K work decompo
 _SK_TILES = 1 << 16
 
 
+def _multi_rank() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def _attach_sk_ws(d: ConvDesc, device) -> None:
-    if not STREAMK:
+    # The stream-K grid is a STATIC split over 2 x #CU co-resident workgroups: when RCCL channels (or anything else)
+    # occupy CUs, late workgroups hold their tiles' fix-up back.  At one GPU it measures equal to tile-parallel launches
+    # end to end (the two compute streams already fill each other's ragged rounds), so data-parallel runs do without it.
+    if not STREAMK or _multi_rank():
         d.sk_ws, d.sk_ws_bytes = 0, 0
         return
     nbytes = int(_lib.load().erd_conv_igemm_ws_bytes(_SK_TILES))
@@ -313,6 +321,19 @@ def _wino_weights_cached(w: Tensor) -> Tensor:
     return hit[1]
 
 
+_WINO_SCHED = {}
+
+
+def _wino_sched(device) -> Tensor:
+    """two zero-initialised ints per stream: the item counter of the persistent Winograd grid (the kernel leaves them
+    zero, launches on one stream are ordered)"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _WINO_SCHED.get(key)
+    if t is None:
+        t = _WINO_SCHED[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return t
+
+
 def wino_ok(Cin: int, k: int, stride: int, pad: int) -> bool:
     return WINOGRAD and COMPUTE == "f32" and k == 3 and stride == 1 and pad == 1 and Cin % 16 == 0
 
@@ -332,7 +353,7 @@ def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: 
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * 9 * Cin
     nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U.numel()) if _TIMING is not None else 0.0
     _timed_call(kname, flop, "erd_wino_conv3x3", segs, len(xs), _p(U), Cin, Cout, _p(scale), _p(shift),
-                1 if relu else 0, _p(colsum), _stream(), nbytes=nbytes)
+                1 if relu else 0, _p(colsum), _p(_wino_sched(U.device)), _stream(), nbytes=nbytes)
 
 
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:

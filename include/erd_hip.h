@@ -101,7 +101,10 @@ int erd_wino_weights(const float* w_ohwi, float* U, int Cout, int Cin, int flip 
                      erd_stream_t stream);
 /* epilogue: v = acc*scale + shift (+ seg.res) ; ReLU ; zero where seg.mask <= 0 ; colsum[co] += v (atomic) */
 int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout, const float* scale,
-                     const float* shift, int relu, float* colsum, erd_stream_t stream);
+                     const float* shift, int relu, float* colsum,
+                     int* sched /* optional 2 ints, zero on entry (left zero): dynamic item scheduling of the
+                                   persistent grid; NULL = static split */,
+                     erd_stream_t stream);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
