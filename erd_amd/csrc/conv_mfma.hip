@@ -1027,9 +1027,10 @@ extern "C" int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, 
                                 erd_stream_t stream) {
     ERD_REQUIRE(part && dW && nsplit >= 1 && K % 4 == 0, "wgrad_reduce: bad args");
     ERD_REQUIRE(!rowdot || w, "wgrad_reduce: rowdot needs w");
-    if (rowdot) (void)hipMemsetAsync(rowdot, 0, sizeof(float) * Cout, (hipStream_t)stream);
+    // accumulate: bit 0 = add into dW, bit 1 = rowdot is already zero (comes from the caller's zero arena: no memset)
+    if (rowdot && !(accumulate & 2)) (void)hipMemsetAsync(rowdot, 0, sizeof(float) * Cout, (hipStream_t)stream);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, (K + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, part,
-                       nsplit, Cout, K, w, rowscale, dW, accumulate, rowdot);
+                       nsplit, Cout, K, w, rowscale, dW, accumulate & 1, rowdot);
     return erd::check_launch("wgrad_reduce");
 }
 

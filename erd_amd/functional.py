@@ -99,14 +99,15 @@ def _sunk(p: Tensor) -> None:
 
 
 def _emit_wgrad(w: Tensor, part: Tensor, S: int, wk: Tensor, scale: Optional[Tensor], rowdot: Optional[Tensor]):
-    """reduce the split-K partial slabs into the weight gradient: into the flat slot (returns None) or a new tensor"""
+    """reduce the split-K partial slabs into the weight gradient: into the flat slot (returns None) or a new tensor.
+    `rowdot` comes from K.zeros_f32 (already zero)."""
     sink = _sink(w)
     if sink is not None:
-        K.wgrad_reduce(part, S, wk, scale, ohwi(sink), True, rowdot)
+        K.wgrad_reduce(part, S, wk, scale, ohwi(sink), True, rowdot, rowdot_zeroed=True)
         _sunk(w)
         return None
     dWk = torch.empty_like(wk)
-    K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot)
+    K.wgrad_reduce(part, S, wk, scale, dWk, False, rowdot, rowdot_zeroed=True)
     return _to_oihw(dWk)
 
 
@@ -155,7 +156,7 @@ class ConvBNAct(Function):
         dW = dgamma = None
         fork = _Fork(x.device)
         if need_w or need_g:
-            rowdot = torch.empty_like(scale) if need_g else None
+            rowdot = K.zeros_f32(scale.numel(), scale.device) if need_g else None
             dgamma = torch.empty_like(scale) if need_g else None
             with fork:
                 part, S = K.conv_wgrad_partials([x], [dz], k, stride, pad)
@@ -235,7 +236,7 @@ class BottleneckFn(Function):
                 return
             wk = ohwi(w)
             part, S = K.conv_wgrad_partials([xin], [dz], k, s, pad)
-            rowdot = torch.empty_like(scale) if need[base + 1] else None
+            rowdot = K.zeros_f32(scale.numel(), scale.device) if need[base + 1] else None
             grads[5 * idx] = _emit_wgrad(w, part, S, wk, scale, rowdot)
             if need[base + 1]:
                 gs = _sink(g)

@@ -488,11 +488,12 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
 
 
 def wgrad_reduce(part: Tensor, S: int, w: Tensor, rowscale: Optional[Tensor], dW: Tensor, accumulate: bool,
-                 rowdot: Optional[Tensor]) -> None:
+                 rowdot: Optional[Tensor], rowdot_zeroed: bool = False) -> None:
+    """rowdot_zeroed: the caller took rowdot from the step's zero arena (zeros_f32): no memset launch"""
     Cout = w.shape[0]
     K = w.numel() // Cout
-    call("erd_wgrad_reduce", _p(part), S, Cout, K, _p(w), _p(rowscale), _p(dW), 1 if accumulate else 0,
-         _p(rowdot), _stream())
+    call("erd_wgrad_reduce", _p(part), S, Cout, K, _p(w), _p(rowscale), _p(dW),
+         (1 if accumulate else 0) | (2 if rowdot_zeroed else 0), _p(rowdot), _stream())
 
 
 # ---------------------------------------------------------------------------------------------

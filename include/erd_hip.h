@@ -135,7 +135,8 @@ int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream);
 
 /* dW (+)= rowscale[co] * sum_s part[s]; optional rowdot[co] = <W[co,:], sum_s part[s][co,:]>
  * (used for d gamma of a frozen-statistics BN: resnet.py:648-657 keeps BN in eval while
- * gamma/beta train). */
+ * gamma/beta train).  accumulate: bit 0 = add into dW instead of storing; bit 1 = rowdot already holds zeros
+ * (otherwise it is cleared here). */
 int erd_wgrad_reduce(const float* part, int nsplit, int Cout, int K, const float* w,
                      const float* rowscale, float* dW, int accumulate, float* rowdot,
                      erd_stream_t stream);
