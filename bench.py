@@ -230,6 +230,11 @@ def main():
                                "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                                "gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
                                "algorithmic_bytes_per_launch": int(dom["min_bytes"] / dom["launches"])}
+            if dom["kernel"].startswith("conv_wino"):
+                # `achieved` counts the direct-convolution flops of the launch (the algorithmic figure); Winograd
+                # F(2x2,3x3) executes 16/36 of those multiplications on the matrix cores
+                out["roofline"]["executed_flop_fraction"] = round(16 / 36, 4)
+                out["roofline"]["mfma_pipe_utilisation"] = round(out["roofline"]["frac"] * 16 / 36, 4)
             out["kernels"] = {k: {"ms_per_step": round(r["ms"] / rsteps, 3),
                                   "tflops": round(r["flop"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flop"] else None,
                                   "launches_per_step": r["launches"] // rsteps} for k, r in ktime.items()}
