@@ -126,21 +126,22 @@ __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restr
 
 // dz = dy * (y>0) (dz may alias dy); colsum[c] += sum over rows of dz.  rows are [npix][C] with an image
 // stride (level views of [N][A][C] buffers): row r -> img r / rows_per_img.
-// Thread (column group c4 = tid % C4w, row lane = tid / C4w) streams float4s down its column, 4 rows in flight;
-// the block combines its row lanes through LDS and issues ONE atomic per channel.
+// Block (x = row range, y = column group of C4w float4s): thread (column c4 = tid % C4w, row lane = tid / C4w) streams
+// float4s down its column, 4 rows in flight; the block combines its row lanes through LDS and issues ONE atomic per
+// channel.  Same-address float atomics retire at ~6 per microsecond, so the grid is cut into 64-channel column groups
+// x long row ranges (a few hundred adds per channel) rather than into many short full-width row ranges.
 __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __restrict__ y, const float* dy, float* dz,
                                                                int64_t npix, int C, int64_t nstride,
                                                                int64_t rows_per_img, float* __restrict__ colsum,
-                                                               int use_relu, int rows_per_block) {
+                                                               int use_relu, int rows_per_block, int C4w) {
     __shared__ float4 red[256];
-    const int C4 = C >> 2;
-    const int C4w = C4 < 256 ? C4 : 256;            // columns handled concurrently
     const int lanes = 256 / C4w;
     const int rl = threadIdx.x / C4w;
     const bool dense = nstride == rows_per_img * C;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = min(npix, r_begin + rows_per_block);
-    for (int c4 = threadIdx.x % C4w; c4 < C4; c4 += 256) {
+    {
+        const int c4 = blockIdx.y * C4w + threadIdx.x % C4w;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rl < lanes) {
             auto offset = [&](int64_t r) -> int64_t {
@@ -215,7 +216,7 @@ __global__ void bn_dgamma_kernel(const float* __restrict__ rowdot, const float* 
 // mean_rstd float [N][nseg][G][2].
 // ------------------------------------------------------------------------------------------------
 constexpr int GN_ROWS = 128;       // rows per block of the streaming (apply) kernels
-constexpr int GN_STAT_ROWS = 512;  // rows per block of the backward statistics kernel (fewer atomics per byte)
+constexpr int GN_STAT_ROWS = 512;  // rows per block of the statistics kernels (fewer atomics per byte)
 
 __device__ __forceinline__ int find_level(const erd_levels& lv, int64_t a) {
     int s = 0;
@@ -241,18 +242,32 @@ __device__ __forceinline__ void gn_chunk(const erd_levels& lv, const GnChunks& c
     r1 = min(lv.off[s] + lv.cnt[s], r0 + rows);
 }
 
+// Statistics kernels: grid (row chunks, N, 4 column groups).  A block owns 16 float4 columns (64 channels = 8 groups)
+// and 16 row lanes over a long row range: the same bytes in flight as a full-width block over a quarter of the rows,
+// but a quarter of the same-address atomics (those retire at ~6 per microsecond and were the limiter).
 template <int C, int G>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ c, double* __restrict__ stats,
                                                        int64_t A, erd_levels lv, GnChunks ch) {
-    constexpr int C4 = C / 4;          // 64 float4 columns
     constexpr int CPG = C / G;         // channels per group (8)
-    static_assert(CPG == 8 && C4 == 64, "tuned for C=256, G=32");
+    static_assert(CPG == 8 && C == 256, "tuned for C=256, G=32");
     const int n = blockIdx.y;
     int s; int64_t r0, r1;
-    gn_chunk(lv, ch, blockIdx.x, s, r0, r1, GN_ROWS);
-    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 4 row lanes
+    gn_chunk(lv, ch, blockIdx.x, s, r0, r1, GN_STAT_ROWS);
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;  // 16 columns x 16 row lanes
+    const int c4 = blockIdx.z * 16 + cl;
     float sum = 0.f, sq = 0.f;
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
+    int64_t r = r0 + rl;
+    for (; r + 48 < r1; r += 64) {
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(c + ((int64_t)n * A + r + 16 * q) * C + c4 * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sum += v[q].x + v[q].y + v[q].z + v[q].w;
+            sq += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+        }
+    }
+    for (; r < r1; r += 16) {
         const float4 v = *reinterpret_cast<const float4*>(c + ((int64_t)n * A + r) * C + c4 * 4);
         sum += v.x + v.y + v.z + v.w;
         sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -260,13 +275,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     // a group = 2 adjacent float4 columns -> combine lane pairs
     sum += __shfl_xor(sum, 1, 64);
     sq += __shfl_xor(sq, 1, 64);
-    __shared__ float red[4][32][2];
-    if ((c4 & 1) == 0) { red[rl][c4 >> 1][0] = sum; red[rl][c4 >> 1][1] = sq; }
+    __shared__ float red[16][8][2];
+    if ((cl & 1) == 0) { red[rl][cl >> 1][0] = sum; red[rl][cl >> 1][1] = sq; }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 16) {
         const int g = threadIdx.x >> 1, k = threadIdx.x & 1;
-        const double t = (double)red[0][g][k] + (double)red[1][g][k] + (double)red[2][g][k] + (double)red[3][g][k];
-        atomicAdd(stats + (((int64_t)n * lv.nseg + s) * G + g) * 2 + k, t);
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += (double)red[q][g][k];
+        atomicAdd(stats + (((int64_t)n * lv.nseg + s) * G + blockIdx.z * 8 + g) * 2 + k, t);
     }
 }
 
@@ -323,17 +340,14 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
     const int n = blockIdx.y;
     int s; int64_t r0, r1;
     gn_chunk(lv, ch, blockIdx.x, s, r0, r1, GN_STAT_ROWS);
-    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;  // 16 columns x 16 row lanes (see gn_stats_kernel)
+    const int c4 = blockIdx.z * 16 + cl;
     const int g = c4 >> 1;
     const float2 mr = *reinterpret_cast<const float2*>(mean_rstd + (((int64_t)n * lv.nseg + s) * G + g) * 2);
     const float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
     const float4 be = reinterpret_cast<const float4*>(beta)[c4];
     float s1 = 0.f, s2 = 0.f;
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
-        const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
-        const float4 v = *reinterpret_cast<const float4*>(c + off);
-        const float4 d = *reinterpret_cast<const float4*>(dy + off);
 #define GN_ONE(F)                                                          \
         {                                                                  \
             const float xh = (v.F - mr.x) * mr.y;                          \
@@ -344,33 +358,48 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
             s1 += dh;                                                      \
             s2 += dh * xh;                                                 \
         }
-        GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w)
-#undef GN_ONE
+    int64_t r = r0 + rl;
+    for (; r + 16 < r1; r += 32) {          // two rows in flight per thread
+        const int64_t off0 = ((int64_t)n * A + r) * C + c4 * 4, off1 = off0 + (int64_t)16 * C;
+        const float4 v0 = *reinterpret_cast<const float4*>(c + off0), d0 = *reinterpret_cast<const float4*>(dy + off0);
+        const float4 v1 = *reinterpret_cast<const float4*>(c + off1), d1 = *reinterpret_cast<const float4*>(dy + off1);
+        { const float4 v = v0, d = d0; GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w) }
+        { const float4 v = v1, d = d1; GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w) }
     }
+    for (; r < r1; r += 16) {
+        const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
+        const float4 v = *reinterpret_cast<const float4*>(c + off);
+        const float4 d = *reinterpret_cast<const float4*>(dy + off);
+        GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w)
+    }
+#undef GN_ONE
     s1 += __shfl_xor(s1, 1, 64);
     s2 += __shfl_xor(s2, 1, 64);
-    __shared__ float red[4][32][2];
-    __shared__ float4 redc[4][64][2];
-    if ((c4 & 1) == 0) { red[rl][g][0] = s1; red[rl][g][1] = s2; }
-    redc[rl][c4][0] = dg;
-    redc[rl][c4][1] = db;
+    __shared__ float red[16][8][2];
+    __shared__ float4 redc[16][16][2];
+    if ((cl & 1) == 0) { red[rl][cl >> 1][0] = s1; red[rl][cl >> 1][1] = s2; }
+    redc[rl][cl][0] = dg;
+    redc[rl][cl][1] = db;
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 16) {
         const int gg = threadIdx.x >> 1, k = threadIdx.x & 1;
-        const double t = (double)red[0][gg][k] + (double)red[1][gg][k] + (double)red[2][gg][k] + (double)red[3][gg][k];
-        atomicAdd(stats + (((int64_t)n * lv.nseg + s) * G + gg) * 2 + k, t);
-    } else if (threadIdx.x < 128) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += (double)red[q][gg][k];
+        atomicAdd(stats + (((int64_t)n * lv.nseg + s) * G + blockIdx.z * 8 + gg) * 2 + k, t);
+    } else if (threadIdx.x >= 64 && threadIdx.x < 80) {
         const int cc = threadIdx.x - 64;
         float4 a = redc[0][cc][0], b = redc[0][cc][1];
 #pragma unroll
-        for (int q = 1; q < 4; ++q) {
+        for (int q = 1; q < 16; ++q) {
             a.x += redc[q][cc][0].x; a.y += redc[q][cc][0].y; a.z += redc[q][cc][0].z; a.w += redc[q][cc][0].w;
             b.x += redc[q][cc][1].x; b.y += redc[q][cc][1].y; b.z += redc[q][cc][1].z; b.w += redc[q][cc][1].w;
         }
-        atomicAdd(dgamma + cc * 4 + 0, a.x); atomicAdd(dgamma + cc * 4 + 1, a.y);
-        atomicAdd(dgamma + cc * 4 + 2, a.z); atomicAdd(dgamma + cc * 4 + 3, a.w);
-        atomicAdd(dbeta + cc * 4 + 0, b.x); atomicAdd(dbeta + cc * 4 + 1, b.y);
-        atomicAdd(dbeta + cc * 4 + 2, b.z); atomicAdd(dbeta + cc * 4 + 3, b.w);
+        const int ch0 = (blockIdx.z * 16 + cc) * 4;
+        atomicAdd(dgamma + ch0 + 0, a.x); atomicAdd(dgamma + ch0 + 1, a.y);
+        atomicAdd(dgamma + ch0 + 2, a.z); atomicAdd(dgamma + ch0 + 3, a.w);
+        atomicAdd(dbeta + ch0 + 0, b.x); atomicAdd(dbeta + ch0 + 1, b.y);
+        atomicAdd(dbeta + ch0 + 2, b.z); atomicAdd(dbeta + ch0 + 3, b.w);
     }
 }
 
@@ -705,11 +734,16 @@ extern "C" int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, i
                                    erd_stream_t stream) {
     ERD_REQUIRE(dy && C % 4 == 0 && (!use_relu || (y && dz)), "relu_bwd: bad args");
     if (npix == 0) return 0;
-    ERD_REQUIRE((C / 4) <= 256 ? (256 % (C / 4) == 0) : ((C / 4) % 256 == 0), "relu_bwd: C=%d unsupported", C);
-    int rpb = 128;
-    while ((npix + rpb - 1) / rpb > 2048) rpb *= 2;
-    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((unsigned)((npix + rpb - 1) / rpb)), dim3(256), 0,
-                       (hipStream_t)stream, y, dy, dz, npix, C, nstride_rows, rows_per_img, colsum, use_relu, rpb);
+    const int C4 = C / 4;
+    ERD_REQUIRE(C4 % 16 == 0 || 256 % C4 == 0, "relu_bwd: C=%d unsupported", C);
+    const int cw4 = C4 % 16 == 0 ? 16 : C4, gy = C4 / cw4, lanes = 256 / cw4;
+    static const int blocks_env = getenv("ERD_RELU_BLOCKS") ? atoi(getenv("ERD_RELU_BLOCKS")) : 0;   // tuning aid
+    const int want = blocks_env > 0 ? blocks_env : 512;
+    const int unit = 4 * lanes;                                     // rows one pass of the unrolled loop covers
+    int64_t rpb = (npix + (want / gy > 0 ? want / gy : 1) - 1) / (want / gy > 0 ? want / gy : 1);
+    rpb = (rpb + unit - 1) / unit * unit;
+    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((unsigned)((npix + rpb - 1) / rpb), gy), dim3(256), 0,
+                       (hipStream_t)stream, y, dy, dz, npix, C, nstride_rows, rows_per_img, colsum, use_relu, (int)rpb, cw4);
     return erd::check_launch("relu_bwd_colsum");
 }
 
@@ -728,10 +762,10 @@ extern "C" int erd_gn_relu_fwd(const float* c, float* y, const float* gamma, con
     ERD_REQUIRE(C == 256 && G == 32, "gn_fwd: only C=256,G=32 (gfl_head.py:109-110) is built");
     hipStream_t st = (hipStream_t)stream;
     const GnChunks ch = make_chunks(lv);
-    const GnChunks chs = ch;   // (512-row chunks measured 2.8x slower here: too few blocks per level)
+    const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
-    hipLaunchKernelGGL((gn_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N), dim3(256), 0, st, c, stats_ws, A, *lv, chs);
+    hipLaunchKernelGGL((gn_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st, c, stats_ws, A, *lv, chs);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nst + 255) / 256), dim3(256), 0, st, stats_ws, mean_rstd, N, G, *lv,
                        C / G, eps);
     hipLaunchKernelGGL((gn_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, y, gamma, beta,
@@ -749,7 +783,7 @@ extern "C" int erd_gn_relu_bwd(const float* c, const float* dy, const float* gam
     const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
-    hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st, c, dy, gamma,
                        beta, mean_rstd, stats_ws, dgamma, dbeta, A, *lv, chs);
     hipLaunchKernelGGL((gn_bwd_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
                        beta, mean_rstd, stats_ws, dc, A, *lv, ch);

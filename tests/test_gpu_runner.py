@@ -85,7 +85,9 @@ def test_base_training_then_incremental_stage_then_resume(tmp_path):
     assert torch.equal(r2.model.state_dict()["bbox_head.gfl_reg.weight"].cpu(), r4.model.state_dict()["bbox_head.gfl_reg.weight"].cpu())
 
 
-def test_train_py_cli_smoke(tmp_path):
+@pytest.mark.parametrize("amp", [False, True])
+def test_train_py_cli_smoke(tmp_path, amp):
+    """--amp = the bf16 matrix-core mode (the reference's flag switches to AmpOptimWrapper, tools/train.py:82-92)"""
     import subprocess, sys
     teacher = tmp_path / "teacher.pth"
     from oracle import erd_oracle as O
@@ -94,6 +96,8 @@ def test_train_py_cli_smoke(tmp_path):
            "--synthetic", "2", "--image-size", "123", "153", "--max-iters", "2", "--cfg-options",
            "train_dataloader.batch_size=2", f"model.ori_setting.ori_checkpoint_file={teacher}",
            f"model.ori_setting.ori_config_file={CFG_FIRST}", "default_hooks.logger.interval=1"]
+    if amp:
+        cmd.insert(3, "--amp")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Epoch(train) [1][2/2]" in out.stdout and "loss_dist_bbox" in out.stdout

@@ -8,7 +8,8 @@
 Same flags as the reference's tools/train.py:15-129 (--work-dir, --amp, --auto-scale-lr, --resume, --cfg-options,
 --launcher).  With the config's COCO annotation file present the real pipeline runs (CocoAnnotations + shuffled,
 rank-sharded aspect-ratio batches + the GPU resize/flip/normalise kernel); otherwise, or with `--synthetic ITERS`,
-batches shaped like the reference's demo_mm_inputs.  `--amp` is refused (the path computes in fp32).
+batches shaped like the reference's demo_mm_inputs.  `--amp` selects the bf16 matrix-core mode (`kernels.set_compute("bf16")`:
+bf16 multiplicands, fp32 accumulation and storage -- no loss scaling needed, unlike the reference's fp16 autocast).
 """
 import argparse
 import ast
@@ -45,14 +46,14 @@ def main(argv=None):
     ap.add_argument("--max-iters", type=int, default=None)
     ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
     args = ap.parse_args(argv)
-    if args.amp:
-        raise SystemExit("--amp: the MI355X path computes in fp32 (bf16 is not built)")
-
     import torch
     import torch.distributed as dist
     from erd_amd import Config
     from erd_amd.runner import Runner, SyntheticDetData
 
+    if args.amp:        # the reference switches its OptimWrapper to AmpOptimWrapper (tools/train.py:82-92)
+        from erd_amd import kernels as K
+        K.set_compute("bf16")
     cfg = Config.fromfile(args.config)
     cfg.merge_from_dict(parse_cfg_options(args.cfg_options))
     cfg.work_dir = args.work_dir or cfg.get("work_dir") or os.path.join(
