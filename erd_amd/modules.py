@@ -614,8 +614,7 @@ class GFLHead(nn.Module):
         t.c_old, t.distill, t.lw_ld, t.T, t.dist_loss_weight = 0, False, 0.0, 1.0, 0.0
         v = self._loss_vector(s_cls, s_bbox, t)
         L = len(sizes)
-        return dict(loss_cls=list(v[0:L].unbind(0)), loss_bbox=list(v[L:2 * L].unbind(0)),
-                    loss_dfl=list(v[2 * L:3 * L].unbind(0)))
+        return LossDict(v[:3 * L], dict(loss_cls=(0, L), loss_bbox=(L, 2 * L), loss_dfl=(2 * L, 3 * L)))
 
 
 @MODELS.register_module()
@@ -645,9 +644,8 @@ class GFLHeadIncrementERD(GFLHead):
         t.lw_ld, t.T, t.dist_loss_weight = self.loss_ld.loss_weight, float(self.loss_ld.T), float(dist_loss_weight)
         v = self._loss_vector(s_cls, s_bbox, t)
         L, N = len(sizes), s_cls.shape[0]
-        return dict(loss_cls=list(v[0:L].unbind(0)), loss_bbox=list(v[L:2 * L].unbind(0)),
-                    loss_dfl=list(v[2 * L:3 * L].unbind(0)), loss_dist_cls=list(v[3 * L:3 * L + N].unbind(0)),
-                    loss_dist_bbox=list(v[3 * L + N:].unbind(0)))
+        return LossDict(v, dict(loss_cls=(0, L), loss_bbox=(L, 2 * L), loss_dfl=(2 * L, 3 * L),
+                                loss_dist_cls=(3 * L, 3 * L + N), loss_dist_bbox=(3 * L + N, 3 * L + 2 * N)))
 
     def loss(self, ori_outs, new_outs, batch_data_samples, topk_cls_inds, topk_cls_scores, topk_bbox_inds,
              topk_bbox_preds, ori_num_classes, dist_loss_weight, model) -> dict:
@@ -897,9 +895,30 @@ class TeacherOut:
         return out
 
 
+class LossDict(dict):
+    """The reference's loss dict (name -> list of 0-dim tensors), built from the ONE vector the loss kernels emit.
+    `parse_losses` recognises it and sums the vector directly: a handful of launches instead of ~110 (a mean per
+    entry, Python `sum` chains and their select/add backward nodes)."""
+
+    def __init__(self, vector: Tensor, slices: Dict[str, Tuple[int, int]]):
+        super().__init__({k: list(vector[a:b].unbind(0)) for k, (a, b) in slices.items()})
+        self.vector, self.slices = vector, dict(slices)
+
+    def intact(self) -> bool:
+        return list(self.keys()) == list(self.slices.keys()) and all(
+            isinstance(v, list) and len(v) == b - a for v, (a, b) in zip(self.values(), self.slices.values()))
+
+
 def parse_losses(losses: Dict[str, Union[Tensor, List[Tensor]]]) -> Tuple[Tensor, Dict[str, Tensor]]:
     """mmengine BaseModel.parse_losses (D9): tensor -> mean, list -> sum of means; total over keys with 'loss'."""
     log_vars = OrderedDict()
+    if isinstance(losses, LossDict) and losses.intact() and all("loss" in k for k in losses.slices):
+        d = losses.vector.detach()
+        for name, (a, b) in losses.slices.items():
+            log_vars[name] = d[a:b].sum()
+        total = losses.vector.sum()
+        log_vars["loss"] = total
+        return total, log_vars
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
             log_vars[name] = value.mean()
