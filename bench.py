@@ -34,42 +34,39 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_gpu_batch(bs: int, seed: int, device, num_new: int = 40):
+def synthetic_gpu_batch(bs: int, seed: int, device, cfg, num_new: int = 40):
     """post-preprocess batch of the reference's demo_mm_inputs shape (mmdet/testing/_utils.py:89-202):
-    uint8 pixels -> (x-mean)/std -> zero pad to /32, 1..9 random boxes, labels in [0, C_new)."""
-    from oracle import erd_oracle as O
+    uint8 pixels -> BGR->RGB -> (x-mean)/std -> zero pad to /32, 1..9 random boxes, labels in [0, C_new)."""
     from erd_amd import DetDataSample, InstanceData
-    rng = np.random.RandomState(seed)
+    from erd_amd.synthetic import demo_batch
+    dp = cfg.model.data_preprocessor
     Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
-    mean = torch.tensor(O.PIXEL_MEAN, device=device).view(1, 3, 1, 1)
-    std = torch.tensor(O.PIXEL_STD, device=device).view(1, 3, 1, 1)
+    mean = torch.tensor(list(dp.mean), device=device).view(3, 1, 1)
+    std = torch.tensor(list(dp.std), device=device).view(3, 1, 1)
     x = torch.zeros((bs, 3, Hp, Wp), device=device)
     samples = []
+    imgs, boxes, labels = demo_batch(bs, H, W, num_new, seed)
     for i in range(bs):
-        img = torch.from_numpy(rng.randint(0, 255, size=(3, H, W), dtype=np.uint8)).to(device)
-        x[i, :, :H, :W] = (img[[2, 1, 0]].float() - mean[0]) / std[0]
-        nb = rng.randint(1, 10)
-        boxes = torch.from_numpy(O.rand_bboxes(rng, nb, W, H).astype(np.float32)).to(device)
-        labels = torch.from_numpy(rng.randint(0, num_new, size=nb).astype(np.int64)).to(device)
+        x[i, :, :H, :W] = (imgs[i].to(device)[[2, 1, 0]].float() - mean) / std
         ds = DetDataSample(metainfo=dict(img_shape=(H, W), pad_shape=(Hp, Wp), batch_input_shape=(Hp, Wp)))
-        ds.gt_instances = InstanceData(bboxes=boxes, labels=labels)
+        ds.gt_instances = InstanceData(bboxes=boxes[i].to(device), labels=labels[i].to(device))
         samples.append(ds)
     return x, samples
 
 
 def build_model(device, rank: int):
     """through the reference's own boundary: config files + MODELS.build + teacher checkpoint on disk
-    (gfl_increment_erd.py:95-122).  Weights are procedural (no network for checkpoints)."""
-    from oracle import erd_oracle as O          # synthetic-weight spec only
+    (gfl_increment_erd.py:95-122).  Weights are procedural (erd_amd/synthetic.py; no network for checkpoints)."""
     from erd_amd import Config, MODELS
-    cfg = Config.fromfile(os.path.join(ROOT, "configs", "gfl_increment",
-                                       "gfl_r50_fpn_1x_coco_first_40_incre_last_40_cats.py"))
-    tsd = O.procedural_state_dict(40, seed=0)
+    from erd_amd.synthetic import procedural_state_dict, state_shapes
+    cdir = os.path.join(ROOT, "configs", "gfl_increment")
+    cfg = Config.fromfile(os.path.join(cdir, "gfl_r50_fpn_1x_coco_first_40_incre_last_40_cats.py"))
+    tcfg_file = os.path.join(cdir, "gfl_r50_fpn_1x_coco_first_40_cats.py")
+    tsd = procedural_state_dict(state_shapes(MODELS.build(Config.fromfile(tcfg_file).model)), seed=0)
     ckpt = os.path.join(tempfile.gettempdir(), f"erd_teacher_first40_rank{rank}.pth")
     torch.save(dict(state_dict=tsd), ckpt)
     cfg.model.ori_setting.ori_checkpoint_file = ckpt
-    cfg.model.ori_setting.ori_config_file = os.path.join(ROOT, "configs", "gfl_increment",
-                                                         "gfl_r50_fpn_1x_coco_first_40_cats.py")
+    cfg.model.ori_setting.ori_config_file = tcfg_file
     torch.manual_seed(1234)                      # the student's fresh new-class rows: same on every rank
     model = MODELS.build(cfg.model)
     os.remove(ckpt)
@@ -154,7 +151,7 @@ def main():
     trainer = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
                          base_batch_size=cfg.auto_scale_lr.base_batch_size, batch_size_per_gpu=args.batch,
                          auto_scale_lr=cfg.auto_scale_lr.enable, teacher_graph=args.teacher_graph)
-    batches = [synthetic_gpu_batch(args.batch, seed=rank * 1000 + i, device=device) for i in range(2)]
+    batches = [synthetic_gpu_batch(args.batch, seed=rank * 1000 + i, device=device, cfg=cfg) for i in range(2)]
 
     def set_serial(flag: bool):
         """serial = one HIP stream, kernels back to back: per-launch durations are then well defined"""
@@ -199,7 +196,7 @@ def main():
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss = float(log["loss"]) if log is not None else float("nan")
+    loss = float(log["loss"].detach()) if log is not None else float("nan")
 
     if rank == 0:
         images = args.batch * world * args.steps

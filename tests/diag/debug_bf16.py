@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """stage-by-stage comparison of the bf16 matrix-core mode against the oracle's bf16-multiplicand mode"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from oracle import erd_oracle as O

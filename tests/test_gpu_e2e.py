@@ -242,7 +242,7 @@ def test_bf16_matrix_core_mode_vs_oracle_bf16_multiplicands():
     mode.  A single convolution agrees to 2e-5 (test_gpu_kernels.py: exact products, only the summation order
     differs); through ~60 layers the two sides round activations that differ by 1e-7 to DIFFERENT bf16 neighbours now
     and then, each such flip is a 0.4 % perturbation that makes further flips likelier, and the difference settles at
-    the bf16 quantisation-noise floor (tools/debug_bf16.py: 2e-4 after layer1, 5e-3 from C4 on; 3e-7 in fp32 mode).
+    the bf16 quantisation-noise floor (tests/diag/debug_bf16.py: 2e-4 after layer1, 5e-3 from C4 on; 3e-7 in fp32 mode).
     Whole-network quantities therefore agree at bf16 resolution, not fp32: logits 0.1 abs (observed 0.03), losses
     2e-2 rel (distillation terms 1e-1), ERS index sets >= 75 % overlap.  Gradients at this tiny image size sit on a
     high noise floor in ANY bf16-multiplicand implementation: the oracle's own bf16-mode gradients move by 0.20 (median
