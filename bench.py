@@ -34,11 +34,14 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_gpu_batch(bs: int, seed: int, device, cfg, num_new: int = 40):
+def synthetic_gpu_batch(bs: int, seed: int, device, cfg=None, num_new: int = 40):
     """post-preprocess batch of the reference's demo_mm_inputs shape (mmdet/testing/_utils.py:89-202):
     uint8 pixels -> BGR->RGB -> (x-mean)/std -> zero pad to /32, 1..9 random boxes, labels in [0, C_new)."""
     from erd_amd import DetDataSample, InstanceData
     from erd_amd.synthetic import demo_batch
+    if cfg is None:
+        from erd_amd import Config
+        cfg = Config.fromfile(os.path.join(ROOT, "configs", "gfl_increment", "gfl_r50_fpn_1x_coco_first_40_cats.py"))
     dp = cfg.model.data_preprocessor
     Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
     mean = torch.tensor(list(dp.mean), device=device).view(3, 1, 1)

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liberd_hip.so")
+LIB_PATH = os.environ.get("ERD_HIP_LIB") or os.path.join(_HERE, "lib", "liberd_hip.so")   # override: A/B builds
 
 ERD_MAX_SEG = 5
 ERD_MAX_TAPS = 9
