@@ -176,6 +176,44 @@ def load_image_bgr(path: str) -> np.ndarray:
         return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
 
 
+def prefetch_map(fn, items: Sequence, workers: int, depth: int):
+    """yield fn(item) for every item IN ORDER while up to `depth` later items are already being computed on `workers`
+    threads (the DataLoader's num_workers / prefetch_factor, as threads: image decoding releases the GIL).  workers <= 0:
+    plain serial map.  An exception in fn surfaces at the position of its item."""
+    if workers <= 0:
+        for it in items:
+            yield fn(it)
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="erd-decode") as pool:
+        pending = deque()
+        it = iter(items)
+        try:
+            for _ in range(max(1, depth)):
+                pending.append(pool.submit(fn, next(it)))
+        except StopIteration:
+            pass
+        while pending:
+            head = pending.popleft()
+            try:
+                pending.append(pool.submit(fn, next(it)))
+            except StopIteration:
+                pass
+            try:
+                yield head.result()
+            except BaseException:
+                for f in pending:
+                    f.cancel()
+                raise
+
+
+def pinned(im: np.ndarray):
+    """page-locked copy of a decoded image when a GPU is present (so that the H2D copy is asynchronous)"""
+    t = torch.from_numpy(im)
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
 class GpuDetPipeline:
     """one training batch from image indices: decoded images -> normalised, padded [N,3,H,W] fp32 on the GPU + data
     samples with resized / flipped / clipped boxes.  Deterministic given `seed` (flip decisions per (epoch, index))."""
@@ -202,9 +240,16 @@ class GpuDetPipeline:
             self._tables[key] = tuple(torch.from_numpy(a).to(self.device) for a in (xo, xc, yo, yc))
         return self._tables[key]
 
+    def decode(self, indices: Sequence[int]) -> List[np.ndarray]:
+        """host half of a batch (LoadImageFromFile): safe to run on worker threads, PIL releases the GIL while decoding"""
+        return [self.loader(self.ann.get_data_info(i)["img_path"]) for i in indices]
+
     def batch(self, indices: Sequence[int]):
+        return self.assemble(indices, self.decode(indices))
+
+    def assemble(self, indices: Sequence[int], imgs: Sequence[np.ndarray]):
+        """device half: resize / flip / normalise / pad kernels + the data samples"""
         from . import kernels as K
-        imgs = [self.loader(self.ann.get_data_info(i)["img_path"]) for i in indices]
         new = [rescale_size((im.shape[1], im.shape[0]), self.scale) for im in imgs]          # (w, h)
         H = max(int(math.ceil(h / self.div)) * self.div for _, h in new)
         W = max(int(math.ceil(w / self.div)) * self.div for w, _ in new)
@@ -213,7 +258,7 @@ class GpuDetPipeline:
         for k, (i, im, (nw, nh)) in enumerate(zip(indices, imgs, new)):
             rng = np.random.RandomState((self.seed * 1000003 + self.epoch * 7919 + int(i)) % (2 ** 31 - 1))
             flip = bool(rng.rand() < self.flip_prob)
-            src = torch.from_numpy(im).to(self.device, non_blocking=True)
+            src = (im if isinstance(im, torch.Tensor) else torch.from_numpy(im)).to(self.device, non_blocking=True)
             K.resize_normalize_into(src, self._table(im.shape[0], im.shape[1], nh, nw), (nh, nw), out[k], self.mean, self.std,
                                     flip, self.swap, self.pad_value)
             s = self.ann.data_sample(i, scale_factor=(nw / im.shape[1], nh / im.shape[0]), flip=flip, img_shape=(nh, nw),

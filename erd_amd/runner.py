@@ -146,8 +146,11 @@ class CocoTrainData:
     and the GPU image pipeline.  Batches arrive normalised and padded (`preprocessed=True`)."""
 
     def __init__(self, dataset_cfg: dict, batch_size: int, classes=None, scale=(1333, 800), seed: int = 0, rank: int = 0,
-                 world: int = 1, device="cuda"):
+                 world: int = 1, device="cuda", num_workers: int = 0, prefetch_factor: int = 2):
+        """num_workers / prefetch_factor: `train_dataloader.num_workers` decoding threads working `prefetch_factor`
+        batches ahead of the training step (0 = decode in the training thread)"""
         from .datasets import AspectRatioBatchSampler, CocoAnnotations, GpuDetPipeline
+        self.num_workers, self.prefetch_factor = int(num_workers), int(prefetch_factor)
         root = dataset_cfg.get("data_root", "")
         classes = classes or (dataset_cfg.get("metainfo") or {}).get("classes")     # None: every category of the file
         fc = dataset_cfg.get("filter_cfg") or {}
@@ -174,8 +177,11 @@ class CocoTrainData:
         return -(-len(self._indices()) // self.bs)
 
     def __iter__(self):
-        for idx in self._sampler_cls(self._indices(), self.ann, self.bs):
-            x, samples = self.pipe.batch(idx)
+        from .datasets import pinned, prefetch_map
+        batches = list(self._sampler_cls(self._indices(), self.ann, self.bs))
+        decode = lambda idx: (idx, [pinned(im) for im in self.pipe.decode(idx)])
+        for idx, imgs in prefetch_map(decode, batches, self.num_workers, self.prefetch_factor):
+            x, samples = self.pipe.assemble(idx, imgs)
             yield dict(inputs=x, data_samples=samples, preprocessed=True)
 
 

@@ -153,3 +153,36 @@ def test_cv2_style_resize_restatement_known_answers():
     out, sf = I.resize_flip(img, (133, 80), flip=True)
     assert out.shape == (80, 115, 3) and sf == (115 / 53, 80 / 37)
     assert np.array_equal(out, I.resize_linear_u8(img, 115, 80)[:, ::-1])
+
+
+def test_prefetch_map_order_lookahead_and_errors():
+    """the decoding thread pool: results in item order, at most `depth` items ahead, exceptions at their item"""
+    import threading
+    import time
+    from erd_amd.datasets import prefetch_map
+    started, lock = [], threading.Lock()
+
+    def work(i):
+        with lock:
+            started.append(i)
+        time.sleep(0.02 * ((7 - i) % 3))          # later items may finish first
+        if i == 5:
+            raise ValueError("bad image 5")
+        return i * i
+
+    assert list(prefetch_map(work, range(5), workers=0, depth=2)) == [0, 1, 4, 9, 16]
+    started.clear()
+    got = []
+    gen = prefetch_map(work, range(8), workers=3, depth=2)
+    for v in gen:
+        got.append(v)
+        with lock:
+            assert max(started) <= len(got) + 2          # never more than `depth` items beyond the consumer
+        if len(got) == 5:
+            break
+    gen.close()
+    assert got == [0, 1, 4, 9, 16]
+    import pytest
+    with pytest.raises(ValueError, match="bad image 5"):
+        list(prefetch_map(work, range(8), workers=2, depth=3))
+    assert list(prefetch_map(work, [], workers=2, depth=2)) == []

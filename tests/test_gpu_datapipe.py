@@ -140,3 +140,21 @@ def test_test_py_evaluates_a_checkpoint(tmp_path):
         im = next(i for i in ds["images"] if i["id"] == r["image_id"])
         assert r["bbox"][0] >= -1e-3 and r["bbox"][0] + r["bbox"][2] <= im["width"] + 1e-2
         assert 10 <= r["category_id"] < 90
+
+
+def test_threaded_decode_prefetch_gives_the_same_batches(tmp_path):
+    """train_dataloader.num_workers decoding threads (pinned staging, two batches ahead) == in-thread decoding, bit for
+    bit, in the same order"""
+    from erd_amd.runner import CocoTrainData
+    _make_dataset(tmp_path, [(48, 64), (60, 45), (33, 80), (50, 70), (64, 48), (40, 90), (70, 52)])
+    dcfg = dict(data_root=str(tmp_path), ann_file="ann.json", data_prefix=dict(img=""), metainfo=dict(classes=("a", "b")),
+                filter_cfg=dict(filter_empty_gt=True, min_size=0))
+    runs = []
+    for workers in (0, 3):
+        data = CocoTrainData(dcfg, batch_size=2, scale=(133, 80), seed=5, num_workers=workers, prefetch_factor=2)
+        data.set_epoch(1)
+        runs.append([(b["inputs"].cpu(), [s.gt_instances.bboxes.cpu() for s in b["data_samples"]],
+                      [s.metainfo["img_id"] for s in b["data_samples"]]) for b in data])
+    assert len(runs[0]) == len(runs[1]) == 4
+    for (xa, ba, ia), (xb, bb, ib) in zip(*runs):
+        assert ia == ib and torch.equal(xa, xb) and all(torch.equal(p, q) for p, q in zip(ba, bb))

@@ -82,7 +82,8 @@ def main(argv=None):
         from erd_amd.runner import CocoTrainData
         scale = next((t["scale"] for t in dcfg.get("pipeline", []) if t.get("type") == "Resize"), (1333, 800))
         world = dist.get_world_size() if dist.is_initialized() else 1
-        data = CocoTrainData(dcfg, int(cfg.train_dataloader.batch_size), scale=tuple(scale), seed=0, rank=rank, world=world)
+        data = CocoTrainData(dcfg, int(cfg.train_dataloader.batch_size), scale=tuple(scale), seed=0, rank=rank, world=world,
+                             num_workers=int(cfg.train_dataloader.get("num_workers", 0)))
     else:
         data = SyntheticDetData(int(cfg.train_dataloader.batch_size), num_new, args.synthetic or 50, tuple(args.image_size),
                                 seed=rank)
