@@ -59,9 +59,11 @@ def main(argv=None):
     ev = CocoBBoxEval(gt, cat_ids=ann.cat_ids)
     n = len(ann) if a.max_images is None else min(len(ann), a.max_images)
     results = []
-    for b0 in range(0, n, a.batch_size):
-        idx = list(range(b0, min(n, b0 + a.batch_size)))
-        x, samples = pipe.batch(idx)
+    from erd_amd.datasets import pinned, prefetch_map
+    batches = [list(range(b0, min(n, b0 + a.batch_size))) for b0 in range(0, n, a.batch_size)]
+    decode = lambda idx: (idx, [pinned(im) for im in pipe.decode(idx)])
+    for idx, imgs in prefetch_map(decode, batches, int(cfg.test_dataloader.get("num_workers", 0)), 2):
+        x, samples = pipe.assemble(idx, imgs)
         out = model(x, samples, mode="predict")
         for i, d in zip(idx, out):
             p = d.pred_instances
