@@ -257,11 +257,39 @@ def gen_f8(ref):
     np.savez_compressed(os.path.join(OUT, "f8_predict_unpinned_nms.npz"), **out)
 
 
+def gen_f10(ref):
+    """head-level losses + gradients with EMPTY ground truth (one image / every image) through the reference's
+    GFLHeadIncrementERD.loss: pins the `num_pos == 0` branches (gfl_head_increment_erd.py:293-297), the clamp of both
+    normalisers to >= 1 (:379-398) and the assigner's no-GT path (atss_assigner.py:120-134)."""
+    out = {}
+    for case in (0, 1):
+        sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas = G.f10_inputs(case)
+        teacher, student = ref_stub.build_reference_erd()
+        ref_stub.attach_teacher(student, teacher, 40)
+        s_cls = [t.clone().requires_grad_(True) for t in s_cls]
+        s_bbox = [t.clone().requires_grad_(True) for t in s_bbox]
+        ic, sc, ib, sb = student.sel_pos(t_cls, t_bbox)
+        losses = student.bbox_head.loss((t_cls, t_bbox), (s_cls, s_bbox), _samples(ref, gtb, gtl, metas),
+                                        ic, sc, ib, sb, 40, 1, student)
+        total = O.parse_losses(losses)
+        total.backward()
+        for k, vs in losses.items():
+            out[f"c{case}_{k}"] = np.array([float(v) for v in vs], dtype=np.float32)
+        out[f"c{case}_total"] = np.array(float(total))
+        for l in range(5):
+            out[f"c{case}_g_cls{l}"] = npy(s_cls[l].grad)
+            out[f"c{case}_g_bbox{l}"] = npy(s_bbox[l].grad)
+    np.savez_compressed(os.path.join(OUT, "f10_head_empty_gt.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_stub.load_reference()
-    for fn in (gen_f1, gen_f2, gen_f3, gen_f4, gen_f5, gen_f6, gen_f7, gen_f8, gen_f9):
+    only = set(sys.argv[1:])                 # e.g. `python oracle/gen_golden.py gen_f10`
+    for fn in (gen_f1, gen_f2, gen_f3, gen_f4, gen_f5, gen_f6, gen_f7, gen_f8, gen_f9, gen_f10):
+        if only and fn.__name__ not in only:
+            continue
         fn(ref)
         print("wrote", fn.__name__)
 

@@ -109,6 +109,16 @@ def f6_inputs(N=2, H=256, W=256, c_old=40, c_all=80):
     return sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas
 
 
+def f10_inputs(case):
+    """F6's pyramids with empty ground truth: case 0 = image 0 has no boxes, case 1 = no image has any (no positive
+    anchor in the whole batch: every supervised box / DFL term takes the reference's `pred.sum() * 0` branch)."""
+    sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas = f6_inputs()
+    empty_b, empty_l = torch.zeros((0, 4)), torch.zeros((0,), dtype=torch.long)
+    gtb = [empty_b, gtb[1]] if case == 0 else [empty_b, empty_b.clone()]
+    gtl = [empty_l, gtl[1]] if case == 0 else [empty_l, empty_l.clone()]
+    return sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas
+
+
 # ---- F8: inference post-processing ---------------------------------------------------------------------
 def f8_inputs(case):
     """case 0: 2 images, 256x256 pyramid, 80 classes, ~half of the scores above 0.05 (top-k cut on levels 0-2),

@@ -210,3 +210,38 @@ def test_ers_channel_count_not_multiple_of_4(K, C):
         ic, ib, _, _ = O.ers_select_single(cls[n], bbox[n])
         kc, kb = [int(v) for v in r["counts"][n].cpu()]
         assert torch.equal(r["idx_cls"][n, :kc].cpu(), ic) and torch.equal(r["idx_bbox"][n, :kb].cpu(), ib)
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_head_loss_reference_signature_with_empty_ground_truth(golden, case):
+    """F10 through `GFLHeadIncrementERD.loss(ori_outs, new_outs, samples, topk_*, ori_num_classes, dist_loss_weight,
+    model)` -- the reference's own entry point (gfl_head_increment_erd.py:457-459) -- with one image / every image
+    without boxes; expected losses and gradients come from the REAL reference head (gen_golden.gen_f10)."""
+    import os
+    import e2e_util as U
+    from erd_amd import Config, MODELS, parse_losses
+    g = golden("f10_head_empty_gt.npz")
+    sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas = G.f10_inputs(case)
+    cfg = Config.fromfile(U.CFG_INCRE)
+    hc = dict(cfg.model.bbox_head)
+    hc["train_cfg"] = cfg.model.train_cfg
+    head = MODELS.build(hc).cuda()
+    s_cls = [t.cuda().requires_grad_(True) for t in s_cls]
+    s_bbox = [t.cuda().requires_grad_(True) for t in s_bbox]
+    idx_c, idx_b = [], []
+    for i in range(2):
+        ic, ib, _, _ = O.ers_select_single(O.flatten_levels([t[i:i + 1] for t in t_cls])[0],
+                                           O.flatten_levels([t[i:i + 1] for t in t_bbox])[0])
+        idx_c.append(ic.cuda()); idx_b.append(ib.cuda())
+    losses = head.loss(([t.cuda() for t in t_cls], [t.cuda() for t in t_bbox]), (s_cls, s_bbox),
+                       U.make_samples(gtb, gtl, metas), idx_c, None, idx_b, None, 40, 1, None)
+    for k in ("loss_cls", "loss_bbox", "loss_dfl", "loss_dist_cls", "loss_dist_bbox"):
+        got = np.array([float(v) for v in losses[k]])
+        assert np.allclose(got, g[f"c{case}_{k}"], rtol=1e-4, atol=1e-7), (k, got, g[f"c{case}_{k}"])
+    total, _ = parse_losses(losses)
+    assert float(total) == pytest.approx(float(g[f"c{case}_total"]), rel=1e-4)
+    total.backward()
+    for l in range(5):
+        for got, want in ((s_cls[l].grad, g[f"c{case}_g_cls{l}"]), (s_bbox[l].grad, g[f"c{case}_g_bbox{l}"])):
+            want = torch.from_numpy(want)
+            assert float((got.cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-9, (l, case)

@@ -210,3 +210,24 @@ def test_f7_tiny_end_to_end(golden, fixture, c_old, depth, nparam):
     for i, k in enumerate(names):
         gr = sd[k].grad
         assert float(gr.double().norm()) == pytest.approx(float(g["grad_norms"][i]), rel=1e-3, abs=1e-9), k
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_f10_head_losses_with_empty_ground_truth(golden, case):
+    """one image / every image without boxes (reference fixture gen_f10): the `num_pos == 0` branches and the clamps of
+    both normalisers"""
+    g = golden("f10_head_empty_gt.npz")
+    sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas = G.f10_inputs(case)
+    s_cls = [t.clone().requires_grad_(True) for t in s_cls]
+    s_bbox = [t.clone().requires_grad_(True) for t in s_bbox]
+    losses = O.erd_head_loss(t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas, 40, 80, 1.0)
+    for k, vs in losses.items():
+        close(torch.stack([v.detach() for v in vs]), g[f"c{case}_{k}"], rtol=1e-5, atol=1e-7)
+    total = O.parse_losses(losses)
+    assert float(total) == pytest.approx(float(g[f"c{case}_total"]), rel=1e-5)
+    total.backward()
+    for l in range(5):
+        close(s_cls[l].grad, g[f"c{case}_g_cls{l}"], rtol=1e-4, atol=1e-8)
+        close(s_bbox[l].grad, g[f"c{case}_g_bbox{l}"], rtol=1e-4, atol=1e-8)
+    if case == 1:
+        assert all(float(v) == 0 for v in losses["loss_bbox"]) and all(float(v) == 0 for v in losses["loss_dfl"])
