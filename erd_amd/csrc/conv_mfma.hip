@@ -641,6 +641,174 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wg
 }
 
 // -------------------------------------------------------------------------------------------------
+// weight gradient of a 3x3 stride-1 pad-1 convolution, THREE taps (one kernel row ky) per workgroup.
+// A K-slice is 16 consecutive output pixels of ONE image row; the x slice carries a one-pixel halo on both sides
+// (18 entries, out-of-image entries are zero rows), so tap kx simply reads entries k+kx: the dz slice and the x slice
+// are fetched and staged once for three 128x128 products (the generic kernel fetches both once per tap: 2.8x the
+// global->LDS traffic and LDS writes per MFMA, and 3x the barriers).  192 accumulator registers -> two workgroups
+// per CU.  Partial slabs / split-K / reduce kernel are shared with the generic path.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_wgrad_desc p, const int nslices) {
+    constexpr int BM = 128, BN = 128, BK = 16, BX = BK + 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);        // [2][BK][BM]   dz
+    float* Bs = As + 2 * BK * BM;                      // [2][BX][BN]   x with halo
+    int* offa = reinterpret_cast<int*>(Bs + 2 * BX * BN);   // [2][BK] dz element offsets (-1: zero row)
+    int* offb = offa + 2 * BK;                         // [2][BX] x element offsets (-1: zero row)
+
+    const int tid = threadIdx.x;
+    const int nci = (p.Cin + BN - 1) / BN, nco = (p.Cout + BM - 1) / BM;
+    const int wg = blockIdx.x;
+    const int bx = wg % (nci * 3), by = (wg / (nci * 3)) % nco, bz = wg / (nci * 3 * nco);
+    const int ky = bx / nci;
+    const int ci0 = (bx % nci) * BN;
+    const int co0 = by * BM;
+    const int per = (nslices + p.nsplit - 1) / p.nsplit;
+    const int kt_begin = bz * per;
+    const int kt_end = min(nslices, kt_begin + per);
+    const float* __restrict__ x = p.x;
+    const float* __restrict__ dz = p.dz;
+
+    const int chunk = tid & 31, r0 = tid >> 5;          // 32 float4 chunks per 128-channel row, 8 rows per pass
+    const bool a_cok = co0 + chunk * 4 < p.Cout;
+    const bool b_cok = ci0 + chunk * 4 < p.Cin;
+    const int a_col = co0 + chunk * 4, b_col = ci0 + chunk * 4;
+
+    // slice -> (map, image, row, 16-pixel chunk) -> element offsets; 18 threads, the divisions live here only
+    auto compute_offsets = [&](int kt, int slot) {
+        if (tid < BX) {
+            int oa = -1, ob = -1;
+            if (kt < kt_end) {
+                int l = 0, q = kt;
+#pragma unroll 1
+                for (; l < p.nseg - 1; ++l) {
+                    const int cnt = p.seg[l].N * p.seg[l].GH * ((p.seg[l].GW + BK - 1) / BK);
+                    if (q < cnt) break;
+                    q -= cnt;
+                }
+                const erd_wgrad_seg& g = p.seg[l];
+                const int cpr = (g.GW + BK - 1) / BK;
+                const int c = q % cpr;
+                const int rowi = q / cpr;
+                const int a = rowi % g.GH, n = rowi / g.GH;
+                const int bcol = c * BK + tid - 1;             // x column of entry `tid` (halo of one on each side)
+                const int ih = a + ky - 1;
+                if ((unsigned)bcol < (unsigned)g.IW && (unsigned)ih < (unsigned)g.IH)
+                    ob = (int)(g.x_off + n * g.x_nstride) + (ih * g.IW + bcol) * p.Cin;
+                const int zcol = c * BK + tid;
+                if (tid < BK && zcol < g.GW) oa = (int)(g.dz_off + n * g.dz_nstride) + (a * g.OW + zcol) * p.Cout;
+            }
+            if (tid < BK) offa[slot * BK + tid] = oa;
+            offb[slot * BX + tid] = ob;
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dz), 0, (int)(p.dz_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x), 0, (int)(p.x_elems * 4), 0x00020000);
+    float4 ra[2], rb[2], rh;
+    auto load_global = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = offa[slot * BK + r0 + 8 * j];
+            ra[j] = buf_load16(rs_dz, (o >= 0 && a_cok) ? (unsigned)(o + a_col) * 4u : OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = offb[slot * BX + r0 + 8 * j];
+            rb[j] = buf_load16(rs_x, (o >= 0 && b_cok) ? (unsigned)(o + b_col) * 4u : OOB);
+        }
+        if (tid < 64) {                                  // the two halo-side entries 16, 17
+            const int o = offb[slot * BX + 16 + r0];
+            rh = buf_load16(rs_x, (o >= 0 && b_cok) ? (unsigned)(o + b_col) * 4u : OOB);
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<float4*>(As + (buf * BK + r0 + 8 * j) * BM + chunk * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<float4*>(Bs + (buf * BX + r0 + 8 * j) * BN + chunk * 4) = rb[j];
+        if (tid < 64) *reinterpret_cast<float4*>(Bs + (buf * BX + 16 + r0) * BN + chunk * 4) = rh;
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    f32x16 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        compute_offsets(kt_begin, 0);
+        __syncthreads();
+        load_global(0);
+        compute_offsets(kt_begin + 1, 1);
+        store_lds(0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            const bool more = kt + 1 < kt_end;
+            if (more) load_global(buf ^ 1);
+            compute_offsets(kt + 2, buf);
+            const float* Ab = As + buf * BK * BM + wm * 64 + li;
+            const float* Bb = Bs + buf * BX * BN + wn * 64 + li;
+            // lane half h walks pixels k = 2*ks + h; tap kx reads x entry k + kx.  Entry k+2 of this step is entry
+            // (k+2)+0 of the next one: carried over in registers.
+            float fb0[2], fb1[2], fb2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { fb0[j] = Bb[h * BN + j * 32]; fb1[j] = Bb[(h + 1) * BN + j * 32]; }
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int k = 2 * ks + h;
+                float fa[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = Ab[k * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb2[j] = Bb[(k + 2) * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb0[j], acc[0][i][j], 0, 0, 0);
+                        acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb1[j], acc[1][i][j], 0, 0, 0);
+                        acc[2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb2[j], acc[2][i][j], 0, 0, 0);
+                    }
+                if (ks + 1 < BK / 2) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { fb0[j] = fb2[j]; fb1[j] = Bb[(k + 3) * BN + j * 32]; }
+                }
+            }
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* __restrict__ part = p.part + (int64_t)bz * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + (wn * 2 + j) * 32 + li;
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (co < p.Cout) part[((int64_t)co * 9 + ky * 3 + t) * p.Cin + ci] = acc[t][i][j][r];
+                }
+        }
+}
+
+// -------------------------------------------------------------------------------------------------
 // weight gradient on the bf16 matrix cores (erd_wgrad_desc::bf16_multiplicands): same GEMM over pixels, but the MFMA
 // wants 8 consecutive K values (pixels) of ONE channel per lane while memory is pixel-major.  Each thread therefore
 // loads an 8-pixel x 4-channel micro-tile (8 coalesced 16-B loads), rounds to bf16 and transposes it in registers
@@ -991,6 +1159,20 @@ extern "C" size_t erd_conv_igemm_ws_bytes(int max_tiles) {
     return (size_t)2 * 4 * num_cus() * 128 * 128 * sizeof(float) + (size_t)max_tiles * sizeof(int);
 }
 
+// K-slices of the three-tap kernel (0: the layer is not a 3x3 / stride 1 / pad 1 convolution in tap order ky*3+kx)
+extern "C" int erd_wgrad_row3_slices(const erd_wgrad_desc* d) {
+    if (!d || d->bf16_multiplicands || d->ntaps != 9 || d->in_stride != 1 || d->out_stride != 1 || d->oy || d->ox) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (d->dy[t] != t / 3 - 1 || d->dx[t] != t % 3 - 1) return 0;
+    int64_t n = 0;
+    for (int l = 0; l < d->nseg; ++l) {
+        const erd_wgrad_seg& g = d->seg[l];
+        if (g.GH != g.IH || g.GW != g.IW || g.OH != g.GH || g.OW != g.GW) return 0;
+        n += (int64_t)g.N * g.GH * ((g.GW + 15) / 16);
+    }
+    return n < (1ll << 30) ? (int)n : 0;
+}
+
 extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d != nullptr && d->x && d->dz && d->part, "wgrad: null pointer");
     ERD_REQUIRE(d->ntaps >= 1 && d->ntaps <= ERD_MAX_TAPS, "wgrad: ntaps=%d", d->ntaps);
@@ -1018,6 +1200,22 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
         return erd::check_launch("conv_wgrad_bf16");
     }
     static const int variant = getenv("ERD_WGRAD_VARIANT") ? atoi(getenv("ERD_WGRAD_VARIANT")) : 1;   // tuning aid
+    const char* row3_env = getenv("ERD_WGRAD_ROW3");          // read per call: tests flip it in-process
+    const int row3 = row3_env ? atoi(row3_env) : 1;
+    if (row3 && erd_wgrad_row3_slices(d) > 0) {
+        const int nslices = erd_wgrad_row3_slices(d);
+        const int nci = (d->Cin + 127) / 128, nco = (d->Cout + 127) / 128;
+        const size_t lds = (size_t)2 * (16 * 128 + 18 * 128) * sizeof(float) + 2 * (16 + 18) * sizeof(int);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_row3_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_row3_kernel, dim3(nci * 3 * nco * d->nsplit), dim3(NTHREADS), lds,
+                           (hipStream_t)stream, *d, nslices);
+        return erd::check_launch("conv_wgrad_row3");
+    }
     if (variant == 0) return launch_wgrad<32, 2>(d, (hipStream_t)stream);
     return launch_wgrad<16, 4>(d, (hipStream_t)stream);
 }

@@ -452,9 +452,6 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     _require_gpu(*xs, *dzs)
     Cin, Cout = xs[0].shape[3], dzs[0].shape[3]
     npix = sum(dz.shape[0] * dz.shape[1] * dz.shape[2] for dz in dzs)
-    S = _pick_nsplit(npix, Cout, Cin, k * k)
-    slab = Cout * k * k * Cin
-    part = ws_float("wgrad_part", S * slab, xs[0].device)
     xb = min(x.data_ptr() for x in xs)
     zb = min(z.data_ptr() for z in dzs)
     d = WgradDesc()
@@ -478,9 +475,18 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
         for kw in range(k):
             d.dy[kh * k + kw], d.dx[kh * k + kw] = kh - pad, kw - pad
     d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
+    d.bf16_multiplicands = 1 if COMPUTE == "bf16" else 0
+    row3 = int(_lib.load().erd_wgrad_row3_slices(C.byref(d))) if _os.environ.get("ERD_WGRAD_ROW3", "1") != "0" else 0
+    if row3:      # three taps per workgroup, two workgroups per CU: ONE whole dispatch round of (cout, cin, ky, split) workgroups
+        # (measured best: 2 or 3 rounds pay more partial-slab traffic than they gain; a ragged extra round costs 15-40 %)
+        groups = ((Cout + 127) // 128) * ((Cin + 127) // 128) * 3
+        target = int(_os.environ.get("ERD_WGRAD_ROW3_TARGET", "512"))
+        S = int(max(1, min(target // groups, row3 // 16 if row3 >= 16 else 1, 512)))     # floor: whole dispatch rounds
+    else:
+        S = _pick_nsplit(npix, Cout, Cin, k * k)
+    part = ws_float("wgrad_part", S * Cout * k * k * Cin, xs[0].device)
     d.part = part.data_ptr()
     d.nsplit = S
-    d.bf16_multiplicands = 1 if COMPUTE == "bf16" else 0
     flop = 2.0 * npix * Cout * Cin * k * k
     nbytes = 4.0 * (sum(t.numel() for t in xs) + sum(t.numel() for t in dzs) + part.numel()) if _TIMING is not None else 0.0
     _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes)

@@ -132,6 +132,9 @@ typedef struct {
     int bf16_multiplicands; /* 1: round dz and x to bf16 as they are staged and use the bf16 matrix cores (fp32 partials) */
 } erd_wgrad_desc;
 int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream);
+/* > 0: the layer takes the three-taps-per-workgroup kernel (3x3, stride 1, pad 1, fp32) and this is its number of
+ * K-slices (16-pixel row chunks) -- the caller sizes `nsplit` from it; 0: generic kernel. */
+int erd_wgrad_row3_slices(const erd_wgrad_desc* d);
 
 /* dW (+)= rowscale[co] * sum_s part[s]; optional rowdot[co] = <W[co,:], sum_s part[s][co,:]>
  * (used for d gamma of a frozen-statistics BN: resnet.py:648-657 keeps BN in eval while

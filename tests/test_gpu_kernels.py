@@ -344,6 +344,37 @@ def test_conv_wgrad_bf16_multilevel(K, bf16_mode):
     assert relerr(dW.cpu(), ref.permute(0, 2, 3, 1)) < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Co", [(256, 256), (256, 80), (64, 68), (320, 136)])
+def test_conv_wgrad_fp32_multilevel_three_tap_kernel(K, Cin, Co, monkeypatch):
+    """3x3 / stride 1 weight gradient over the head's five concatenated levels: the three-taps-per-workgroup kernel
+    (16-pixel row chunks with halo; widths 28 / 14 / 7 / 4 / 2 exercise partial chunks and rows narrower than a chunk)
+    against autograd, and against the generic one-tap kernel (ERD_WGRAD_ROW3=0)."""
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    N = 2
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(21, N, A, Cin)
+    dz = G.randn(23, N, A, Co)
+    xs, dzs, ref, off = [], [], 0, 0
+    xg, dg = x.cuda(), dz.cuda()
+    for (h, w) in sizes:
+        xl = x[:, off:off + h * w].reshape(N, h, w, Cin).permute(0, 3, 1, 2)
+        dl = dz[:, off:off + h * w].reshape(N, h, w, Co).permute(0, 3, 1, 2)
+        wz = torch.zeros(Co, Cin, 3, 3, requires_grad=True)
+        ref = ref + torch.autograd.grad(F.conv2d(xl, wz, None, 1, 1), wz, dl)[0]
+        xs.append(xg[:, off:off + h * w].unflatten(1, (h, w)))
+        dzs.append(dg[:, off:off + h * w].unflatten(1, (h, w)))
+        off += h * w
+    outs = []
+    for row3 in ("1", "0"):
+        monkeypatch.setenv("ERD_WGRAD_ROW3", row3)
+        part, S = K.conv_wgrad_partials(xs, dzs, 3, 1, 1)
+        dW = torch.empty((Co, 3, 3, Cin), device="cuda")
+        K.wgrad_reduce(part, S, dW, None, dW, False, None)
+        assert relerr(dW.cpu(), ref.permute(0, 2, 3, 1)) < 2e-5, row3
+        outs.append(dW.cpu())
+    assert relerr(outs[0], outs[1]) < 5e-6
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 256, 256, 26, 30), (1, 64, 64, 20, 28), (2, 128, 128, 25, 42), (1, 256, 80, 13, 21),
                                             (1, 512, 512, 7, 11), (1, 256, 68, 8, 16), (1, 16, 32, 5, 3)])
 def test_winograd_conv3x3_forward(K, N, Cin, Cout, H, W):
