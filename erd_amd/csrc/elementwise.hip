@@ -20,70 +20,130 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // stem: conv 7x7 stride 2 pad 3, 3->64, input NCHW (the detector's public input layout), output NHWC,
-// frozen BN + ReLU fused (resnet.py:636-638).  Direct convolution: Cin=3 does not feed an MFMA K-slice.
-// Block = 256 threads = 8x32 output pixels; each thread accumulates all 64 output channels of one
-// pixel; weights (147x64) and the 21x69x3 input patch live in LDS (weights are read as broadcasts).
+// frozen BN + ReLU fused (resnet.py:636-638).  Implicit GEMM on the fp32 matrix cores: M = 8x32 output pixels per
+// block (one 32-pixel row per MFMA row block, two per wave), N = 64 channels, K = 7*7*3 = 147 (+1 zero row) in
+// the weights' own (kh, kw, c) order.  The 21x69x3 input patch and the [148][64] weight image live in LDS; the A
+// operand is gathered straight from the patch (lane = pixel, the k-th patch offset is a compile-time constant per
+// lane half), the B operand is a conflict-free row read.
 // ------------------------------------------------------------------------------------------------
 constexpr int ST_TH = 8, ST_TW = 32;
 constexpr int ST_PH = ST_TH * 2 + 5, ST_PW = ST_TW * 2 + 5;  // 21 x 69
+constexpr int ST_PWP = ST_PW + 1;                             // padded row
+constexpr int ST_K = 148;
 
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   float* __restrict__ out, int N, int H, int W, int OH, int OW) {
-    __shared__ float4 wl[147 * 16];           // [kh][kw][c][64] as float4 over couts
-    __shared__ float patch[3][ST_PH][ST_PW + 1];
+__host__ __device__ constexpr int stem_patch_off(int k) {     // (kh, kw, c) -> offset inside patch[3][21][70]
+    return k >= 147 ? 0 : (k % 3) * ST_PH * ST_PWP + (k / 21) * ST_PWP + (k / 3) % 7;
+}
+
+__global__ __launch_bounds__(256, 2) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      float* __restrict__ out, int N, int H, int W, int OH, int OW) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int WLD = 65;                    // padded weight row: conflict-free transposing store and row reads
+    constexpr int PATCH = 3 * ST_PH * ST_PWP, NLOAD = (3 * ST_PH * ST_PW + 255) / 256;
+    __shared__ float wl[ST_K * WLD];           // [(kh,kw,c)][co], row 147 = 0
+    __shared__ float patch[2][PATCH];
     const int tid = threadIdx.x;
-    const int n = blockIdx.z;
-    const int oh0 = blockIdx.y * ST_TH, ow0 = blockIdx.x * ST_TW;
-    // weights arrive as [co][kh][kw][c] (OHWI); LDS wants [(kh,kw,c)][co]
+    // weights arrive as [co][kh][kw][c] (OHWI); LDS wants [(kh,kw,c)][co].  Loaded ONCE: the grid is persistent.
     for (int i = tid; i < 147 * 64; i += 256) {
         const int co = i / 147, k = i - co * 147;
-        reinterpret_cast<float*>(wl)[k * 64 + co] = w[i];
+        wl[k * WLD + co] = w[i];
     }
-    const int ih0 = oh0 * 2 - 3, iw0 = ow0 * 2 - 3;
-    for (int i = tid; i < 3 * ST_PH * ST_PW; i += 256) {
-        const int c = i / (ST_PH * ST_PW);
-        const int r = (i / ST_PW) % ST_PH;
-        const int col = i % ST_PW;
-        const int ih = ih0 + r, iw = iw0 + col;
-        float v = 0.f;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((int64_t)(n * 3 + c) * H + ih) * W + iw];
-        patch[c][r][col] = v;
-    }
-    __syncthreads();
-    const int ty = tid >> 5, tx = tid & 31;
-    float4 acc[16];
+    if (tid < 64) wl[147 * WLD + tid] = 0.f;
+    const int tx_n = (OW + ST_TW - 1) / ST_TW, ty_n = (OH + ST_TH - 1) / ST_TH;
+    const int total = tx_n * ty_n * N;
+
+    float pv[NLOAD];
+    auto fetch = [&](int t) {                  // the 21x69x3 input patch of tile t -> registers
+        const int n = t / (tx_n * ty_n), rem = t - n * tx_n * ty_n;
+        const int ih0 = (rem / tx_n) * ST_TH * 2 - 3, iw0 = (rem % tx_n) * ST_TW * 2 - 3;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int kh = 0; kh < 7; ++kh)
-        for (int kw = 0; kw < 7; ++kw)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = patch[c][ty * 2 + kh][tx * 2 + kw];
-                const float4* wr = wl + ((kh * 7 + kw) * 3 + c) * 16;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float4 ww = wr[i];
-                    acc[i].x = fmaf(v, ww.x, acc[i].x);
-                    acc[i].y = fmaf(v, ww.y, acc[i].y);
-                    acc[i].z = fmaf(v, ww.z, acc[i].z);
-                    acc[i].w = fmaf(v, ww.w, acc[i].w);
-                }
-            }
-    const int oh = oh0 + ty, ow = ow0 + tx;
-    if (oh < OH && ow < OW) {
-        float4* o = reinterpret_cast<float4*>(out + ((int64_t)(n * OH + oh) * OW + ow) * 64);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float4 sc = reinterpret_cast<const float4*>(scale)[i];
-            const float4 sh = reinterpret_cast<const float4*>(shift)[i];
-            float4 v;
-            v.x = fmaxf(acc[i].x * sc.x + sh.x, 0.f);
-            v.y = fmaxf(acc[i].y * sc.y + sh.y, 0.f);
-            v.z = fmaxf(acc[i].z * sc.z + sh.z, 0.f);
-            v.w = fmaxf(acc[i].w * sc.w + sh.w, 0.f);
-            o[i] = v;
+        for (int q = 0; q < NLOAD; ++q) {
+            const int i = tid + q * 256;
+            const int c = i / (ST_PH * ST_PW);
+            const int r = (i / ST_PW) % ST_PH;
+            const int col = i % ST_PW;
+            const int ih = ih0 + r, iw = iw0 + col;
+            float v = 0.f;
+            if (i < 3 * ST_PH * ST_PW && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                v = x[((int64_t)(n * 3 + c) * H + ih) * W + iw];
+            pv[q] = v;
         }
+    };
+    auto stash = [&](float* dst) {
+#pragma unroll
+        for (int q = 0; q < NLOAD; ++q) {
+            const int i = tid + q * 256;
+            if (i < 3 * ST_PH * ST_PW) dst[(i / ST_PW) * ST_PWP + i % ST_PW] = pv[q];     // (c*PH + r) rows of PWP
+        }
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, h = lane >> 5;
+    int t = blockIdx.x;
+    if (t < total) { fetch(t); stash(patch[0]); }
+    __syncthreads();
+    for (int it = 0; t < total; t += gridDim.x, ++it) {
+        const float* pc = patch[it & 1];
+        const bool more = t + (int)gridDim.x < total;
+        if (more) fetch(t + gridDim.x);        // in flight behind the MFMAs of this tile
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // pixel (row 2*wave + i, column li) of the tile -> patch origin (2*row, 2*col)
+        const float* pa = pc + (2 * (2 * wave)) * ST_PWP + 2 * li;
+        const float* pb = wl + h * WLD + li;
+        // software pipeline: the operands of step ks+1 are read while the four MFMAs of step ks run; the scheduling
+        // barrier keeps the compiler from hoisting all 296 LDS reads to the top (256 VGPRs + spills otherwise)
+        const int off0 = h ? stem_patch_off(1) : stem_patch_off(0);
+        float a0 = pa[off0], a1 = pa[off0 + 2 * ST_PWP], b0 = pb[0], b1 = pb[32];
+#pragma unroll
+        for (int ks = 0; ks < ST_K / 2; ++ks) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (ks + 1 < ST_K / 2) {
+                const int off = h ? stem_patch_off(2 * ks + 3) : stem_patch_off(2 * ks + 2);
+                na0 = pa[off]; na1 = pa[off + 2 * ST_PWP];
+                nb0 = pb[(ks + 1) * 2 * WLD]; nb1 = pb[(ks + 1) * 2 * WLD + 32];
+            }
+            // weights are the A operand (rows = channels), pixels the B operand (columns): a lane then owns four
+            // CONSECUTIVE channels of its pixel per accumulator quad -> 16-byte stores
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        if (more) stash(patch[(it & 1) ^ 1]);  // that buffer was last read one tile ago (barrier in between)
+        // acc[cb][pr][4g + q] of lane (li, h): channel cb*32 + 8g + 4h + q of pixel (row 2*wave + pr, column li)
+        const int n = t / (tx_n * ty_n), rem = t - n * tx_n * ty_n;
+        const int oh0 = (rem / tx_n) * ST_TH, ow0 = (rem % tx_n) * ST_TW;
+        const int ow = ow0 + li;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int oh = oh0 + 2 * wave + pr;
+            if (oh >= OH || ow >= OW) continue;
+            float* o = out + ((int64_t)(n * OH + oh) * OW + ow) * 64 + 4 * h;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = cb * 32 + 8 * g;
+                    const float4 sc = *reinterpret_cast<const float4*>(scale + ch + 4 * h);
+                    const float4 sh = *reinterpret_cast<const float4*>(shift + ch + 4 * h);
+                    float4 v;
+                    v.x = fmaxf(acc[cb][pr][4 * g + 0] * sc.x + sh.x, 0.f);
+                    v.y = fmaxf(acc[cb][pr][4 * g + 1] * sc.y + sh.y, 0.f);
+                    v.z = fmaxf(acc[cb][pr][4 * g + 2] * sc.z + sh.z, 0.f);
+                    v.w = fmaxf(acc[cb][pr][4 * g + 3] * sc.w + sh.w, 0.f);
+                    *reinterpret_cast<float4*>(o + ch) = v;
+                }
+        }
+        __syncthreads();
     }
 }
 
@@ -577,7 +637,9 @@ extern "C" int erd_stem_conv7x7_bn_relu(const float* x, const float* w, const fl
                                         float* out, int N, int H, int W, erd_stream_t stream) {
     ERD_REQUIRE(x && w && scale && shift && out && N > 0, "stem: bad args");
     const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
-    hipLaunchKernelGGL(stem_kernel, dim3((OW + ST_TW - 1) / ST_TW, (OH + ST_TH - 1) / ST_TH, N), dim3(256), 0,
+    const int64_t tiles = (int64_t)((OW + ST_TW - 1) / ST_TW) * ((OH + ST_TH - 1) / ST_TH) * N;
+    ERD_REQUIRE(tiles < (1ll << 31), "stem: too many tiles");
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0,       // persistent: 2 per CU
                        (hipStream_t)stream, x, w, scale, shift, out, N, H, W, OH, OW);
     return erd::check_launch("stem");
 }
