@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS), ("wk", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32), ("colsum", C.c_void_p),
-                ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("w_bf16", C.c_void_p)]
+                ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("w_bf16", C.c_void_p), ("colsum_copies", i32)]
 
 
 class WgradSeg(C.Structure):
@@ -62,7 +62,7 @@ _SIGNATURES = {
     "erd_to_bf16": [P, P, i64, P],
     "erd_wino_weights_elems": [i32, i32],
     "erd_wino_weights": [P, P, i32, i32, i32, P],
-    "erd_wino_conv3x3": [P, i32, P, i32, i32, P, P, i32, P, P, P],
+    "erd_wino_conv3x3": [P, i32, P, i32, i32, P, P, i32, P, i32, P, P],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_row3_slices": [C.POINTER(WgradDesc)],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
@@ -72,7 +72,7 @@ _SIGNATURES = {
     "erd_maxpool3x3s2": [P, P, i32, i32, i32, i32, P],
     "erd_bn_fold": [P, P, P, P, f32, P, P, i64, P],
     "erd_relu_bwd_colsum": [P, P, P, i64, i32, i64, i64, P, i32, P],
-    "erd_bn_dgamma": [P, P, P, P, f32, P, i32, i32, P],
+    "erd_bn_dgamma": [P, P, i32, P, P, f32, P, P, i32, i32, P],
     "erd_gn_relu_fwd": [P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), f32, P],
     "erd_gn_relu_bwd": [P, P, P, P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), P],
     "erd_upsample2x_add": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, P],

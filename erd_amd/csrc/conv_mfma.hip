@@ -469,10 +469,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                         const float4 v = red[q * C4N + tid];
                         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
                     }
-                    atomicAdd(p.colsum + co + 0, t.x);
-                    if (co + 1 < p.Cout) atomicAdd(p.colsum + co + 1, t.y);
-                    if (co + 2 < p.Cout) atomicAdd(p.colsum + co + 2, t.z);
-                    if (co + 3 < p.Cout) atomicAdd(p.colsum + co + 3, t.w);
+                    float* cs = p.colsum + (p.colsum_copies > 1 ? (int64_t)(blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0);
+                    atomicAdd(cs + co + 0, t.x);
+                    if (co + 1 < p.Cout) atomicAdd(cs + co + 1, t.y);
+                    if (co + 2 < p.Cout) atomicAdd(cs + co + 2, t.z);
+                    if (co + 3 < p.Cout) atomicAdd(cs + co + 3, t.w);
                 }
             }
         }
@@ -1108,6 +1109,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d->Cin > 0 && d->Cin % 4 == 0, "conv: Cin=%d must be a multiple of 4", d->Cin);
     ERD_REQUIRE(d->Cout > 0 && d->wrow % 4 == 0, "conv: Cout=%d wrow=%d", d->Cout, d->wrow);
     ERD_REQUIRE(d->w_bf16 || d->w, "conv: no weights");
+    ERD_REQUIRE(d->colsum_copies >= 0 && (d->colsum_copies & (d->colsum_copies - 1)) == 0, "conv: colsum_copies=%d must be a power of two",
+                d->colsum_copies);
     for (int s = 0; s < d->nseg; ++s) {
         const erd_conv_seg& g = d->seg[s];
         ERD_REQUIRE(g.in && g.out, "conv: null tensor in segment %d", s);

@@ -260,12 +260,15 @@ __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __res
     }
 }
 
-__global__ void bn_dgamma_kernel(const float* __restrict__ rowdot, const float* __restrict__ dbeta,
+__global__ void bn_dgamma_kernel(const float* __restrict__ rowdot, const float* __restrict__ dbeta, int copies,
                                  const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                 float* __restrict__ dgamma, int accumulate, int C) {
+                                 float* __restrict__ dgamma, float* __restrict__ dbeta_out, int accumulate, int C) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < C) {
-        const float v = (1.0f / sqrtf(var[i] + eps)) * (rowdot[i] - mean[i] * dbeta[i]);
+        float db = dbeta[i];
+        for (int r = 1; r < copies; ++r) db += dbeta[(int64_t)r * C + i];
+        if (dbeta_out) dbeta_out[i] = db;
+        const float v = (1.0f / sqrtf(var[i] + eps)) * (rowdot[i] - mean[i] * db);
         dgamma[i] = accumulate ? dgamma[i] + v : v;
     }
 }
@@ -809,11 +812,11 @@ extern "C" int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, i
     return erd::check_launch("relu_bwd_colsum");
 }
 
-extern "C" int erd_bn_dgamma(const float* rowdot, const float* dbeta, const float* mean, const float* var, float eps,
-                             float* dgamma, int accumulate, int C, erd_stream_t stream) {
-    ERD_REQUIRE(rowdot && dbeta && mean && var && dgamma, "bn_dgamma: null");
-    hipLaunchKernelGGL(bn_dgamma_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowdot, dbeta, mean,
-                       var, eps, dgamma, accumulate, C);
+extern "C" int erd_bn_dgamma(const float* rowdot, const float* dbeta, int copies, const float* mean, const float* var,
+                             float eps, float* dgamma, float* dbeta_out, int accumulate, int C, erd_stream_t stream) {
+    ERD_REQUIRE(rowdot && dbeta && mean && var && dgamma && copies >= 1, "bn_dgamma: bad args");
+    hipLaunchKernelGGL(bn_dgamma_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowdot, dbeta, copies,
+                       mean, var, eps, dgamma, dbeta_out, accumulate, C);
     return erd::check_launch("bn_dgamma");
 }
 

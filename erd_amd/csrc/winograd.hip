@@ -96,7 +96,8 @@ struct WinoDesc {
     const float* scale;
     const float* shift;
     int relu;
-    float* colsum;           // optional [Cout]: += column sums of the stored result
+    float* colsum;           // optional [colsum_copies][Cout]: += column sums of the stored result
+    int colsum_copies;       // 0/1 or a power of two: workgroup b adds into row b mod copies
     int blocks_per_nb;       // workgroups per cout block
     int nitems;              // workgroup items = blocks_per_nb * cout blocks
     int* sched;              // optional {next-item counter, finished-workgroup counter}, zero on entry and on exit
@@ -285,7 +286,8 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         float csum = 0.f;
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) csum += emit(it, rep);
-        if (p.colsum && it.cout0 + o_c < p.Cout) atomicAdd(p.colsum + it.cout0 + o_c, csum);
+        if (p.colsum && it.cout0 + o_c < p.Cout)
+            atomicAdd(p.colsum + (p.colsum_copies > 1 ? (blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) + it.cout0 + o_c, csum);
     };
 
     // The two roles run separate code paths with the SAME barrier sequence per item (2 + nks + 2); keeping them apart lets
@@ -425,8 +427,8 @@ extern "C" size_t erd_wino_weights_elems(int Cout, int Cin) {
 }
 
 extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout,
-                                const float* scale, const float* shift, int relu, float* colsum, int* sched,
-                                erd_stream_t stream) {
+                                const float* scale, const float* shift, int relu, float* colsum, int colsum_copies,
+                                int* sched, erd_stream_t stream) {
     ERD_REQUIRE(segs && U && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
     ERD_REQUIRE(Cin % KS == 0 && Cout > 0, "wino: Cin=%d must be a multiple of %d", Cin, KS);
     WinoDesc d;
@@ -438,6 +440,8 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     d.shift = shift;
     d.relu = relu;
     d.colsum = colsum;
+    ERD_REQUIRE(colsum_copies >= 0 && (colsum_copies & (colsum_copies - 1)) == 0, "wino: colsum_copies must be a power of two");
+    d.colsum_copies = colsum_copies;
     d.sched = sched;
     ERD_REQUIRE(!colsum || Cout % 4 == 0, "wino: colsum needs Cout %% 4 == 0");
     static const int dbg = getenv("ERD_WINO_DBG") ? atoi(getenv("ERD_WINO_DBG")) : 0;

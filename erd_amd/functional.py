@@ -239,12 +239,21 @@ class BottleneckFn(Function):
             rowdot = K.zeros_f32(scale.numel(), scale.device) if need[base + 1] else None
             grads[5 * idx] = _emit_wgrad(w, part, S, wk, scale, rowdot)
             if need[base + 1]:
+                # a replicated [copies, C] accumulator is folded here; the fold lands in d beta's flat slot (zero at
+                # this point) or in a new tensor
+                rep = dbeta.dim() == 2
+                bs_fold = (_sink(b) if need[base + 2] else None) if rep else None
+                fold = None if not rep else (bs_fold if bs_fold is not None else torch.empty_like(dbeta[0]))
                 gs = _sink(g)
                 if gs is not None:                      # the slot is zero: plain store == accumulation
-                    K.bn_dgamma(rowdot, dbeta, m, v, eps, out=gs)
+                    K.bn_dgamma(rowdot, dbeta, m, v, eps, out=gs, dbeta_out=fold)
                     _sunk(g)
                 else:
-                    grads[5 * idx + 1] = K.bn_dgamma(rowdot, dbeta, m, v, eps)
+                    grads[5 * idx + 1] = K.bn_dgamma(rowdot, dbeta, m, v, eps, dbeta_out=fold)
+                if rep:
+                    dbeta = fold
+            elif dbeta.dim() == 2:
+                dbeta = dbeta.sum(0)
             if need[base + 2]:
                 bs = _sink(b)
                 if bs is None:
@@ -262,11 +271,14 @@ class BottleneckFn(Function):
         dz3, db3 = K.relu_bwd_colsum(y, dy.contiguous(), True, colsum_into=beta_slot(2, y.shape[3]))
         wgrad(2, o2, dz3, 1, 1, 0, s3, db3)
         dz2 = torch.empty_like(o2)
-        db2 = beta_slot(1, o2.shape[3])
+        # the epilogues of the two input-gradient convolutions add their column sums into 8 replicated rows (hundreds of
+        # tiles adding to ONE row would serialise on the memory-side atomic unit); wgrad()'s bn_dgamma folds them
+        rep_slot = lambda n: K.zeros_f32(K.COLSUM_COPIES * n, dev).view(K.COLSUM_COPIES, n)
+        db2 = rep_slot(o2.shape[3])
         K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[2][0]), s3), [dz2], 1, 1, 0, relu_mask=[o2], colsum=db2)
         wgrad(1, o1, dz2, 3, stride, 1, s2, db2)
         dz1 = torch.empty_like(o1)
-        db1 = beta_slot(0, o1.shape[3])
+        db1 = rep_slot(o1.shape[3])
         K.conv_dgrad([dz2], K.weight_transpose(ohwi(P[1][0]), s2), [dz1], 3, stride, 1, relu_mask=[o1], colsum=db1)
         wgrad(0, x, dz1, 1, 1, 0, s1, db1)
         dx = None

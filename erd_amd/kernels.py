@@ -54,7 +54,10 @@ def timing_end():
     return out
 
 
-def _timed_call(kname: str, flop: float, cname: str, *args, nbytes: float = 0.0) -> None:
+TIMING_DETAIL = False      # tools/step_breakdown.py: one record per layer shape instead of per kernel class
+
+
+def _timed_call(kname: str, flop: float, cname: str, *args, nbytes: float = 0.0, tag: str = "") -> None:
     """nbytes: the launch's algorithmic HBM bytes (every operand read once, the result written once)"""
     if _TIMING is None:
         call(cname, *args)
@@ -63,6 +66,8 @@ def _timed_call(kname: str, flop: float, cname: str, *args, nbytes: float = 0.0)
     s.record()
     call(cname, *args)
     e.record()
+    if TIMING_DETAIL and tag:
+        kname = f"{kname} {tag}"
     _TIMING.setdefault(kname, []).append((s, e, flop, nbytes))
 
 
@@ -291,7 +296,8 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     _attach_sk_ws(d, w.device)
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
     nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel()) if _TIMING is not None else 0.0
-    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes)
+    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes,
+                tag=_shape_tag(d, k, stride) if TIMING_DETAIL else "")
 
 
 WINOGRAD = _os.environ.get("ERD_WINO", "1") != "0"     # F(2x2,3x3) for the fp32 3x3 stride-1 convolutions (winograd.hip)
@@ -353,7 +359,9 @@ def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: 
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * 9 * Cin
     nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U.numel()) if _TIMING is not None else 0.0
     _timed_call(kname, flop, "erd_wino_conv3x3", segs, len(xs), _p(U), Cin, Cout, _p(scale), _p(shift),
-                1 if relu else 0, _p(colsum), _p(_wino_sched(U.device)), _stream(), nbytes=nbytes)
+                1 if relu else 0, _p(colsum), (colsum.numel() // Cout if colsum is not None else 0),
+                _p(_wino_sched(U.device)), _stream(), nbytes=nbytes,
+                tag=f"px{sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs)} {Cin}->{Cout} k3s1" if TIMING_DETAIL else "")
 
 
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
@@ -372,6 +380,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
                accumulate: bool = False, res: Optional[Sequence[Tensor]] = None,
                relu_mask: Optional[Sequence[Tensor]] = None, colsum: Optional[Tensor] = None) -> None:
     """dxs[i] (+)= conv_transpose(dzs[i]); wt = weight_transpose(w) is [Cin,k,k,Cout].
+    colsum: [Cin] or a replicated [copies, Cin] accumulator (copies a power of two; bn_dgamma folds the rows).
     stride 1: one launch; stride 2: one launch per output-parity class (no zero-multiplies).
     Pixels of dx that no tap reaches (k=1, stride 2) are NOT written: pass accumulate=True on a
     buffer that already holds the other branch's gradient, or zero it first."""
@@ -422,6 +431,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.shift = 0
         d.relu = 0
         d.colsum = 0 if colsum is None else colsum.data_ptr()
+        d.colsum_copies = 0 if colsum is None else colsum.numel() // Cin        # [copies, Cin of the forward conv]
         if wtb is not None:
             d.w_bf16 = wtb.data_ptr()
         _attach_sk_ws(d, wt.device)
@@ -429,7 +439,13 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         # (stride 2: each parity class reads dz once and writes a quarter of dx)
         nbytes = 4.0 * (sum(t.numel() for t in dzs) + sum(t.numel() for t in dxs) / (stride * stride) + wt.numel() /
                         (stride * stride)) if _TIMING is not None else 0.0
-        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes)
+        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes,
+                    tag=(_shape_tag(d, k, stride) + f" class{py}{px}") if TIMING_DETAIL else "")
+
+
+def _shape_tag(d, k: int, stride: int) -> str:
+    px = sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg))
+    return f"px{px} {d.Cin}->{d.Cout} k{k}s{stride}"
 
 
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
@@ -489,7 +505,8 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     d.nsplit = S
     flop = 2.0 * npix * Cout * Cin * k * k
     nbytes = 4.0 * (sum(t.numel() for t in xs) + sum(t.numel() for t in dzs) + part.numel()) if _TIMING is not None else 0.0
-    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes)
+    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes,
+                tag=f"px{npix} {Cin}->{Cout} k{k}s{stride} S{S}" if TIMING_DETAIL else "")
     return part, S
 
 
@@ -568,10 +585,17 @@ def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum
     return dz, colsum
 
 
+COLSUM_COPIES = 8      # rows of a replicated column-sum accumulator (power of two): see erd_conv_desc::colsum_copies
+
+
 def bn_dgamma(rowdot: Tensor, dbeta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5,
-              out: Optional[Tensor] = None) -> Tensor:
-    dg = torch.empty_like(dbeta) if out is None else out
-    call("erd_bn_dgamma", _p(rowdot), _p(dbeta), _p(mean), _p(var), eps, _p(dg), 0, dbeta.numel(), _stream())
+              out: Optional[Tensor] = None, dbeta_out: Optional[Tensor] = None) -> Tensor:
+    """dbeta: [C] or the replicated [copies, C] accumulator of a gradient convolution's epilogue; its row sum is
+    stored to `dbeta_out` when given"""
+    Cc = dbeta.shape[-1]
+    copies = dbeta.numel() // Cc
+    dg = torch.empty(Cc, dtype=torch.float32, device=dbeta.device) if out is None else out
+    call("erd_bn_dgamma", _p(rowdot), _p(dbeta), copies, _p(mean), _p(var), eps, _p(dg), _p(dbeta_out), 0, Cc, _stream())
     return dg
 
 

@@ -69,7 +69,7 @@ typedef struct {
     const float* scale;  /* optional [Cout]: v = acc*scale[co]            */
     const float* shift;  /* optional [Cout]: v += shift[co]  (bias / folded BN) */
     int relu;            /* v = max(v,0) */
-    float* colsum;       /* optional [Cout]: += column sums of the stored result (atomic) */
+    float* colsum;       /* optional [colsum_copies][Cout]: += column sums of the stored result (atomic) */
     /* optional stream-K workspace (>= erd_conv_igemm_ws_bytes()): lets the launch split the K loop of
      * boundary tiles across workgroups so that all CUs finish together; NULL = one workgroup per tile.
      * The ticket area (the last max_tiles*4 bytes) must be ZERO on entry; the kernel leaves it zero. */
@@ -79,6 +79,9 @@ typedef struct {
      * bf16 matrix cores (v_mfma_f32_32x32x16_bf16): activations are rounded to bf16 as they are staged, products
      * are exact, accumulation / epilogue / output stay fp32 (BASELINE.json configs[2]; `w` is then unused). */
     const void* w_bf16;
+    /* 0 / 1: one row of sums.  2^k: workgroup b adds into row (b mod 2^k) -- same-address float atomics retire at about
+     * six per microsecond, a 1000-tile launch would otherwise wait for them; the consumer folds the rows (erd_bn_dgamma). */
+    int colsum_copies;
 } erd_conv_desc;
 
 /* replaces: F.conv2d dispatches at resnet.py:268-283, res_layer.py:57-63, fpn.py:196,215-220,
@@ -101,7 +104,7 @@ int erd_wino_weights(const float* w_ohwi, float* U, int Cout, int Cin, int flip 
                      erd_stream_t stream);
 /* epilogue: v = acc*scale + shift (+ seg.res) ; ReLU ; zero where seg.mask <= 0 ; colsum[co] += v (atomic) */
 int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout, const float* scale,
-                     const float* shift, int relu, float* colsum,
+                     const float* shift, int relu, float* colsum, int colsum_copies /* see erd_conv_desc */,
                      int* sched /* optional 2 ints, zero on entry (left zero): dynamic item scheduling of the
                                    persistent grid; NULL = static split */,
                      erd_stream_t stream);
@@ -183,9 +186,10 @@ int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, int64_t npix, int C,
                         int64_t nstride_rows, int64_t rows_per_img, float* colsum, int use_relu,
                         erd_stream_t stream);
-/* dgamma = rsqrt(var+eps) * (rowdot - mean*dbeta) */
-int erd_bn_dgamma(const float* rowdot, const float* dbeta, const float* mean, const float* var,
-                  float eps, float* dgamma, int accumulate, int C, erd_stream_t stream);
+/* dbeta_sum = sum over the `copies` rows of dbeta[copies][C] (stored to dbeta_out when given);
+ * dgamma = rsqrt(var+eps) * (rowdot - mean*dbeta_sum) */
+int erd_bn_dgamma(const float* rowdot, const float* dbeta, int copies, const float* mean, const float* var,
+                  float eps, float* dgamma, float* dbeta_out, int accumulate, int C, erd_stream_t stream);
 
 /* ---- GroupNorm(32)+ReLU over level-concatenated [N][A][C] maps (gfl_head.py:158-177) -------- */
 typedef struct {
