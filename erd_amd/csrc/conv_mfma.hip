@@ -17,6 +17,7 @@
 //
 // Forward conv, stride-1 input-gradient and the 4 parity classes of a stride-2 input-gradient are
 // all expressed through the tap list of erd_conv_desc (include/erd_hip.h).
+#include <algorithm>
 #include "erd_common.h"
 #include <stdlib.h>
 #ifndef ERD_SGB
@@ -1089,8 +1090,13 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     // of the resident slots (measured: whole step 105 -> 118 img/s with tile-parallel launches everywhere else;
     // 264-tile layers 64 -> 41 us without the split, 132-tile 3x3 layers 134 -> 80 us with it)
     const bool sk_pays = BF ? tiles * 2 <= slots : true;
-    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && nkt * BKT >= 512 && (int64_t)tiles * nkt >= slots) {
-        G = slots;
+    // tiny launches (the stride-2 P6 / P7 convolutions: 6-18 tiles with 72 K-slices each) still split K, but every
+    // workgroup keeps at least `min_slices` slices: 6 workgroups walking 72 slices each took 181 us for 2 MFLOP
+    static const int min_slices = getenv("ERD_SK_MIN_SLICES") ? atoi(getenv("ERD_SK_MIN_SLICES")) : 8;
+    const int64_t units = (int64_t)tiles * nkt;
+    const bool tiny = units < slots && min_slices > 0 && nkt >= 2 * min_slices && !BF;
+    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && nkt * BKT >= 512 && (units >= slots || tiny)) {
+        G = (int)std::min<int64_t>(slots, min_slices > 0 ? std::max<int64_t>(tiles, units / min_slices) : slots);
         ws.slabs = reinterpret_cast<float*>(d->sk_ws);
         ws.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(d->sk_ws) + slab_bytes);
         // tickets are zero on entry: the workspace is zero-initialised by its owner and every reducer re-zeroes
@@ -1136,8 +1142,19 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     const int64_t tiles = mtiles * ((d->Cout + 127) / 128);
     // short K loops, or so many tiles that tile-granular dispatch is already balanced: four small workgroups per
     // CU hide each other's staging/barrier phases best (measured 136 vs 131 TF on 8192 tiles x K=2048)
-    if (d->ntaps * d->Cin <= 256 || tiles >= 16 * 2 * num_cus())
+    if (d->ntaps * d->Cin <= 256) {
+        // Tile-parallel launches finish in whole dispatch rounds: pick the co-residency whose LAST round is fullest.
+        // cost = rounds x (workgroups per CU / steady-state efficiency at that co-residency: 0.83 / 0.85 / 0.87 measured)
+        static const int pick = getenv("ERD_IGEMM_PICK") ? atoi(getenv("ERD_IGEMM_PICK")) : 1;   // 0: always four per CU
+        const int64_t cus = num_cus();
+        const double c2 = (double)((tiles + 2 * cus - 1) / (2 * cus)) * (2.0 / 0.83);
+        const double c3 = (double)((tiles + 3 * cus - 1) / (3 * cus)) * (3.0 / 0.85);
+        const double c4 = (double)((tiles + 4 * cus - 1) / (4 * cus)) * (4.0 / 0.87);
+        if (pick && c3 < c4 && c3 <= c2) return launch_igemm<128, 128, 2, 2, 16, 3>(d, st);
+        if (pick && c2 < c4 && c2 < c3) return launch_igemm<128, 128, 2, 2, 32, 2>(d, st);
         return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
+    }
+    if (tiles >= 16 * 2 * num_cus()) return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
     return launch_igemm<128, 128, 2, 2, 32, 2>(d, st);
 }
 
