@@ -650,8 +650,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_wgrad_kernel(const erd_wg
 // global->LDS traffic and LDS writes per MFMA, and 3x the barriers).  192 accumulator registers -> two workgroups
 // per CU.  Partial slabs / split-K / reduce kernel are shared with the generic path.
 // -------------------------------------------------------------------------------------------------
+// Wave tiling <WAVES_M, FM, FN>: the 4 waves form a WAVES_M x (4 / WAVES_M) grid, each owning FM x FN 32x32 blocks per tap.
+// <2,2,2>: 128 output channels x 128 input channels.  <1,3,1> / <1,2,1>: 96 / 64 output channels (the heads' 80- and
+// 68-channel convolutions would waste 37-47 % of a 128-row tile).
+template <int WAVES_M, int FM, int FN>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_wgrad_desc p, const int nslices) {
-    constexpr int BM = 128, BN = 128, BK = 16, BX = BK + 2;
+    constexpr int BM = 128, BN = 128, BK = 16, BX = BK + 2;     // LDS tile widths (loads beyond BME rows are masked)
+    constexpr int WAVES_N = 4 / WAVES_M, BME = WAVES_M * FM * 32;
+    static_assert(WAVES_N * FN * 32 == BN && BME <= BM, "wave tiling");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);        // [2][BK][BM]   dz
     float* Bs = As + 2 * BK * BM;                      // [2][BX][BN]   x with halo
@@ -659,12 +665,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
     int* offb = offa + 2 * BK;                         // [2][BX] x element offsets (-1: zero row)
 
     const int tid = threadIdx.x;
-    const int nci = (p.Cin + BN - 1) / BN, nco = (p.Cout + BM - 1) / BM;
+    const int nci = (p.Cin + BN - 1) / BN, nco = (p.Cout + BME - 1) / BME;
     const int wg = blockIdx.x;
     const int bx = wg % (nci * 3), by = (wg / (nci * 3)) % nco, bz = wg / (nci * 3 * nco);
     const int ky = bx / nci;
     const int ci0 = (bx % nci) * BN;
-    const int co0 = by * BM;
+    const int co0 = by * BME;
     const int per = (nslices + p.nsplit - 1) / p.nsplit;
     const int kt_begin = bz * per;
     const int kt_end = min(nslices, kt_begin + per);
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
     const float* __restrict__ dz = p.dz;
 
     const int chunk = tid & 31, r0 = tid >> 5;          // 32 float4 chunks per 128-channel row, 8 rows per pass
-    const bool a_cok = co0 + chunk * 4 < p.Cout;
+    const bool a_cok = chunk * 4 < BME && co0 + chunk * 4 < p.Cout;
     const bool b_cok = ci0 + chunk * 4 < p.Cin;
     const int a_col = co0 + chunk * 4, b_col = ci0 + chunk * 4;
 
@@ -737,15 +743,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
     };
 
     const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
-    f32x16 acc[3][2][2];
+    f32x16 acc[3][FM][FN];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
@@ -761,32 +767,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
             const bool more = kt + 1 < kt_end;
             if (more) load_global(buf ^ 1);
             compute_offsets(kt + 2, buf);
-            const float* Ab = As + buf * BK * BM + wm * 64 + li;
-            const float* Bb = Bs + buf * BX * BN + wn * 64 + li;
+            const float* Ab = As + buf * BK * BM + wm * FM * 32 + li;
+            const float* Bb = Bs + buf * BX * BN + wn * FN * 32 + li;
             // lane half h walks pixels k = 2*ks + h; tap kx reads x entry k + kx.  Entry k+2 of this step is entry
             // (k+2)+0 of the next one: carried over in registers.
-            float fb0[2], fb1[2], fb2[2];
+            float fb0[FN], fb1[FN], fb2[FN];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { fb0[j] = Bb[h * BN + j * 32]; fb1[j] = Bb[(h + 1) * BN + j * 32]; }
+            for (int j = 0; j < FN; ++j) { fb0[j] = Bb[h * BN + j * 32]; fb1[j] = Bb[(h + 1) * BN + j * 32]; }
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
                 const int k = 2 * ks + h;
-                float fa[2];
+                float fa[FM];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = Ab[k * BM + i * 32];
+                for (int i = 0; i < FM; ++i) fa[i] = Ab[k * BM + i * 32];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb2[j] = Bb[(k + 2) * BN + j * 32];
+                for (int j = 0; j < FN; ++j) fb2[j] = Bb[(k + 2) * BN + j * 32];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < FN; ++j) {
                         acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb0[j], acc[0][i][j], 0, 0, 0);
                         acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb1[j], acc[1][i][j], 0, 0, 0);
                         acc[2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb2[j], acc[2][i][j], 0, 0, 0);
                     }
                 if (ks + 1 < BK / 2) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) { fb0[j] = fb2[j]; fb1[j] = Bb[(k + 3) * BN + j * 32]; }
+                    for (int j = 0; j < FN; ++j) { fb0[j] = fb2[j]; fb1[j] = Bb[(k + 3) * BN + j * 32]; }
                 }
             }
             if (more) store_lds(buf ^ 1);
@@ -797,14 +803,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ci = ci0 + (wn * 2 + j) * 32 + li;
+        for (int j = 0; j < FN; ++j) {
+            const int ci = ci0 + (wn * FN + j) * 32 + li;
             if (ci >= p.Cin) continue;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int co = co0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (co < p.Cout) part[((int64_t)co * 9 + ky * 3 + t) * p.Cin + ci] = acc[t][i][j][r];
                 }
         }
@@ -1224,16 +1230,18 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     const int row3 = row3_env ? atoi(row3_env) : 1;
     if (row3 && erd_wgrad_row3_slices(d) > 0) {
         const int nslices = erd_wgrad_row3_slices(d);
-        const int nci = (d->Cin + 127) / 128, nco = (d->Cout + 127) / 128;
+        const int bme = d->Cout <= 64 ? 64 : (d->Cout <= 96 ? 96 : 128);
+        const int nci = (d->Cin + 127) / 128, nco = (d->Cout + bme - 1) / bme;
         const size_t lds = (size_t)2 * (16 * 128 + 18 * 128) * sizeof(float) + 2 * (16 + 18) * sizeof(int);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_row3_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
+        void (*kern)(const erd_wgrad_desc, const int) =
+            bme == 64 ? conv_wgrad_row3_kernel<1, 2, 1> : (bme == 96 ? conv_wgrad_row3_kernel<1, 3, 1> : conv_wgrad_row3_kernel<2, 2, 2>);
+        static bool attr_done[3] = {false, false, false};
+        const int vi = bme == 64 ? 0 : (bme == 96 ? 1 : 2);
+        if (!attr_done[vi]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done[vi] = true;
         }
-        hipLaunchKernelGGL(conv_wgrad_row3_kernel, dim3(nci * 3 * nco * d->nsplit), dim3(NTHREADS), lds,
-                           (hipStream_t)stream, *d, nslices);
+        hipLaunchKernelGGL(kern, dim3(nci * 3 * nco * d->nsplit), dim3(NTHREADS), lds, (hipStream_t)stream, *d, nslices);
         return erd::check_launch("conv_wgrad_row3");
     }
     if (variant == 0) return launch_wgrad<32, 2>(d, (hipStream_t)stream);

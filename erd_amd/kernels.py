@@ -495,7 +495,8 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     row3 = int(_lib.load().erd_wgrad_row3_slices(C.byref(d))) if _os.environ.get("ERD_WGRAD_ROW3", "1") != "0" else 0
     if row3:      # three taps per workgroup, two workgroups per CU: ONE whole dispatch round of (cout, cin, ky, split) workgroups
         # (measured best: 2 or 3 rounds pay more partial-slab traffic than they gain; a ragged extra round costs 15-40 %)
-        groups = ((Cout + 127) // 128) * ((Cin + 127) // 128) * 3
+        bme = 64 if Cout <= 64 else (96 if Cout <= 96 else 128)        # rows of the kernel's output tile (erd_conv_wgrad)
+        groups = ((Cout + bme - 1) // bme) * ((Cin + 127) // 128) * 3
         target = int(_os.environ.get("ERD_WGRAD_ROW3_TARGET", "512"))
         S = int(max(1, min(target // groups, row3 // 16 if row3 >= 16 else 1, 512)))     # floor: whole dispatch rounds
     else:

@@ -344,7 +344,7 @@ def test_conv_wgrad_bf16_multilevel(K, bf16_mode):
     assert relerr(dW.cpu(), ref.permute(0, 2, 3, 1)) < 2e-5
 
 
-@pytest.mark.parametrize("Cin,Co", [(256, 256), (256, 80), (64, 68), (320, 136)])
+@pytest.mark.parametrize("Cin,Co", [(256, 256), (256, 80), (64, 68), (320, 136), (128, 40), (256, 64)])
 def test_conv_wgrad_fp32_multilevel_three_tap_kernel(K, Cin, Co, monkeypatch):
     """3x3 / stride 1 weight gradient over the head's five concatenated levels: the three-taps-per-workgroup kernel
     (16-pixel row chunks with halo; widths 28 / 14 / 7 / 4 / 2 exercise partial chunks and rows narrower than a chunk)
