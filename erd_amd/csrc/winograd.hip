@@ -233,12 +233,13 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             fbo[j][1] = (base + (unsigned)(it.cb1 * (Cin / 4) + h) * 32u + (unsigned)li) * 16u;
         }
     };
-    auto load_fb = [&](const unsigned (&fbo)[4][2], int ks_, int kk, float4 (&f)[4][2]) {
+    auto load_fb = [&](const unsigned (&fbo)[4][2], int ks_, int kk, float4 (&f)[4][2], bool two) {
         const unsigned soff = (unsigned)(min(ks_, nks - 1) * (KS / 4) + 2 * kk) * 512u;      // 32 lanes x 16 B per chunk
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f[j][0] = buf_load16_s(rs_U, fbo[j][0], soff);
-            f[j][1] = buf_load16_s(rs_U, fbo[j][1], soff);
+        for (int j = 0; j < 4; ++j) f[j][0] = buf_load16_s(rs_U, fbo[j][0], soff);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j][1] = buf_load16_s(rs_U, fbo[j][1], soff);
         }
     };
 
@@ -299,8 +300,11 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         float4 fb[2][4][2];                                 // [k-step][position][cout sub-tile]
         unsigned fbo[4][2], nfbo[4][2];
         fb_offsets(cur, fbo);
-        load_fb(fbo, 0, 0, fb[0]);
-        load_fb(fbo, 0, 1, fb[1]);
+        // an item whose second 32-channel sub-block lies beyond Cout (Cout = 40 / 68 / 80 heads: 64+4, 64+16) skips that
+        // sub-block's weight fragments and MFMAs: half the matrix work of the item
+        bool two = cur.cout0 + 32 < p.Cout;
+        load_fb(fbo, 0, 0, fb[0], true);
+        load_fb(fbo, 0, 1, fb[1], true);
         for (;;) {
             f32x16 acc[4][2];
 #pragma unroll
@@ -331,14 +335,18 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
                 for (int kk = 0; kk < 2; ++kk) {
                     if (!(p.dbg & 4)) {
 #define ERD_WMFMA(m)                                                                                              \
-                        _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < 2; ++q)  \
-                            acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][j].m, fb[kk][j][q].m, acc[j][q], 0, 0, 0);
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+                            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][j].m, fb[kk][j][0].m, acc[j][0], 0, 0, 0); \
+                        if (two) {                                                                                    \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+                                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][j].m, fb[kk][j][1].m, acc[j][1], 0, 0, 0); \
+                        }
                         ERD_WMFMA(x) ERD_WMFMA(y) ERD_WMFMA(z) ERD_WMFMA(w)
 #undef ERD_WMFMA
                     }
                     if (!(p.dbg & 2)) {
-                        if (last) load_fb(nfbo, 0, kk, fb[kk]);
-                        else load_fb(fbo, ks + 1, kk, fb[kk]);
+                        if (last) load_fb(nfbo, 0, kk, fb[kk], true);      // (the next item may need both sub-blocks)
+                        else load_fb(fbo, ks + 1, kk, fb[kk], two);
                     }
                 }
                 __syncthreads();
@@ -363,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             }
             item = nxt_item;
             cur = nxt;
+            two = cur.cout0 + 32 < p.Cout;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { fbo[j][0] = nfbo[j][0]; fbo[j][1] = nfbo[j][1]; }
             __syncthreads();                                // Zs consumed: the operand buffers may be refilled
