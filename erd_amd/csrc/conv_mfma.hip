@@ -397,6 +397,19 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
         for (int half = 0; half < WAVES_M; ++half) {
             __syncthreads();                                    // operand tiles / previous half fully consumed
+            // residual / ReLU-mask rows of this half are requested NOW: their latency hides behind the staging below
+            // (inside the store loop every row would wait for its own load: ~1 us x 8 dependent iterations per half)
+            constexpr int NPF = (FM * 32) / RPS;
+            constexpr bool PREFETCH = MINW <= 3;                // (four workgroups per CU: 128 registers, no room)
+            float4 pf[PREFETCH ? NPF : 1];                      // residual rows, or mask rows when there is no residual
+            const float* pf_src = res ? res : msk;
+            if (PREFETCH && pf_src && (p.Cout & 3) == 0 && n0 + (tid % C4N) * 4 < p.Cout) {
+#pragma unroll
+                for (int q = 0; q < NPF; ++q) {
+                    const int oo = rows[half * FM * 32 + tid / C4N + q * RPS].out_off;
+                    if (oo >= 0) pf[PREFETCH ? q : 0] = *reinterpret_cast<const float4*>(pf_src + oo + n0 + (tid % C4N) * 4);
+                }
+            }
             if (wm == half) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
@@ -437,19 +450,21 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
                 if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
                 float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int rr = tid / C4N; rr < FM * 32; rr += RPS) {
+#pragma unroll
+                for (int q = 0; q < NPF; ++q) {
+                    const int rr = tid / C4N + q * RPS;
                     const int oo = rows[half * FM * 32 + rr].out_off;
                     if (oo < 0) continue;
                     float4 v = *reinterpret_cast<const float4*>(stage + rr * SLD + c4 * 4);
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                     if (has_alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
                     if (res) {
-                        const float4 rv = *reinterpret_cast<const float4*>(res + oo + co);
+                        const float4 rv = PREFETCH ? pf[PREFETCH ? q : 0] : *reinterpret_cast<const float4*>(res + oo + co);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (msk) {      // gradient of the ReLU that produced this tensor's forward twin (fused dz = dy*(y>0))
-                        const float4 mv = *reinterpret_cast<const float4*>(msk + oo + co);
+                        const float4 mv = (PREFETCH && !res) ? pf[PREFETCH ? q : 0] : *reinterpret_cast<const float4*>(msk + oo + co);
                         v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
                         v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
                     }
