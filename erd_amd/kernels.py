@@ -451,8 +451,8 @@ def _shape_tag(d, k: int, stride: int) -> str:
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * ntaps
     kt = (npix + 31) // 32
-    target = 1024 if _os.environ.get("ERD_WGRAD_VARIANT", "1") == "0" else 2048
-    want = max(1, (target + tiles - 1) // tiles)          # two dispatch rounds of 4 workgroups per CU
+    target = 1024 if _os.environ.get("ERD_WGRAD_VARIANT", "1") == "0" else int(_os.environ.get("ERD_WGRAD_TARGET", "1024"))
+    want = max(1, target // tiles)          # ONE whole dispatch round of 4 workgroups per CU (measured: two rounds pay more partial-slab traffic than they gain; never a ragged extra round)
     return int(max(1, min(want, kt // 8 if kt >= 8 else 1, 512)))
 
 
