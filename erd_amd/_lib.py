@@ -23,7 +23,8 @@ f32 = C.c_float
 class ConvSeg(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("res", C.c_void_p), ("alpha", C.c_void_p),
                 ("mask", C.c_void_p), ("N", i32), ("IH", i32), ("IW", i32), ("GH", i32), ("GW", i32), ("OH", i32), ("OW", i32),
-                ("in_nstride", i64), ("out_nstride", i64), ("res_nstride", i64)]
+                ("in_nstride", i64), ("out_nstride", i64), ("res_nstride", i64),
+                ("tap0", i32), ("ntaps", i32), ("oy", i32), ("ox", i32)]
 
 
 class ConvDesc(C.Structure):

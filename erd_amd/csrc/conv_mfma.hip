@@ -79,7 +79,7 @@ int xcd_order_enabled() {
 // k-values instead of 4 floats (a K-slice is CH*8 values), activations are read as fp32 (two 16-B loads per chunk)
 // and rounded to bf16 on their way into LDS, weights come pre-rounded (erd_conv_desc::w_bf16); accumulation, the
 // stream-K hand-over and the epilogue stay fp32.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false, bool ST = false>
 __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
                                                                      const SkWs ws) {
     constexpr int FM = BM / (WAVES_M * 32);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     for (long long u = u_begin; u < u_end;) {
         const int tt = (int)(u / nkt);
         const int ks = (int)(u - (long long)tt * nkt);
-        const int ke = (int)min((long long)nkt, ks + (u_end - u));
+        int ke = (int)min((long long)nkt, ks + (u_end - u));
         u += ke - ks;
         const int nt = tt % ntn;
         int mt = tt / ntn;
@@ -148,6 +148,15 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         const erd_conv_seg& sg = p.seg[s];
         const int IH = sg.IH, IW = sg.IW;
         const float* __restrict__ in = sg.in;
+        // per-segment tap set (parity classes of a stride-2 input gradient in one launch): fewer K-slices for this tile
+        // (ST: only the instantiation that serves such launches carries the extra scalars)
+        const int tap_lo = (ST && sg.ntaps) ? sg.tap0 : 0, nt_s = (ST && sg.ntaps) ? sg.ntaps : p.ntaps;
+        const int oy_s = (ST && sg.ntaps) ? sg.oy : p.oy, ox_s = (ST && sg.ntaps) ? sg.ox : p.ox;
+        const int nkt_t = ST ? nt_s * cpt : nkt;
+        if (ST) {
+            ke = min(ke, nkt_t);
+            if (ks >= ke) continue;
+        }
 
         __syncthreads();   // previous tile's epilogue / fragment reads are done with LDS
         if (tid < BM) {
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 ri.ih0 = a * p.in_stride;
                 ri.iw0 = b * p.in_stride;
                 ri.out_off = (int)(n * sg.out_nstride) +
-                             ((a * p.out_stride + p.oy) * sg.OW + (b * p.out_stride + p.ox)) * p.Cout;
+                             ((a * p.out_stride + oy_s) * sg.OW + (b * p.out_stride + ox_s)) * p.Cout;
             } else {
                 ri.in_off = 0;
                 ri.ih0 = -(1 << 28);
@@ -183,8 +192,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             const RowInfo ri = rows[r0 + RPP * j];
             a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk * KPC) * 4u;
             unsigned m = 0;
-            for (int t = 0; t < p.ntaps; ++t) {
-                const int ih = ri.ih0 + p.dy[t], iw = ri.iw0 + p.dx[t];
+            for (int t = 0; t < nt_s; ++t) {
+                const int ih = ri.ih0 + p.dy[tap_lo + t], iw = ri.iw0 + p.dx[tap_lo + t];
                 m |= ((unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW) ? (1u << t) : 0u;
             }
             a_mask[j] = m;
@@ -211,8 +220,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         auto slice_begin = [&]() {
             const int cb = cc * BK;
             ctap = tap;
-            adelta = ((p.dy[tap] * IW + p.dx[tap]) * Cin + cb) * 4;    // bytes, relative to tap (0,0)
-            bdelta = (p.wk[tap] + cb) * (BF ? 2 : 4);
+            adelta = ((p.dy[tap_lo + tap] * IW + p.dx[tap_lo + tap]) * Cin + cb) * 4;    // bytes, relative to tap (0,0)
+            bdelta = (p.wk[tap_lo + tap] + cb) * (BF ? 2 : 4);
             cok = cb + chunk * KPC < Cin;   // Cin % 4 == 0: a 4-value group is all-in or all-out
             cok1 = BF && cb + chunk * KPC + 4 < Cin;
             if (++cc == cpt) { cc = 0; ++tap; }
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         }
 
         // ---- partial tile: hand the accumulators over; the last contributor to arrive reduces ----------
-        if (ks != 0 || ke != nkt) {
+        if (ks != 0 || ke != nkt_t) {
             const long long t0 = (long long)tt * nkt;
             const int first_b = (int)(((t0 + 1) * G - 1) / U);
             const int last_b = (int)(((t0 + nkt) * G - 1) / U);
@@ -1077,7 +1086,7 @@ int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false>
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     constexpr int BK = (BKT / 4) * (BF ? 8 : 4);
     int tiles = 0;
@@ -1091,7 +1100,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
     const size_t oper = (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4), stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
     const size_t lds = (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1116,7 +1125,10 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     static const int min_slices = getenv("ERD_SK_MIN_SLICES") ? atoi(getenv("ERD_SK_MIN_SLICES")) : 8;
     const int64_t units = (int64_t)tiles * nkt;
     const bool tiny = units < slots && min_slices > 0 && nkt >= 2 * min_slices && !BF;
-    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && nkt * BKT >= 512 && (units >= slots || tiny)) {
+    bool seg_taps = false;           // per-segment tap sets: tiles have different K lengths -> whole tiles only,
+    for (int s = 0; s < d->nseg; ++s) seg_taps |= d->seg[s].ntaps > 0;     // dealt round-robin over the XCDs (a contiguous
+    if (seg_taps) ws.xcd_order = 0;  // chunk per XCD would hand one XCD all the 4-tap tiles and another all the 1-tap ones)
+    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && !seg_taps && nkt * BKT >= 512 && (units >= slots || tiny)) {
         G = (int)std::min<int64_t>(slots, min_slices > 0 ? std::max<int64_t>(tiles, units / min_slices) : slots);
         ws.slabs = reinterpret_cast<float*>(d->sk_ws);
         ws.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(d->sk_ws) + slab_bytes);
@@ -1141,6 +1153,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     for (int s = 0; s < d->nseg; ++s) {
         const erd_conv_seg& g = d->seg[s];
         ERD_REQUIRE(g.in && g.out, "conv: null tensor in segment %d", s);
+        ERD_REQUIRE(g.ntaps >= 0 && g.tap0 >= 0 && g.tap0 + g.ntaps <= ERD_MAX_TAPS && g.ntaps <= d->ntaps,
+                    "conv: segment %d tap set [%d, %d) (launch ntaps %d)", s, g.tap0, g.tap0 + g.ntaps, d->ntaps);
         ERD_REQUIRE((int64_t)g.N * g.in_nstride < (1ll << 29) && (int64_t)g.N * g.out_nstride < (1ll << 31),
                     "conv: segment %d too large (input must stay below 2 GiB: 32-bit buffer byte offsets)", s);
     }
@@ -1149,6 +1163,10 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     // kernel; short ones (1x1 convs on <=256 channels) are prologue/epilogue-latency bound and want many small
     // co-resident workgroups (BK=16, half the LDS and staging registers -> 4 workgroups per CU).
     static const int variant = getenv("ERD_IGEMM_VARIANT") ? atoi(getenv("ERD_IGEMM_VARIANT")) : 0;   // tuning aid
+    bool seg_taps_any = false;
+    for (int s = 0; s < d->nseg; ++s) seg_taps_any |= d->seg[s].ntaps > 0;
+    if (seg_taps_any)   // per-segment tap sets (merged parity classes): one dedicated instantiation per precision
+        return d->w_bf16 ? launch_igemm<128, 128, 2, 2, 32, 2, true, true>(d, st) : launch_igemm<128, 128, 2, 2, 32, 2, false, true>(d, st);
     if (d->w_bf16) {    // bf16 matrix cores: the loaders, not the MFMAs, set the pace -> the plain 2-workgroup variant
         if (variant == 2) return launch_igemm<128, 128, 2, 2, 16, 4, true>(d, st);
         if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2, true>(d, st);

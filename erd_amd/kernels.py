@@ -396,6 +396,9 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         wtb = wt if wt.dtype == torch.bfloat16 else to_bf16(wt)
     elif wt.dtype != torch.float32:
         raise ValueError("conv_dgrad: bf16 weights in f32 compute mode")
+    if stride == 2 and k == 3 and len(dzs) == 1 and MERGE_PARITY:
+        _dgrad_s2_merged(dzs[0], wt, wtb, dxs[0], pad, Cin, Cout, accumulate, res, relu_mask, colsum)
+        return
     classes = [(0, 0)] if stride == 1 else [(py, px) for py in range(stride) for px in range(stride)]
     for (py, px) in classes:
         taps = []
@@ -441,6 +444,52 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
                         (stride * stride)) if _TIMING is not None else 0.0
         _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes,
                     tag=(_shape_tag(d, k, stride) + f" class{py}{px}") if TIMING_DETAIL else "")
+
+
+MERGE_PARITY = _os.environ.get("ERD_MERGE_PARITY", "1") != "0"
+
+
+def _dgrad_s2_merged(dz: Tensor, wt: Tensor, wtb, dx: Tensor, pad: int, Cin: int, Cout: int, accumulate: bool, res,
+                     relu_mask, colsum) -> None:
+    """The four output-parity classes of a 3x3 / stride-2 input gradient (4 + 2 + 2 + 1 taps) as four segments of ONE
+    launch with per-segment tap sets: ~1000 tiles of mixed length in one grid instead of four ragged launches of ~260."""
+    k, stride = 3, 2
+    d = ConvDesc()
+    nseg, tap0, flop = 0, 0, 0.0
+    for (py, px) in ((1, 1), (0, 1), (1, 0), (0, 0)):              # longest K loops first
+        taps = [((py + pad - kh) // stride, (px + pad - kw) // stride, (kh * k + kw) * Cout)
+                for kh in range(k) if (py + pad - kh) % stride == 0
+                for kw in range(k) if (px + pad - kw) % stride == 0]
+        GH = (dx.shape[1] - py + stride - 1) // stride
+        GW = (dx.shape[2] - px + stride - 1) // stride
+        if not taps or GH <= 0 or GW <= 0:
+            continue
+        sg = d.seg[nseg]
+        r = dx if accumulate else (None if res is None else res[0])
+        _fill_seg(sg, dz, dx, GH, GW, r, None, None if relu_mask is None else relu_mask[0])
+        sg.tap0, sg.ntaps, sg.oy, sg.ox = tap0, len(taps), py, px
+        for t, (dy, dx_, wk) in enumerate(taps):
+            d.dy[tap0 + t], d.dx[tap0 + t], d.wk[tap0 + t] = dy, dx_, wk
+        tap0 += len(taps)
+        flop += 2.0 * sg.N * GH * GW * Cin * len(taps) * Cout
+        nseg += 1
+    if nseg == 0:
+        return
+    d.nseg = nseg
+    d.ntaps = max(d.seg[i].ntaps for i in range(nseg))
+    d.w = wt.data_ptr() if wtb is None else 0
+    d.Cin, d.Cout, d.wrow = Cout, Cin, k * k * Cout     # roles swap: contraction over Cout
+    d.in_stride, d.out_stride, d.oy, d.ox = 1, stride, 0, 0
+    d.scale = d.shift = 0
+    d.relu = 0
+    d.colsum = 0 if colsum is None else colsum.data_ptr()
+    d.colsum_copies = 0 if colsum is None else colsum.numel() // Cin
+    if wtb is not None:
+        d.w_bf16 = wtb.data_ptr()
+    d.sk_ws, d.sk_ws_bytes = 0, 0
+    nbytes = 4.0 * (dz.numel() + dx.numel() + wt.numel()) if _TIMING is not None else 0.0
+    _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes,
+                tag=(_shape_tag(d, k, stride) + " merged") if TIMING_DETAIL else "")
 
 
 def _shape_tag(d, k: int, stride: int) -> str:

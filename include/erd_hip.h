@@ -56,6 +56,11 @@ typedef struct {
                           * of the tensor whose gradient this launch produces) */
     int N, IH, IW, GH, GW, OH, OW;
     int64_t in_nstride, out_nstride, res_nstride;
+    /* optional per-segment tap set (ntaps > 0): this segment uses taps [tap0, tap0 + ntaps) of the launch's dy/dx/wk
+     * arrays and its own output offset (oy, ox) -- the four parity classes of a stride-2 input gradient (1 + 2 + 2 + 4
+     * taps of a 3x3 kernel) then run as four segments of ONE launch; erd_conv_desc::ntaps must be the largest count.
+     * ntaps == 0: the launch-wide taps and (oy, ox). */
+    int tap0, ntaps, oy, ox;
 } erd_conv_seg;
 
 typedef struct {
