@@ -281,7 +281,8 @@ class ERDTrainer:
             self._apply_pending()
             self.flat.zero_grad()
             K.zero_arena_begin(self.device)
-            s_cls, s_bbox, sizes = model._forward_cat(inputs)
+            with K.distillation_forward():
+                s_cls, s_bbox, sizes = model._forward_cat(inputs)
             cur.wait_stream(self.side)
             for t in teacher_out.tensors():
                 t.record_stream(cur)

@@ -134,6 +134,7 @@ class ConvBNAct(Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, mean, var, res, k: int, stride: int, pad: int, relu: bool, eps: float):
+        K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         wk = ohwi(w)
         scale, shift = _bn_fold_cached(gamma, beta, mean, var, eps)
         N, H, W_, _ = x.shape
@@ -184,6 +185,7 @@ class BottleneckFn(Function):
 
     @staticmethod
     def forward(ctx, x, stride: int, eps: float, *params):
+        K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         # params: (w,g,b,mean,var) x {conv1,conv2,conv3[,downsample]}
         has_down = len(params) == 20
         P = [params[5 * i:5 * i + 5] for i in range(4 if has_down else 3)]
@@ -300,6 +302,7 @@ class ConvBias(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, k: int, stride: int, pad: int):
+        K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         wk = ohwi(w)
         N, H, W_, _ = x.shape
         OH, OW = K.conv_out_size(H, k, stride, pad), K.conv_out_size(W_, k, stride, pad)
@@ -357,6 +360,7 @@ class FPNOutputs(Function):
 
     @staticmethod
     def forward(ctx, l3, l4, l5, w0, w1, w2, w3, w4, b0, b1, b2, b3, b4):
+        K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         lats = [l3, l4, l5]
         ws = [w0, w1, w2, w3, w4]
         bs = [b0, b1, b2, b3, b4]
@@ -418,6 +422,7 @@ class HeadConvGN(Function):
 
     @staticmethod
     def forward(ctx, x_cat, w, gamma, beta, sizes, eps: float):
+        K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         wk = ohwi(w)
         c = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=torch.float32, device=x_cat.device)
         K.conv_forward(K.level_views(x_cat, sizes), wk, K.level_views(c, sizes), 3, 1, 1)
@@ -451,6 +456,7 @@ class HeadConvBias(Function):
 
     @staticmethod
     def forward(ctx, x_cat, w, b, sizes):
+        K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         wk = ohwi(w)
         out = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=torch.float32, device=x_cat.device)
         K.conv_forward(K.level_views(x_cat, sizes), wk, K.level_views(out, sizes), 3, 1, 1, shift=b.detach())

@@ -157,11 +157,14 @@ def test_full_size_teacher_logits_and_ers_sets_vs_oracle():
 def test_full_size_step_losses_and_gradients_vs_oracle():
     """BASELINE size (800x1333 -> 800x1344, 22 400 anchors), one image: the WHOLE step -- teacher, ERS, NMS, student,
     all five loss groups and every parameter gradient -- against the CPU oracle on the same procedural weights and
-    demo_mm_inputs-style sample.  Losses 1e-3 (north_star's tolerance; observed 1e-5) and the ERS index sets bit-exact.
-    Gradients per tensor in relative L2 norm: at this size ~1e8 ReLU decisions sit in front of every gradient and a
-    fraction ~1e-6 of them flips under ANY change of fp32 summation order, which moves every gradient tensor by
-    ~1.5e-3 -- the test measures that floor itself (the same step with the direct kernels instead of Winograd: same
-    losses to 1e-6) and requires the distance to the oracle to be of that order (median < 5e-3, < 4x the floor)."""
+    demo_mm_inputs-style sample.  Losses 1e-3 (north_star's tolerance; observed 1e-5), ERS index sets bit-exact,
+    gradients within 1e-3 in relative L2 norm (median over the 175 tensors and over all elements together).
+
+    The distillation gradients are differences (student - teacher) of nearly equal logits here (student = teacher + 2 %
+    weight noise), which amplifies the teacher's rounding error by |t| / |s - t|: with the teacher's 3x3 convolutions
+    on the direct kernels (the default) the gradients sit ~7e-4 from the oracle, with ALL kernels direct 2e-4, with the
+    teacher on the Winograd kernels (kernels.WINO_TEACHER, 5 % faster) 1.5e-3 -- the second half of the test pins that
+    documented trade-off (< 5e-3) so that it cannot drift silently."""
     import numpy as np
     from oracle import erd_oracle as O
     from erd_amd import kernels as K
@@ -170,15 +173,14 @@ def test_full_size_step_losses_and_gradients_vs_oracle():
     tsd, ssd = f7_state_dicts()
     imgs, boxes, labels = O.synthetic_batch(1, 800, 1333, 40, seed=7)
     x, metas = O.preprocess(imgs)
-    torch.set_num_threads(min(16, torch.get_num_threads()))
     sd = {k: (v.clone().requires_grad_(True) if O.trainable(k) and v.dtype == torch.float32 else v) for k, v in ssd.items()}
     ref_losses, aux = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80, return_aux=True)
     O.parse_losses(ref_losses).backward()
     names = [k for k, v in sd.items() if O.trainable(k) and v.dtype == torch.float32]
+    ref = {k: sd[k].grad.double() for k in names}
 
-    def gpu_step(winograd: bool):
-        old = K.WINOGRAD
-        K.WINOGRAD = winograd
+    def gpu_step(wino_teacher: bool):
+        keep, K.WINO_TEACHER = K.WINO_TEACHER, wino_teacher
         try:
             model = build_erd(tsd, ssd)
             losses = model(x.cuda(), make_samples(boxes, labels, metas), mode="loss")
@@ -190,15 +192,7 @@ def test_full_size_step_losses_and_gradients_vs_oracle():
                 t = model.teacher_pass(x.cuda())
             return {k: [float(v.detach()) for v in vs] for k, vs in losses.items()}, grads, t
         finally:
-            K.WINOGRAD = old
-
-    losses, grads, t = gpu_step(True)
-    _, grads_direct, _ = gpu_step(False)
-    for k, vs in ref_losses.items():
-        assert np.allclose(losses[k], [float(v) for v in vs], rtol=1e-3, atol=1e-7), (k, losses[k], vs)
-    cnt = t.ers["counts"].cpu()
-    assert torch.equal(t.ers["idx_cls"][0, :int(cnt[0, 0])].cpu(), aux["ers_cls"][0])
-    assert torch.equal(t.ers["idx_bbox"][0, :int(cnt[0, 1])].cpu(), aux["ers_bbox"][0])
+            K.WINO_TEACHER = keep
 
     def dist(ga, gb):
         errs, num, den = [], 0.0, 0.0
@@ -209,10 +203,14 @@ def test_full_size_step_losses_and_gradients_vs_oracle():
                 errs.append(float((a - b).norm() / b.norm()))
         return float(np.median(errs)), max(errs), (num / den) ** 0.5
 
-    ref = {k: sd[k].grad.double() for k in names}
-    med, mx, glob = dist(grads, ref)
-    fmed, fmx, fglob = dist(grads, grads_direct)
-    print("full-size step: %d gradient tensors; vs oracle: rel L2 median %.2e max %.2e global %.2e; "
-          "Winograd vs direct kernels (the rounding floor): median %.2e max %.2e global %.2e" %
-          (len(names), med, mx, glob, fmed, fmx, fglob))
-    assert med < 5e-3 and glob < 2e-2 and med < 4 * max(fmed, 5e-4), (med, glob, fmed)
+    for wino_teacher, tol in ((False, 1e-3), (True, 5e-3)):
+        losses, grads, t = gpu_step(wino_teacher)
+        for k, vs in ref_losses.items():
+            assert np.allclose(losses[k], [float(v) for v in vs], rtol=1e-3, atol=1e-7), (k, losses[k], vs)
+        cnt = t.ers["counts"].cpu()
+        assert torch.equal(t.ers["idx_cls"][0, :int(cnt[0, 0])].cpu(), aux["ers_cls"][0])
+        assert torch.equal(t.ers["idx_bbox"][0, :int(cnt[0, 1])].cpu(), aux["ers_bbox"][0])
+        med, mx, glob = dist(grads, ref)
+        print("full-size step, unrecorded convolutions (teacher, frozen trunk) on %s kernels: %d gradient tensors vs oracle: rel L2 median %.2e max %.2e global %.2e"
+              % ("Winograd" if wino_teacher else "direct", len(names), med, mx, glob))
+        assert med < tol and glob < tol, (wino_teacher, med, glob, mx)
