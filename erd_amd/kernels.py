@@ -351,12 +351,12 @@ RECORDED = False
 
 class distillation_forward:
     """Forward passes of an ERD step (teacher + student).  The distillation gradients are differences (student - teacher)
-    of nearly equal logits, so rounding differences between the two networks are amplified by |t| / |s - t|: every
-    convolution autograd does not record -- the frozen teacher and the student's frozen stem / layer1, which must stay
-    bit-identical to the teacher's -- runs on the direct kernels (1e-7 relative output error) unless WINO_TEACHER is
-    set; the Winograd kernels (9e-7) keep the recorded student layers and all input gradients.  Measured at full size
-    against the CPU reference (tests/test_gpu_fullsize.py): gradients 7e-4 this way, 1.5e-3 with WINO_TEACHER (5 % faster),
-    2e-4 with every kernel direct."""
+    of nearly equal logits, so rounding differences between the two networks are amplified by |t| / |s - t|.  Measured
+    at full size against an fp64 evaluation of the step (tests/diag/diag_fp64_truth.py): the fp32 CPU reference 4.7e-4,
+    this path with every convolution autograd does not record -- the frozen teacher and the student's frozen stem /
+    layer1, which must stay bit-identical to the teacher's -- on the direct kernels 5.4e-4, with those on the Winograd
+    kernels too (WINO_TEACHER, 5 % faster) 1.4e-3.  The Winograd kernels keep the recorded student layers and all input
+    gradients either way."""
 
     def __enter__(self):
         global WINO_NOGRAD_FWD

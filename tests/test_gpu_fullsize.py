@@ -161,10 +161,11 @@ def test_full_size_step_losses_and_gradients_vs_oracle():
     gradients within 1e-3 in relative L2 norm (median over the 175 tensors and over all elements together).
 
     The distillation gradients are differences (student - teacher) of nearly equal logits here (student = teacher + 2 %
-    weight noise), which amplifies the teacher's rounding error by |t| / |s - t|: with the teacher's 3x3 convolutions
-    on the direct kernels (the default) the gradients sit ~7e-4 from the oracle, with ALL kernels direct 2e-4, with the
-    teacher on the Winograd kernels (kernels.WINO_TEACHER, 5 % faster) 1.5e-3 -- the second half of the test pins that
-    documented trade-off (< 5e-3) so that it cannot drift silently."""
+    weight noise), which amplifies rounding differences between the two networks by |t| / |s - t|.  With every
+    convolution autograd does not record (teacher, frozen trunk) on the direct kernels -- the default -- the gradients
+    sit ~7e-4 from the oracle (5e-4 from an fp64 evaluation, as close as the fp32 CPU reference itself:
+    tests/diag/diag_fp64_truth.py); with those on the Winograd kernels too (kernels.WINO_TEACHER, 5 % faster) 1.5e-3 --
+    the second half of the test pins that documented trade-off (< 5e-3) so that it cannot drift silently."""
     import numpy as np
     from oracle import erd_oracle as O
     from erd_amd import kernels as K
