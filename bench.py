@@ -127,9 +127,6 @@ def main():
     ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
                     help="f32: fp32 matrix cores (BASELINE configs[1], the headline).  bf16: the 1x1/3x3 convolutions on the "
                          "bf16 matrix cores, fp32 accumulation and storage (BASELINE configs[2])")
-    ap.add_argument("--fast-teacher", action="store_true",
-                    help="frozen teacher's 3x3 convolutions on the Winograd kernels too: +5 %, but the distillation gradients "
-                         "then sit 1.5e-3 from the CPU reference instead of 7e-4 (DESIGN.md 3, tests/test_gpu_fullsize.py)")
     ap.add_argument("--serial", action="store_true",
                     help="no stream concurrency in the timed region either (the rocprofv3 companion run)")
     args = ap.parse_args()
@@ -152,7 +149,6 @@ def main():
     from erd_amd import kernels as K
     from erd_amd.engine import ERDTrainer
     K.set_compute(args.compute)
-    K.WINO_TEACHER = K.WINO_TEACHER or args.fast_teacher
     model, cfg = build_model(device, rank)
     opt = cfg.optim_wrapper.optimizer
     trainer = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
@@ -217,8 +213,7 @@ def main():
                                    ", procedural weights", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
-            "teacher": ("hipGraph replay" if args.teacher_graph else "eager launches") +
-                       (", Winograd 3x3 (fast teacher)" if K.WINO_TEACHER else ", direct 3x3 (gradients within 1e-3 of the CPU reference)"),
+            "teacher": "hipGraph replay" if args.teacher_graph else "eager launches",
         }
         if ktime:
             dom = max(ktime.values(), key=lambda r: r["ms"])

@@ -281,7 +281,7 @@ class ERDTrainer:
             self._apply_pending()
             self.flat.zero_grad()
             K.zero_arena_begin(self.device)
-            with K.distillation_forward():
+            with K.distillation_forward(K.WINO_FROZEN_TRUNK):
                 s_cls, s_bbox, sizes = model._forward_cat(inputs)
             cur.wait_stream(self.side)
             for t in teacher_out.tensors():

@@ -345,23 +345,27 @@ def _wino_sched(device) -> Tensor:
 WINO_TRAIN_FWD = _os.environ.get("ERD_WINO_TRAIN_FWD", "1") != "0"
 WINO_NOGRAD_FWD = _os.environ.get("ERD_WINO_NOGRAD_FWD", "1") != "0"
 WINO_DGRAD = _os.environ.get("ERD_WINO_DGRAD", "1") != "0"
-WINO_TEACHER = _os.environ.get("ERD_WINO_TEACHER", "0") == "1"
+WINO_TEACHER = _os.environ.get("ERD_WINO_TEACHER", "1") != "0"
+WINO_FROZEN_TRUNK = _os.environ.get("ERD_WINO_FROZEN_TRUNK", "0") == "1"
 RECORDED = False
 
 
 class distillation_forward:
-    """Forward passes of an ERD step (teacher + student).  The distillation gradients are differences (student - teacher)
-    of nearly equal logits, so rounding differences between the two networks are amplified by |t| / |s - t|.  Measured
-    at full size against an fp64 evaluation of the step (tests/diag/diag_fp64_truth.py): the fp32 CPU reference 4.7e-4,
-    this path with every convolution autograd does not record -- the frozen teacher and the student's frozen stem /
-    layer1, which must stay bit-identical to the teacher's -- on the direct kernels 5.4e-4, with those on the Winograd
-    kernels too (WINO_TEACHER, 5 % faster) 1.4e-3.  The Winograd kernels keep the recorded student layers and all input
-    gradients either way."""
+    """Scope in which the convolutions autograd does NOT record (a frozen teacher; the student's frozen stem / layer1)
+    may use the Winograd kernels or not.  Measured at full size (tests/diag/diag_wino_matrix.py, all 16 placements,
+    gradients against the CPU oracle): Winograd in the teacher and in the input gradients changes nothing (2.0e-4 with
+    every other kernel direct), in the student's recorded layers 7.2e-4, in the student's FROZEN TRUNK 1.5e-3 -- although
+    each of these layers is, taken alone, slightly closer to fp64 on Winograd than on the direct kernel
+    (tests/diag/diag_layer1_error.py): a perturbation of the student's earliest activations is amplified through all
+    trainable layers behind it.  Hence: teacher on Winograd (WINO_TEACHER), student trunk direct (WINO_FROZEN_TRUNK off)."""
+
+    def __init__(self, winograd=None):
+        self.winograd = WINO_FROZEN_TRUNK if winograd is None else winograd
 
     def __enter__(self):
         global WINO_NOGRAD_FWD
         self.keep = WINO_NOGRAD_FWD
-        WINO_NOGRAD_FWD = WINO_TEACHER
+        WINO_NOGRAD_FWD = self.winograd
         return self
 
     def __exit__(self, *exc):

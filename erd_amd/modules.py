@@ -862,7 +862,7 @@ class GFLIncrementERD(GFL):
         """the no-grad half of `loss` (:205-208): teacher forward, ERS, the NMS of the selected teacher boxes and
         (when the data samples are given) the ATSS targets -- everything that does not depend on the student's
         parameters, so the trainer runs it on a side stream."""
-        with K.distillation_forward():
+        with K.distillation_forward(K.WINO_TEACHER):
             t_cls, t_bbox, sizes = self.ori_model._forward_cat(batch_inputs)
         ers = self.sel_pos_cat(t_cls, t_bbox)
         anchors = self.bbox_head.prior_generator.grid_priors_cat(sizes, t_cls.device)
@@ -879,7 +879,7 @@ class GFLIncrementERD(GFL):
             with torch.no_grad():   # D6: the reference omits no_grad; teacher params are frozen => identical
                 teacher_out = self.teacher_pass(batch_inputs)
         t = teacher_out
-        with K.distillation_forward():
+        with K.distillation_forward(K.WINO_FROZEN_TRUNK):
             s_cls, s_bbox, sizes = self._forward_cat(batch_inputs)
         return self.bbox_head.loss_cat(t.t_cls, t.t_bbox, s_cls, s_bbox, sizes, batch_data_samples, t.ers, t.keep,
                                        self.ori_num_classes, self.dist_loss_weight, targets=t.targets)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size one-image ERD step: distance of the gradients of (a) the fp32 CPU oracle, (b) the HIP path with the teacher on
-the direct kernels, (c) the HIP path with the teacher on the Winograd kernels from an fp64 evaluation of the same step.
+the direct kernels, (c) the HIP path with the student trunk on the Winograd kernels from an fp64 evaluation of the same step.
 Answers: is the Winograd teacher less ACCURATE, or only less similar to the fp32 CPU reference's rounding pattern?"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +28,7 @@ def oracle(dtype):
 
 
 def gpu(wino_teacher):
-    keep, K.WINO_TEACHER = K.WINO_TEACHER, wino_teacher
+    keep, K.WINO_FROZEN_TRUNK = K.WINO_FROZEN_TRUNK, wino_teacher
     try:
         model = build_erd(tsd, ssd)
         losses = model(x.cuda(), make_samples(boxes, labels, metas), mode="loss")
@@ -37,7 +37,7 @@ def gpu(wino_teacher):
         p = dict(model.named_parameters())
         return {k: p[k].grad.detach().cpu().double() for k in names}, float(total.detach())
     finally:
-        K.WINO_TEACHER = keep
+        K.WINO_FROZEN_TRUNK = keep
 
 
 def dist(ga, gb):
@@ -54,11 +54,11 @@ g64, l64 = oracle(torch.float64)
 g32, l32 = oracle(torch.float32)
 gd, ld = gpu(False)
 gw, lw = gpu(True)
-print("total loss: fp64 %.9f | fp32 CPU %.9f | HIP direct teacher %.9f | HIP Winograd teacher %.9f" % (l64, l32, ld, lw))
+print("total loss: fp64 %.9f | fp32 CPU %.9f | HIP direct trunk %.9f | HIP Winograd trunk %.9f" % (l64, l32, ld, lw))
 print("gradients vs the fp64 evaluation:")
 print("  fp32 CPU oracle (the reference path)   ", dist(g32, g64))
-print("  HIP, teacher on the direct kernels     ", dist(gd, g64))
-print("  HIP, teacher on the Winograd kernels   ", dist(gw, g64))
+print("  HIP, student trunk on the direct kernels     ", dist(gd, g64))
+print("  HIP, student trunk on the Winograd kernels   ", dist(gw, g64))
 print("gradients vs the fp32 CPU oracle:")
-print("  HIP, teacher on the direct kernels     ", dist(gd, g32))
-print("  HIP, teacher on the Winograd kernels   ", dist(gw, g32))
+print("  HIP, student trunk on the direct kernels     ", dist(gd, g32))
+print("  HIP, student trunk on the Winograd kernels   ", dist(gw, g32))
