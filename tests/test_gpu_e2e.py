@@ -184,12 +184,10 @@ def test_trainer_three_steps_follow_oracle_sgd_trajectory():
         d_ref = (sd[k] - ssd[k]).double()
         d_got = (params[k].detach().cpu() - ssd[k]).double()
         num += float((d_got - d_ref).pow(2).sum()); den += float(d_ref.pow(2).sum())
-    # Tolerance: at 128x160 the step's gradient is chaotic at rounding level (ReLU / ERS flips): two runs of THIS
-    # implementation that differ only in how stream-K splits the K loops of the tiny launches (ERD_SK_MIN_SLICES=0 vs 8:
-    # teacher logits equal to 2.5e-7, loss to 1.7e-7) already differ by 2.9e-3 in the one-step gradient
-    # (tests/diag/diag_sk_grads.py), and three momentum steps amplify that; observed 2e-2 ... 5.2e-2 across split
-    # settings.  The per-step losses above are the tight check (2e-3); this one catches a wrong lr / momentum / decay.
-    assert den > 0 and (num / den) ** 0.5 < 1e-1, (num / den) ** 0.5
+    # Observed 1.6e-2 (with the student's frozen trunk on the direct kernels; 5e-2 when its three layer1 convolutions ran on
+    # the Winograd kernels -- that is how the trunk's sensitivity first showed up, see test_gpu_fullsize.py).  The per-step
+    # losses above are the tight check (2e-3); this one catches a wrong lr / momentum / weight decay.
+    assert den > 0 and (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
     print("3-step displacement rel L2 err: %.2e; losses %s vs %s" % ((num / den) ** 0.5, got, ref_loss))
     # frozen parts did not move; the teacher is untouched
     for k, v in ssd.items():
