@@ -120,3 +120,24 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert lib.erd_abi_version() == 1
     # argument errors come back as codes + message, never as exceptions across the ABI
     assert lib.erd_conv_igemm(None, None) == -1 and b"null" in lib.erd_last_error()
+
+
+def test_distillation_forward_scopes_the_unrecorded_winograd_switch():
+    """kernels.distillation_forward(flag) sets where no-grad / frozen convolutions may use the Winograd kernels and
+    restores the previous setting, also when the body raises; defaults: teacher on, student's frozen trunk off."""
+    from erd_amd import kernels as K
+    assert K.WINO_TEACHER is True and K.WINO_FROZEN_TRUNK is False
+    before = K.WINO_NOGRAD_FWD
+    with K.distillation_forward(False):
+        assert K.WINO_NOGRAD_FWD is False
+        with K.distillation_forward(True):
+            assert K.WINO_NOGRAD_FWD is True
+        assert K.WINO_NOGRAD_FWD is False
+    assert K.WINO_NOGRAD_FWD == before
+    try:
+        with K.distillation_forward():          # default argument: the frozen-trunk setting
+            assert K.WINO_NOGRAD_FWD == K.WINO_FROZEN_TRUNK
+            raise RuntimeError("boom")
+    except RuntimeError:
+        pass
+    assert K.WINO_NOGRAD_FWD == before
