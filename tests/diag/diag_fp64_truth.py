@@ -13,7 +13,8 @@ from erd_amd import kernels as K
 from erd_amd import parse_losses
 
 tsd, ssd = f7_state_dicts()
-imgs, boxes, labels = O.synthetic_batch(1, 800, 1333, 40, seed=7)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+imgs, boxes, labels = O.synthetic_batch(1, 800, 1333, 40, seed=SEED)
 x, metas = O.preprocess(imgs)
 names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
 
