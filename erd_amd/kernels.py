@@ -352,8 +352,8 @@ RECORDED = False
 
 class distillation_forward:
     """Scope in which the convolutions autograd does NOT record (a frozen teacher; the student's frozen stem / layer1)
-    may use the Winograd kernels or not.  Measured at full size (tests/diag/diag_wino_matrix.py, all 16 placements,
-    gradients against the CPU oracle): Winograd in the teacher and in the input gradients changes nothing (2.0e-4 with
+    may use the Winograd kernels or not.  Measured at full size on one input (tests/diag/diag_wino_matrix.py, all 16
+    placements, gradients against the CPU oracle; DESIGN.md 3 has the seed sweep and the fp64 comparison): Winograd in the teacher and in the input gradients changes nothing (2.0e-4 with
     every other kernel direct), in the student's recorded layers 7.2e-4, in the student's FROZEN TRUNK 1.5e-3 -- although
     each of these layers is, taken alone, slightly closer to fp64 on Winograd than on the direct kernel
     (tests/diag/diag_layer1_error.py): a perturbation of the student's earliest activations is amplified through all
