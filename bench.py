@@ -114,6 +114,19 @@ def pmc_traffic_per_launch(symbol_prefix: str):
     return int(mb / n * 1e6), "profiles/" + files[-1]
 
 
+def pmc_mfma_busy(symbol_prefix: str):
+    """matrix-pipe busy fraction of the kernels whose symbol starts with `symbol_prefix` from the committed PMC summary
+    (one `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass, tools/pmc_mfma.py); None when absent"""
+    pdir = os.path.join(ROOT, "profiles")
+    files = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_mfma_busy.json")) if os.path.isdir(pdir) else []
+    if not files:
+        return None, None
+    d = json.load(open(os.path.join(pdir, files[-1])))
+    rows = [(v["launches"], v["mfma_busy_fraction"]) for k, v in d.items() if k.startswith(symbol_prefix)]
+    n = sum(r[0] for r in rows)
+    return (round(sum(a * b for a, b in rows) / n, 4), "profiles/" + files[-1]) if n else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +243,8 @@ def main():
                                "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                                "gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
                                "algorithmic_bytes_per_launch": int(dom["min_bytes"] / dom["launches"])}
+            sym = {"conv_wgrad": "conv_wgrad", "conv_wino_fwd": "wino_conv", "conv_wino_dgrad": "wino_conv"}.get(dom["kernel"], "conv_igemm")
+            out["roofline"]["mfma_busy_pmc"], out["roofline"]["mfma_busy_source"] = pmc_mfma_busy(sym)
             if dom["kernel"].startswith("conv_wino"):
                 # `achieved` counts the direct-convolution flops of the launch (the algorithmic figure); Winograd
                 # F(2x2,3x3) executes 16/36 of those multiplications on the matrix cores
