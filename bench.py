@@ -32,6 +32,7 @@ H, W = 800, 1333
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = f32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+STEP_GFLOP_PER_IMAGE = 1663.6       # teacher fwd 431.8 + student fwd 436.0 + student bwd 795.8
 
 
 def synthetic_gpu_batch(bs: int, seed: int, device, cfg=None, num_new: int = 40):
@@ -76,26 +77,72 @@ def build_model(device, rank: int):
     return model.to(device).train(), cfg
 
 
-def cpu_baseline(seconds_budget: float = 30.0):
-    """the oracle restatement (kind 'port') on the host cores: one full ERD step on the SAME workload shape
-    (4 images, 800x1344): ~10-20 s of CPU work."""
+def _host_cpu():
+    """(model name, physical cores, logical cores) of the host this runs on"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = logical
+    try:      # a container may expose fewer cores than the machine has
+        logical = min(logical, len(os.sched_getaffinity(0)))
+        physical = min(physical, logical)
+    except AttributeError:
+        pass
+    return model, physical, logical
+
+
+def cpu_baseline():
+    """the oracle restatement (kind 'port') on the host's physical cores, batch 2, synthetic
+    demo_mm_inputs-shaped images at 1333x800, median of 3 after 1 warm-up, for (i) BASELINE.json configs[0] -- plain
+    GFL first-40 forward + loss -- and (ii) the ERD step (teacher fwd + ERS + NMS + student fwd + losses + backward).
+    `value` is (ii), the workload of the GPU number next to it.  A bounded sample: 8 CPU steps, roughly 30-60 s."""
     from oracle import erd_oracle as O
-    ncores = min(os.cpu_count() or 1, 16)     # oneDNN at batch 1 stops scaling (and a shared host thrashes) beyond this
-    torch.set_num_threads(ncores)
+    model, physical, logical = _host_cpu()
+    torch.set_num_threads(physical)
     tsd = O.procedural_state_dict(40, seed=0)
     ssd = O.student_state_from_teacher(tsd, 80, seed=1)
-    sd = {k: (v.clone().requires_grad_(True) if O.trainable(k) and v.dtype == torch.float32 else v)
-          for k, v in ssd.items()}
-    nimg = 4
+    nimg = 2
     imgs, boxes, labels = O.synthetic_batch(nimg, H, W, 40, seed=0)
     x, metas = O.preprocess(imgs)
-    t0 = time.time()
-    losses = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80)
-    O.parse_losses(losses).backward()
-    dt = time.time() - t0
-    return dict(value=round(nimg / dt, 4), unit="images/sec", cores=ncores, kind="port",
-                sample=f"{nimg} images 800x1344, 1 ERD step (teacher fwd+ERS+NMS+student fwd+losses+backward), "
-                       "oracle/erd_oracle.py on torch-CPU fp32, %.1f s" % dt)
+
+    def gfl_first40():
+        with torch.no_grad():
+            cls, bbox = O.gfl_forward(tsd, x)
+            return O.parse_losses(O.gfl_head_loss(cls, bbox, boxes, labels, metas, 40))
+
+    def erd_step():
+        sd = {k: (v.clone().requires_grad_(True) if O.trainable(k) and v.dtype == torch.float32 else v)
+              for k, v in ssd.items()}
+        O.parse_losses(O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80)).backward()
+
+    def median3(fn):
+        fn()                                     # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return sorted(ts)[1], ts
+
+    t_gfl, all_gfl = median3(gfl_first40)
+    t_erd, all_erd = median3(erd_step)
+    return dict(value=round(nimg / t_erd, 4), unit="images/sec", cores=physical, kind="port",
+                cpu_model=model, logical_cpus=logical,
+                sample=f"batch {nimg} at {(H + 31) // 32 * 32}x{(W + 31) // 32 * 32}, median of 3 after 1 warm-up: ERD step (teacher fwd+ERS+NMS+student "
+                       f"fwd+losses+backward) {t_erd:.2f} s; oracle/erd_oracle.py on torch-CPU fp32, {physical} threads",
+                configs0_gfl_first40_fwd_loss={"value": round(nimg / t_gfl, 4), "unit": "images/sec",
+                                               "seconds": round(t_gfl, 3)},
+                seconds_all={"erd_step": [round(t, 3) for t in all_erd], "gfl_first40": [round(t, 3) for t in all_gfl]})
 
 
 def pmc_traffic_per_launch(symbol_prefix: str):
@@ -230,21 +277,30 @@ def main():
         }
         if ktime:
             dom = max(ktime.values(), key=lambda r: r["ms"])
-            peak_tf = FP32_MFMA_PEAK_TFLOPS if (args.compute == "f32" or dom["kernel"] == "conv_wgrad") else BF16_MFMA_PEAK_TFLOPS
-            traffic, traffic_src = pmc_traffic_per_launch({"conv_wgrad": "conv_wgrad", "conv_wino_fwd": "wino_conv",
-                                                           "conv_wino_dgrad": "wino_conv"}.get(dom["kernel"], "conv_igemm"))
+            peak_tf = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else BF16_MFMA_PEAK_TFLOPS   # every GEMM class follows --compute
+            sym = {"conv_wgrad": "conv_wgrad", "conv_wino_fwd": "wino", "conv_wino_dgrad": "wino"}.get(dom["kernel"], "conv_igemm")
+            # PMC counters cannot be read from inside this process: `traffic` / `mfma_busy_pmc` are STATIC values from the
+            # committed profile of the same command (fp32 only; the profile names its commit) -- pointers, not measurements
+            traffic, traffic_src = pmc_traffic_per_launch(sym) if args.compute == "f32" else (None, None)
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"],
                                "achieved": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
                                "peak": peak_tf, "unit": "TFLOP/s",
                                "frac": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12 / peak_tf, 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, PMC)",
-                               "traffic_source": traffic_src, "pass": f"{rsteps} extra steps, streams serialized",
+                               "traffic_source": traffic_src, "traffic_static": True,
+                               "pass": f"{rsteps} extra steps, streams serialized",
                                "launches_per_step": dom["launches"] // rsteps,
                                "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                                "gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
                                "algorithmic_bytes_per_launch": int(dom["min_bytes"] / dom["launches"])}
-            sym = {"conv_wgrad": "conv_wgrad", "conv_wino_fwd": "wino_conv", "conv_wino_dgrad": "wino_conv"}.get(dom["kernel"], "conv_igemm")
-            out["roofline"]["mfma_busy_pmc"], out["roofline"]["mfma_busy_source"] = pmc_mfma_busy(sym)
+            out["roofline"]["mfma_busy_pmc"], out["roofline"]["mfma_busy_source"] = \
+                pmc_mfma_busy(sym) if args.compute == "f32" else (None, None)
+            out["roofline"]["mfma_busy_static"] = True
+            # step level: the algorithmic work of the WHOLE step (1663.6 GFLOP per image) over the
+            # un-instrumented step time of the timed region, against the same peak
+            out["roofline"]["step_gflop_per_image"] = STEP_GFLOP_PER_IMAGE
+            out["roofline"]["step_tflops"] = round(args.batch * STEP_GFLOP_PER_IMAGE / (1e3 * dt / args.steps), 2)
+            out["roofline"]["step_frac"] = round(out["roofline"]["step_tflops"] / peak_tf, 4)
             if dom["kernel"].startswith("conv_wino"):
                 # `achieved` counts the direct-convolution flops of the launch (the algorithmic figure); Winograd
                 # F(2x2,3x3) executes 16/36 of those multiplications on the matrix cores

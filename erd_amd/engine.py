@@ -101,6 +101,7 @@ class BucketedGradSync:
         self.streams = list(streams)     # HIP streams that may hold gradient-producing kernels of one backward pass
         self._works: List = []
         self._remaining: List[int] = []
+        self.late_buckets = 0            # buckets whose all-reduce had to be issued by wait() (diagnostic)
         for i, p in enumerate(flat.params):
             hook = self._make_hook(i)
             p.register_post_accumulate_grad_hook(hook)
@@ -129,6 +130,19 @@ class BucketedGradSync:
         return hook
 
     def wait(self) -> None:
+        # a bucket whose countdown never reached zero (a parameter without a gradient this step, or a broken
+        # "one notification per parameter" contract) would leave rank-local gradients in the flat buffer and let the
+        # ranks diverge silently: its collective is issued here, behind every gradient-producing stream
+        for b, left in enumerate(self._remaining):
+            if left > 0:
+                s, e, _ = self.flat.buckets[b]
+                if self.streams:
+                    cs = torch.cuda.current_stream(self.flat.grad.device)
+                    for st in self.streams:
+                        if st != cs:
+                            cs.wait_stream(st)
+                self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                self.late_buckets += 1
         for w in self._works:
             w.wait()
         self._works = []

@@ -123,6 +123,24 @@ def _gpu_only(x: Tensor, who: str) -> None:
 # ---------------------------------------------------------------------------------------------------
 # ResNet
 # ---------------------------------------------------------------------------------------------------
+def _resolve_pretrained(checkpoint: str) -> Optional[str]:
+    """local path of an init_cfg checkpoint, or None.  'torchvision://resnet50' -> resnet50*.pth under
+    $ERD_PRETRAINED_DIR or <torch hub dir>/checkpoints (the names torchvision's own downloader uses)."""
+    if os.path.isfile(checkpoint):
+        return checkpoint
+    if "://" not in checkpoint:
+        return None
+    name = checkpoint.split("://", 1)[1]
+    import glob
+    dirs = [os.environ.get("ERD_PRETRAINED_DIR"), os.path.join(torch.hub.get_dir(), "checkpoints")]
+    for d in dirs:
+        if d and os.path.isdir(d):
+            hits = sorted(glob.glob(os.path.join(d, name + "*.pth")))
+            if hits:
+                return hits[0]
+    return None
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -221,7 +239,41 @@ class ResNet(nn.Module):
         return self
 
     def init_weights(self):
-        pass        # ConvHolder/FrozenStatBN constructors already hold the reference's default init
+        """mmengine BaseModule.init_weights with `init_cfg=dict(type='Pretrained', checkpoint=...)` (the shipped
+        configs: 'torchvision://resnet50', configs/gfl_increment/*first_40_cats.py:45): load the ImageNet backbone.
+        torchvision's keys map one to one onto conv1 / bn1 / layerX.Y.{convZ,bnZ,downsample.{0,1}}; `fc.*` is dropped.
+        A 'torchvision://name' checkpoint is looked up on disk only ($ERD_PRETRAINED_DIR, then torch hub's checkpoint
+        directory) -- there is no download.  An unresolvable checkpoint RAISES: training a base detector on a frozen
+        random stem + layer1 with mean-0 / var-1 BN statistics cannot reproduce the reference's model
+        (set ERD_ALLOW_RANDOM_BACKBONE=1 to continue on the constructors' kaiming weights, with a warning)."""
+        cfg = self.init_cfg
+        if not cfg:
+            return      # ConvHolder / FrozenStatBN constructors already hold the reference's default init
+        if cfg.get("type") != "Pretrained":
+            raise NotImplementedError(f"ResNet.init_cfg type {cfg.get('type')!r}: only 'Pretrained' is built")
+        path = _resolve_pretrained(str(cfg["checkpoint"]))
+        if path is None:
+            msg = (f"ResNet init_cfg: cannot resolve {cfg['checkpoint']!r} on disk (no network); put the file under "
+                   f"$ERD_PRETRAINED_DIR or pass backbone.init_cfg.checkpoint=/path/to/resnet.pth")
+            if os.environ.get("ERD_ALLOW_RANDOM_BACKBONE", "0") != "1":
+                raise FileNotFoundError(msg)
+            import warnings
+            warnings.warn(msg + " -- continuing with RANDOM (kaiming) backbone weights", RuntimeWarning)
+            return
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+        sd = sd.get("state_dict", sd)
+        prefix = cfg.get("prefix")
+        if prefix:
+            sd = {k[len(prefix):].lstrip("."): v for k, v in sd.items() if k.startswith(prefix)}
+        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd and not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in sd if k not in own]
+        if missing or unexpected:
+            raise RuntimeError(f"{path}: not a ResNet-{self.depth} state dict (missing {missing[:4]}..., "
+                               f"unexpected {unexpected[:4]}...)")
+        self.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+        self._freeze_stages()
 
     def forward(self, x: Tensor) -> Tuple[Tensor, ...]:
         """x: [N,3,H,W] NCHW fp32 -> tuple of logical-NCHW (channels_last) stage outputs."""
@@ -735,6 +787,14 @@ class GFL(nn.Module):
     def with_neck(self) -> bool:
         return self.neck is not None
 
+    def init_weights(self) -> None:
+        """mmengine BaseModule.init_weights as the reference Runner calls it before training: a no-op once the model
+        is initialised (`_is_init`; GFLIncrementERD sets it after the teacher / warm start, gfl_increment_erd.py:63-65),
+        otherwise the backbone's `init_cfg` ('Pretrained') is honoured; neck and head hold their init already."""
+        if not self._is_init:
+            self.backbone.init_weights()
+            self._is_init = True
+
     def extract_feat(self, batch_inputs: Tensor) -> Tuple[Tensor, ...]:
         x = self.backbone(batch_inputs)
         return self.neck(x) if self.with_neck else x
@@ -919,7 +979,7 @@ def parse_losses(losses: Dict[str, Union[Tensor, List[Tensor]]]) -> Tuple[Tensor
         for name, (a, b) in losses.slices.items():
             log_vars[name] = d[a:b].sum()
         total = losses.vector.sum()
-        log_vars["loss"] = total
+        log_vars["loss"] = total.detach()      # (the returned `total` carries the graph; a logged one would pin it)
         return total, log_vars
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
@@ -929,5 +989,6 @@ def parse_losses(losses: Dict[str, Union[Tensor, List[Tensor]]]) -> Tuple[Tensor
         else:
             raise TypeError(f"{name} is not a tensor or list of tensors")
     total = sum(v for k, v in log_vars.items() if "loss" in k)
-    log_vars["loss"] = total
+    log_vars = OrderedDict((k, v.detach()) for k, v in log_vars.items())
+    log_vars["loss"] = total.detach()
     return total, log_vars

@@ -40,9 +40,11 @@ def model_state_dict(model: torch.nn.Module, with_teacher: bool = True) -> "Orde
 
 def save_checkpoint(path: str, model: torch.nn.Module, trainer: Optional[ERDTrainer] = None, meta: Optional[dict] = None,
                     with_teacher: bool = True) -> None:
+    if trainer is not None:
+        trainer.flush()        # the SGD update of the last step is deferred behind the next teacher forward: apply it
+                               # BEFORE the weights are read, or the file pairs stale weights with newer momentum
     ckpt = dict(meta=dict(meta or {}), state_dict=model_state_dict(model, with_teacher))
     if trainer is not None:
-        trainer.flush()
         ckpt["optimizer"] = trainer.optimizer_state_dict()
         ckpt["meta"].update(iter=trainer.iter)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -196,7 +198,10 @@ class Runner:
         self.log = log if self.rank == 0 else (lambda *_: None)
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.work_dir = cfg.get("work_dir") or os.path.join("work_dirs", "erd")
-        self.model = MODELS.build(cfg.model).to(self.device).train()
+        model = MODELS.build(cfg.model)
+        if not (cfg.get("load_from") or cfg.get("resume")):
+            model.init_weights()      # backbone.init_cfg 'Pretrained' (a loaded checkpoint supersedes it); raises when unresolvable
+        self.model = model.to(self.device).train()
         opt = cfg.optim_wrapper.optimizer
         if opt.type != "SGD":
             raise NotImplementedError("only SGD (the ERD configs) is built")

@@ -18,7 +18,8 @@ def _cfg(path, work_dir, **over):
     from erd_amd import Config
     cfg = Config.fromfile(path)
     cfg.work_dir = str(work_dir)
-    cfg.merge_from_dict({"train_dataloader.batch_size": 2, "train_cfg.max_epochs": 2,
+    # (backbone.init_cfg=None as in the reference's own detector tests, test_single_stage.py:38-71: no ImageNet file here)
+    cfg.merge_from_dict({"train_dataloader.batch_size": 2, "train_cfg.max_epochs": 2, "model.backbone.init_cfg": None,
                          "default_hooks.logger.interval": 1, **over})
     return cfg
 
@@ -38,6 +39,10 @@ def test_base_training_then_incremental_stage_then_resume(tmp_path):
     # config :112-116: SGD lr .01, auto_scale_lr on (x world*bs/16), LinearLR warm-up from x.001 by iteration
     assert h1[0]["lr"] == pytest.approx(0.01 * 2 / 16 * 0.001) and h1[1]["lr"] > h1[0]["lr"]
     base_ckpt = tmp_path / "first40" / "epoch_2.pth"
+    # the file holds the weights AFTER the epoch's last (deferred) update: equal to the live model, and a checkpoint
+    # written right after a step at a non-negligible learning rate differs from one written before that step's flush
+    for k, v in torch.load(base_ckpt, map_location="cpu", weights_only=False)["state_dict"].items():
+        assert torch.equal(v, r1.model.state_dict()[k].cpu()), k
     assert base_ckpt.is_file() and (tmp_path / "first40" / "last_checkpoint").read_text() == str(base_ckpt)
     ck = torch.load(base_ckpt, map_location="cpu", weights_only=False)
     assert ck["meta"]["epoch"] == 2 and ck["meta"]["iter"] == 4

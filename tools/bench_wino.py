@@ -29,7 +29,10 @@ CASES = [("head tower 5 levels", 256, 256, sizes_of(800, 1344)), ("head cls80", 
          ("fpn.out P3", 256, 256, [(100, 168)]), ("L1.conv2", 64, 64, [(200, 336)]), ("L2.conv2", 128, 128, [(100, 168)]),
          ("L3.conv2", 256, 256, [(50, 84)]), ("L4.conv2", 512, 512, [(25, 42)])]
 print(f"{'layer':22s} {'GFLOP':>7s} | {'direct us':>9s} {'TF':>6s} | {'wino us':>8s} {'TF(alg)':>7s} | speedup")
+ONLY = [o for o in os.environ.get("ONLY", "").split(",") if o]
 for name, Cin, Cout, sizes in CASES:
+    if ONLY and name not in ONLY:
+        continue
     A = sum(h * w for h, w in sizes)
     x = torch.randn(N, A, Cin, device="cuda")
     w = torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.05
