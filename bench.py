@@ -275,6 +275,11 @@ def main():
             "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
             "teacher": "hipGraph replay" if args.teacher_graph else "eager launches",
         }
+        shared = bool(getattr(model, "shares_trunk", lambda: False)()) and not args.teacher_graph
+        # student and teacher hold the same frozen stem + layer1: computed once per step and fed to both.  The skipped
+        # launches are the student's copy (2.53 + 14.31 GMAC per image, BASELINE.md section 3 / SURVEY Appendix A);
+        # `roofline.step_frac` keeps counting the ALGORITHMIC work of the reference's step (both copies)
+        out["shared_frozen_trunk"] = {"enabled": shared, "skipped_gflop_per_image": 33.68 if shared else 0.0}
         if ktime:
             dom = max(ktime.values(), key=lambda r: r["ms"])
             peak_tf = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else BF16_MFMA_PEAK_TFLOPS   # every GEMM class follows --compute

@@ -39,6 +39,17 @@ __device__ __forceinline__ float pack_bf16(float a, float b) {
 
 constexpr int NTHREADS = 256;
 
+#ifdef ERD_IGEMM_TRACE      // debug builds only: per-workgroup phase cycles (tools/_igemm_trace.py)
+__device__ unsigned long long g_igemm_trace[1024 * 8];
+#define IG_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define IG_ACC(slot, v) if (threadIdx.x == 0 && blockIdx.x < 1024) g_igemm_trace[blockIdx.x * 8 + slot] += __builtin_amdgcn_s_memtime() - v
+#define IG_SET(slot, val) if (threadIdx.x == 0 && blockIdx.x < 1024) g_igemm_trace[blockIdx.x * 8 + slot] = (val)
+#else
+#define IG_T0(v)
+#define IG_ACC(slot, v)
+#define IG_SET(slot, val)
+#endif
+
 struct RowInfo {
     int in_off;   // element offset of image n in `in`
     int ih0, iw0; // a*in_stride, b*in_stride
@@ -128,7 +139,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
 
+    IG_T0(t_kernel);
+    IG_SET(0, t_kernel);
+    for (int q_ = 1; q_ < 8; ++q_) { IG_SET(q_, 0ull); }
     for (long long u = u_begin; u < u_end;) {
+        IG_T0(t_pro);
         const int tt = (int)(u / nkt);
         const int ks = (int)(u - (long long)tt * nkt);
         int ke = (int)min((long long)nkt, ks + (u_end - u));
@@ -268,6 +283,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         store_lds(0);
         __syncthreads();
 
+        IG_ACC(2, t_pro);
+        IG_T0(t_loop);
         constexpr int KSTEPS = CH / 2;      // one k-step = the two chunks (h = 0 / 1) a wave's lanes read
         constexpr int APS = (AJ + KSTEPS - 1) / KSTEPS, BPS = (BJ + KSTEPS - 1) / KSTEPS;   // loads per k-step
         for (int kt = ks; kt < ke; ++kt) {
@@ -330,6 +347,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             __syncthreads();
         }
 
+        IG_ACC(3, t_loop);
+        IG_SET(6, g_igemm_trace[blockIdx.x * 8 + 6] + (unsigned long long)(ke - ks));
+        IG_T0(t_fix);
         // ---- partial tile: hand the accumulators over; the last contributor to arrive reduces ----------
         if (ks != 0 || ke != nkt_t) {
             const long long t0 = (long long)tt * nkt;
@@ -338,26 +358,29 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             const int ncontrib = last_b - first_b + 1;
             const int my_slot = (tt == (int)(u_begin / nkt)) ? 0 : 1;
             // slab layout: float4 q = (fragment, register quad) of lane tid at [q][tid]: 16-B stores/loads, coalesced
-            float4* slab = reinterpret_cast<float4*>(ws.slabs + ((size_t)(2 * wg + my_slot)) * (BM * BN));
+            // Slabs travel with sc1 (write-through) stores and sc1 loads: visible across the XCDs' L2s without the
+            // agent-scope release / acquire fences, whose `buffer_wbl2 sc1` writes back EVERY dirty line of the XCD's L2
+            // (the output rows other workgroups have just stored) -- measured 27k cycles per workgroup in this hand-over
+            // on the 264-tile 1x1 layers, a seventh of the kernel (cdna_hip_programming Guideline 16, sc1 form).
+            const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(
+                ws.slabs, 0, (int)std::min<size_t>((size_t)2 * G * BM * BN * 4, 0x7fffffffu), 0x00020000);
+            const unsigned slab_off = (unsigned)((size_t)(2 * wg + my_slot) * (BM * BN) * 4) + (unsigned)tid * 16u;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        slab[((i * FN + j) * 4 + g) * NTHREADS + tid] = make_float4(
-                            acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    for (int g = 0; g < 4; ++g) {
+                        u32x4 v;
+                        v.x = __float_as_uint(acc[i][j][4 * g]); v.y = __float_as_uint(acc[i][j][4 * g + 1]);
+                        v.z = __float_as_uint(acc[i][j][4 * g + 2]); v.w = __float_as_uint(acc[i][j][4 * g + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, slab_off + (unsigned)(((i * FN + j) * 4 + g) * NTHREADS * 16), 0, 16 /* sc1 */);
+                    }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int old = __hip_atomic_fetch_add(ws.cnt + tt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == ncontrib - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                bcast[0] = old;
-            }
+            if (tid == 0) bcast[0] = __hip_atomic_fetch_add(ws.cnt + tt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            if (bcast[0] != ncontrib - 1) continue;   // somebody else finishes this tile
+            if (bcast[0] != ncontrib - 1) { IG_ACC(4, t_fix); IG_SET(1, __builtin_amdgcn_s_memtime()); continue; }   // somebody else finishes this tile
             // Two contributors (the common case): a + b == b + a bit for bit, so the reducer keeps its own
             // accumulators and adds the other slab.  Three or more: re-sum every slab in K order from zero so the
             // result does not depend on who arrived last.
@@ -374,22 +397,24 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 const int bb = first_b + c;
                 if (pair && bb == wg) continue;
                 const int bfirst_tile = (int)(((U * bb) / G) / nkt);
-                const float4* sl = reinterpret_cast<const float4*>(
-                    ws.slabs + ((size_t)(2 * bb + (tt == bfirst_tile ? 0 : 1))) * (BM * BN));
+                const unsigned so = (unsigned)((size_t)(2 * bb + (tt == bfirst_tile ? 0 : 1)) * (BM * BN) * 4) + (unsigned)tid * 16u;
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const float4 v = sl[((i * FN + j) * 4 + g) * NTHREADS + tid];
-                            acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y;
-                            acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w;
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_slab, so + (unsigned)(((i * FN + j) * 4 + g) * NTHREADS * 16), 0, 16 /* sc1 */);
+                            acc[i][j][4 * g] += __uint_as_float(v.x); acc[i][j][4 * g + 1] += __uint_as_float(v.y);
+                            acc[i][j][4 * g + 2] += __uint_as_float(v.z); acc[i][j][4 * g + 3] += __uint_as_float(v.w);
                         }
             }
             if (tid == 0) ws.cnt[tt] = 0;   // leave the ticket zeroed for the next launch (stream-ordered)
         }
 
+        IG_ACC(4, t_fix);
+        IG_T0(t_epi);
         // ---- epilogue: accumulators -> LDS (64 rows at a time) -> coalesced float4 rows --------------------
         // A lane owns one output column, so direct stores would be 64 dword stores per lane (store-issue bound).
         // Staging the tile through the (now idle) operand LDS turns them into 16-B stores of whole 512-B rows and
@@ -502,6 +527,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 }
             }
         }
+        IG_ACC(5, t_epi);
+        IG_SET(1, __builtin_amdgcn_s_memtime());
     }
 }
 
@@ -1213,6 +1240,13 @@ int launch_wgrad(const erd_wgrad_desc* d, hipStream_t st) {
     return erd::check_launch("conv_wgrad");
 }
 }  // namespace
+
+#ifdef ERD_IGEMM_TRACE
+extern "C" int erd_igemm_trace(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_igemm_trace), sizeof(g_igemm_trace));
+}
+#endif
 
 extern "C" size_t erd_conv_igemm_ws_bytes(int max_tiles) {
     return (size_t)2 * 4 * num_cus() * 128 * 128 * sizeof(float) + (size_t)max_tiles * sizeof(int);

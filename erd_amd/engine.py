@@ -170,11 +170,13 @@ class TeacherGraphs:
             stream = torch.cuda.current_stream(inputs.device)
             static_in = inputs.clone()
             with torch.no_grad():
-                self.model.teacher_pass(static_in)      # eager warm-up: workspaces, anchor / folded-BN caches
+                self.model.teacher_pass(static_in, share_trunk=False)      # eager warm-up: workspaces, anchor / folded-BN caches
+                # (share_trunk=False: the captured teacher computes its own frozen trunk -- a hand-over event to the student's
+                #  stream cannot be recorded inside a graph)
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream), torch.no_grad():
-                out = self.model.teacher_pass(static_in)
+                out = self.model.teacher_pass(static_in, share_trunk=False)
             ent = self.graphs[key] = (graph, static_in, out)
         graph, static_in, out = ent
         static_in.copy_(inputs, non_blocking=True)
@@ -295,8 +297,11 @@ class ERDTrainer:
             self._apply_pending()
             self.flat.zero_grad()
             K.zero_arena_begin(self.device)
+            if teacher_out.trunk is not None:      # shared frozen trunk: the student starts at its first trainable stage
+                cur.wait_event(teacher_out.trunk_event)
+                teacher_out.trunk[0].record_stream(cur)
             with K.distillation_forward(K.WINO_FROZEN_TRUNK):
-                s_cls, s_bbox, sizes = model._forward_cat(inputs)
+                s_cls, s_bbox, sizes = model._forward_cat(inputs, trunk=teacher_out.trunk)
             cur.wait_stream(self.side)
             for t in teacher_out.tensors():
                 t.record_stream(cur)

@@ -275,27 +275,51 @@ class ResNet(nn.Module):
         self.load_state_dict({k: v for k, v in sd.items()}, strict=False)
         self._freeze_stages()
 
-    def forward(self, x: Tensor) -> Tuple[Tensor, ...]:
-        """x: [N,3,H,W] NCHW fp32 -> tuple of logical-NCHW (channels_last) stage outputs."""
+    def trunk(self, x: Tensor):
+        """the frozen front of the network (resnet.py:613-629 `_freeze_stages`): stem + max-pool + the first
+        `frozen_stages` stages, run without autograd.  Returns (h, outs): the NHWC map the first trainable stage reads
+        and the outputs of the frozen stages listed in `out_indices`.  A detector whose student and teacher hold the same
+        frozen trunk computes it once and feeds both (GFLIncrementERD.shares_trunk)."""
         _gpu_only(x, "ResNet.forward")
         if x.dtype != torch.float32:
             raise TypeError("fp32 inputs only")
         x = x.contiguous()
+        outs = []
         with torch.no_grad():
             scale, shift = Fn._bn_fold_cached(self.bn1.weight, self.bn1.bias, self.bn1.running_mean,
                                               self.bn1.running_var, self.bn1.eps)
             h = K.stem(x, Fn.ohwi(self.conv1.weight), scale, shift)
-        outs = []
+            for i in range(min(max(self.frozen_stages, 0), len(self.res_layers))):
+                for blk in getattr(self, self.res_layers[i]):
+                    h = blk(h)
+                if i in self.out_indices:
+                    outs.append(_nchw(h))
+        return h, outs
+
+    def forward(self, x: Tensor, trunk=None) -> Tuple[Tensor, ...]:
+        """x: [N,3,H,W] NCHW fp32 -> tuple of logical-NCHW (channels_last) stage outputs.  `trunk`: the result of
+        `trunk(x)` of a network with the SAME frozen front (then x is not read)."""
+        h, outs = self.trunk(x) if trunk is None else trunk
+        outs = list(outs)
         for i, name in enumerate(self.res_layers):
+            if (i + 1) <= self.frozen_stages:
+                continue
             layer = getattr(self, name)
-            frozen = (i + 1) <= self.frozen_stages
-            ctxm = torch.no_grad() if (frozen or not torch.is_grad_enabled()) else torch.enable_grad()
+            ctxm = torch.no_grad() if not torch.is_grad_enabled() else torch.enable_grad()
             with ctxm:
                 for blk in layer:
                     h = blk(h)
             if i in self.out_indices:
                 outs.append(_nchw(h))
         return tuple(outs)
+
+    def trunk_tensors(self) -> List[Tensor]:
+        """every parameter / buffer the frozen front reads (for the equality check of a shared trunk)"""
+        mods = [self.conv1, self.bn1] + [getattr(self, n) for n in self.res_layers[:max(self.frozen_stages, 0)]]
+        out = []
+        for m in mods:
+            out += [t for _, t in sorted(m.state_dict().items()) if t.dtype == torch.float32]
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -799,8 +823,9 @@ class GFL(nn.Module):
         x = self.backbone(batch_inputs)
         return self.neck(x) if self.with_neck else x
 
-    def _forward_cat(self, batch_inputs: Tensor):
-        p_cat, sizes = self.neck.forward_cat(self.backbone(batch_inputs))
+    def _forward_cat(self, batch_inputs: Tensor, trunk=None):
+        p_cat, sizes = self.neck.forward_cat(self.backbone(batch_inputs, trunk=trunk) if trunk is not None
+                                             else self.backbone(batch_inputs))
         cls, bbox = self.bbox_head.forward_cat(p_cat, sizes)
         return cls, bbox, sizes
 
@@ -918,16 +943,44 @@ class GFLIncrementERD(GFL):
         ib = [r["idx_bbox"][i, :int(cnt[i, 1])] for i in range(tc.shape[0])]
         return ic, [tc[i][ic[i]] for i in range(len(ic))], ib, [tb[i][ib[i]] for i in range(len(ib))]
 
-    def teacher_pass(self, batch_inputs: Tensor, batch_data_samples=None) -> "TeacherOut":
+    def shares_trunk(self) -> bool:
+        """True when the student's frozen front (stem + the first `frozen_stages` stages) is bit-identical to the
+        teacher's: same depth / frozen_stages, no trainable tensor in it, every parameter and buffer equal.  Checked on
+        the device once per (storage, version) state -- loading other weights into either network re-checks."""
+        if os.environ.get("ERD_SHARE_TRUNK", "1") == "0":
+            return False
+        a, b = self.backbone, self.ori_model.backbone
+        if a.depth != b.depth or a.frozen_stages < 1 or a.frozen_stages != b.frozen_stages:
+            return False
+        ta, tb = a.trunk_tensors(), b.trunk_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in ta + tb)
+        hit = getattr(self, "_trunk_shared", None)
+        if hit is None or hit[0] != key:
+            same = len(ta) == len(tb) and not any(t.requires_grad for t in ta) and all(
+                x.shape == y.shape and bool(torch.equal(x, y)) for x, y in zip(ta, tb))
+            hit = self._trunk_shared = (key, same)
+        return hit[1]
+
+    def teacher_pass(self, batch_inputs: Tensor, batch_data_samples=None, share_trunk: bool = True) -> "TeacherOut":
         """the no-grad half of `loss` (:205-208): teacher forward, ERS, the NMS of the selected teacher boxes and
         (when the data samples are given) the ATSS targets -- everything that does not depend on the student's
         parameters, so the trainer runs it on a side stream."""
+        trunk, trunk_event = None, None
+        if self.shares_trunk():
+            # student and teacher hold the same frozen stem + layer1 (the warm start copies them, :83-93, and nothing
+            # updates them): computed ONCE, on the kernels the student's trunk uses, and fed to both networks
+            with K.distillation_forward(K.WINO_FROZEN_TRUNK):
+                trunk = self.backbone.trunk(batch_inputs)
+            if share_trunk:      # (share_trunk=False: same arithmetic, but the map is not handed on -- hipGraph capture)
+                trunk_event = torch.cuda.Event()
+                trunk_event.record()
         with K.distillation_forward(K.WINO_TEACHER):
-            t_cls, t_bbox, sizes = self.ori_model._forward_cat(batch_inputs)
+            t_cls, t_bbox, sizes = self.ori_model._forward_cat(batch_inputs, trunk=trunk)
         ers = self.sel_pos_cat(t_cls, t_bbox)
         anchors = self.bbox_head.prior_generator.grid_priors_cat(sizes, t_cls.device)
         keep, kcnt = K.distill_nms(t_cls, t_bbox, anchors, ers["idx_bbox"], ers["counts"], 0.005)
         out = TeacherOut(t_cls, t_bbox, sizes, ers, keep, kcnt)
+        out.trunk, out.trunk_event = (trunk, trunk_event) if share_trunk else (None, None)
         if batch_data_samples is not None:
             gts, _, metas = unpack_gt_instances(batch_data_samples)
             out.targets = self.bbox_head._targets(sizes, gts, metas, t_cls.device)
@@ -940,7 +993,7 @@ class GFLIncrementERD(GFL):
                 teacher_out = self.teacher_pass(batch_inputs)
         t = teacher_out
         with K.distillation_forward(K.WINO_FROZEN_TRUNK):
-            s_cls, s_bbox, sizes = self._forward_cat(batch_inputs)
+            s_cls, s_bbox, sizes = self._forward_cat(batch_inputs, trunk=t.trunk)
         return self.bbox_head.loss_cat(t.t_cls, t.t_bbox, s_cls, s_bbox, sizes, batch_data_samples, t.ers, t.keep,
                                        self.ori_num_classes, self.dist_loss_weight, targets=t.targets)
 
@@ -949,9 +1002,13 @@ class TeacherOut:
     def __init__(self, t_cls, t_bbox, sizes, ers, keep, keep_count):
         self.t_cls, self.t_bbox, self.sizes, self.ers, self.keep, self.keep_count = t_cls, t_bbox, sizes, ers, keep, keep_count
         self.targets: Optional[SimpleNamespace] = None
+        self.trunk = None             # (h, outs) of the shared frozen trunk, or None: the student computes its own
+        self.trunk_event = None       # recorded on the producing stream right after the trunk
 
     def tensors(self) -> List[Tensor]:
         out = [self.t_cls, self.t_bbox, self.keep, self.keep_count] + list(self.ers.values())
+        if self.trunk is not None:
+            out += [self.trunk[0]] + list(self.trunk[1])
         if self.targets is not None:
             out += [v for v in vars(self.targets).values() if isinstance(v, torch.Tensor)]
         return out

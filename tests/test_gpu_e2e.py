@@ -303,3 +303,41 @@ def test_bf16_matrix_core_mode_vs_oracle_bf16_multiplicands():
               "grad rel L2 median %.2e max %.2e" % (dmax, lerr, min(jac), float(np.median(errs)), max(errs)))
     finally:
         K.set_compute("f32")
+
+
+def test_shared_frozen_trunk_feeds_both_networks(monkeypatch):
+    """Student stem + layer1 are frozen and warm-started from the teacher checkpoint (gfl_increment_erd.py:83-93,
+    resnet.py:613-629): when the two copies are bit-identical the trunk is computed once per step and fed to both
+    networks.  Same losses and gradients as two separate trunks; any difference between the copies turns sharing off."""
+    from erd_amd import parse_losses
+    tsd, ssd = f7_state_dicts()
+    model = build_erd(tsd, ssd)
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=3)
+    x, metas = O.preprocess(imgs)
+    samples = make_samples(boxes, labels, metas)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        total, log = parse_losses(model(x.cuda(), samples, mode="loss"))
+        total.backward()
+        return float(total), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    assert model.shares_trunk()
+    with torch.no_grad():
+        out = model.teacher_pass(x.cuda())
+    assert out.trunk is not None and out.trunk[0].shape[-1] == 256          # C2, NHWC
+    shared_total, shared_grads = step()
+    monkeypatch.setenv("ERD_SHARE_TRUNK", "0")
+    assert not model.shares_trunk()
+    own_total, own_grads = step()
+    assert shared_total == pytest.approx(own_total, rel=1e-5)
+    num = sum(float((shared_grads[k] - own_grads[k]).double().pow(2).sum()) for k in own_grads)
+    den = sum(float(own_grads[k].double().pow(2).sum()) for k in own_grads)
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5      # (the teacher's trunk moves from Winograd to the direct kernels)
+    monkeypatch.delenv("ERD_SHARE_TRUNK")
+    assert model.shares_trunk()
+    with torch.no_grad():
+        model.backbone.layer1[1].bn2.bias.add_(1e-3)              # the copies now differ: every network computes its own
+    assert not model.shares_trunk()
+    with torch.no_grad():
+        assert model.teacher_pass(x.cuda()).trunk is None
