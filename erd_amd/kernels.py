@@ -375,7 +375,8 @@ class distillation_forward:
 
 
 def wino_ok(Cin: int, k: int, stride: int, pad: int) -> bool:
-    return WINOGRAD and COMPUTE == "f32" and k == 3 and stride == 1 and pad == 1 and Cin % 16 == 0
+    # (16-channel K slices; the kernel's look-ahead pipeline wants at least four of them per item)
+    return WINOGRAD and COMPUTE == "f32" and k == 3 and stride == 1 and pad == 1 and Cin % 16 == 0 and Cin >= 64
 
 
 def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: int, scale: Optional[Tensor] = None,

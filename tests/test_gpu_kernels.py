@@ -376,7 +376,10 @@ def test_conv_wgrad_fp32_multilevel_three_tap_kernel(K, Cin, Co, monkeypatch):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 256, 256, 26, 30), (1, 64, 64, 20, 28), (2, 128, 128, 25, 42), (1, 256, 80, 13, 21),
-                                            (1, 512, 512, 7, 11), (1, 256, 68, 8, 16), (1, 16, 32, 5, 3)])
+                                            (1, 512, 512, 7, 11), (1, 256, 68, 8, 16), (1, 64, 32, 5, 3),
+                                            # ragged tile grids: every block shape of the cover (1x32 / 2x16 bottom strips,
+                                            # 32x1 / 16x2 / 8x4 right strips)
+                                            (1, 64, 64, 34, 66), (2, 64, 64, 12, 20), (1, 64, 96, 100, 168), (1, 128, 64, 50, 84)])
 def test_winograd_conv3x3_forward(K, N, Cin, Cout, H, W):
     """Winograd F(2x2,3x3) == direct 3x3 stride-1 convolution (odd sizes: partial tiles; Cout not a multiple of 64)"""
     x = G.randn(41, N, Cin, H, W)

@@ -1,9 +1,8 @@
 #!/bin/bash
-# tools/build_abl.sh N...: liberd_hip variants with compile-time ablations of the Winograd kernel (erd_amd/lib/abl/liberd_hip_N.so)
+# tools/build_abl.sh NAME [extra hipcc flags...]: a liberd_hip variant with the Winograd cycle trace compiled in
+# (erd_amd/lib/abl/liberd_hip_NAME.so; read back with tools/_trace.py through ERD_HIP_LIB)
 cd "$(dirname "$0")/../erd_amd/csrc"
 mkdir -p ../lib/abl
-for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DERD_WINO_ABL=$n $EXTRA -c winograd.hip -o /tmp/winograd_abl_$n.o 2>/dev/null &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC conv_mfma.o elementwise.o losses.o predict.o /tmp/winograd_abl_$n.o -o ../lib/abl/liberd_hip_$n.so &
-done
-wait
+n=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DERD_WINO_TRACE "$@" -c winograd.hip -o /tmp/winograd_abl_$n.o 2>/dev/null &&
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC conv_mfma.o elementwise.o losses.o predict.o /tmp/winograd_abl_$n.o -o ../lib/abl/liberd_hip_$n.so
