@@ -100,6 +100,19 @@ _SIGNATURES = {
     "erd_predict_ws_bytes": [i32, i32, i32],
     "erd_predict_topk": [P, P, P, i32, i64, i32, P, P, P, f32, i32, P, P, P, P, P, C.c_size_t, P],
     "erd_predict_nms": [P, P, P, P, i32, i32, P, f32, f32, i32, P, P, P, P, C.c_size_t, P],
+    "erd_qfl_rows": [P, P, P, i64, i32, P, P],
+    "erd_qfl_bwd": [P, P, P, P, i64, i32, P, P],
+    "erd_dfl": [P, P, P, i64, i32, P, P, P],
+    "erd_kd_kl_rows": [P, P, P, i64, i32, f32, P, P, P],
+    "erd_giou": [P, P, P, i64, f32, P, P, P],
+    "erd_bbox_overlaps": [P, P, i64, i64, i32, i32, f32, P, P],
+    "erd_integral": [P, P, i64, i32, P, P, P],
+    "erd_distance2bbox": [P, P, P, i64, f32, f32, P, P, P],
+    "erd_bbox2distance": [P, P, i64, f32, f32, P, P],
+    "erd_weighted_sum": [P, P, i64, C.c_double, P, P],
+    "erd_loss_coef": [P, P, i64, f32, P, P],
+    "erd_rows_mul": [P, P, i64, f32, P, P],
+    "erd_atss_result": [P, P, i64, P, P, P, P],
 }
 
 EXPORTS = ["erd_abi_version", "erd_last_error"] + sorted(_SIGNATURES)

@@ -1155,7 +1155,8 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     bool seg_taps = false;           // per-segment tap sets: tiles have different K lengths -> whole tiles only,
     for (int s = 0; s < d->nseg; ++s) seg_taps |= d->seg[s].ntaps > 0;     // dealt round-robin over the XCDs (a contiguous
     if (seg_taps) ws.xcd_order = 0;  // chunk per XCD would hand one XCD all the 4-tap tiles and another all the 1-tap ones)
-    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && !seg_taps && nkt * BKT >= 512 && (units >= slots || tiny)) {
+    static const int sk_min_k = getenv("ERD_SK_MIN_K") ? atoi(getenv("ERD_SK_MIN_K")) : 512;
+    if (d->sk_ws && d->sk_ws_bytes >= need && ragged && sk_pays && !seg_taps && nkt * BKT >= sk_min_k && (units >= slots || tiny)) {
         G = (int)std::min<int64_t>(slots, min_slices > 0 ? std::max<int64_t>(tiles, units / min_slices) : slots);
         ws.slabs = reinterpret_cast<float*>(d->sk_ws);
         ws.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(d->sk_ws) + slab_bytes);

@@ -425,24 +425,102 @@ class AnchorGenerator:
         return out
 
 
+class AssignResult:
+    """assigners/assign_result.py:8-50: `gt_inds` 0 = unassigned / g + 1, `max_overlaps`, `labels` (-1 = unassigned)"""
+
+    def __init__(self, num_gts: int, gt_inds: Tensor, max_overlaps: Tensor, labels: Tensor):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    @property
+    def num_preds(self) -> int:
+        return len(self.gt_inds)
+
+
+class SamplingResult:
+    """samplers/sampling_result.py:86-116 (the fields the GFL target code reads)"""
+
+    def __init__(self, pos_inds, neg_inds, priors, gt_bboxes, assign_result, gt_flags, avg_factor_with_neg: bool = True):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.num_pos, self.num_neg = max(pos_inds.numel(), 1), max(neg_inds.numel(), 1)
+        self.avg_factor_with_neg = avg_factor_with_neg
+        self.avg_factor = self.num_pos + self.num_neg if avg_factor_with_neg else self.num_pos
+        self.pos_priors, self.neg_priors = priors[pos_inds], priors[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        self.pos_gt_labels = assign_result.labels[pos_inds]
+        if gt_bboxes.numel() == 0:
+            self.pos_gt_bboxes = gt_bboxes.view(-1, 4)
+        else:
+            self.pos_gt_bboxes = gt_bboxes.view(-1, 4)[self.pos_assigned_gt_inds.long()]
+
+
 @TASK_UTILS.register_module()
 class ATSSAssigner:
     def __init__(self, topk: int, alpha=None, iou_calculator=dict(type="BboxOverlaps2D"), ignore_iof_thr: float = -1):
         if alpha is not None or ignore_iof_thr > 0:
             raise NotImplementedError("cost-based / ignore-region ATSS is outside the ERD hot path")
         self.topk = topk
+        self.alpha = alpha
+        self.iou_calculator = TASK_UTILS.build(iou_calculator) if isinstance(iou_calculator, dict) else iou_calculator
+
+    def assign(self, pred_instances, num_level_priors: Sequence[int], gt_instances, gt_instances_ignore=None) -> AssignResult:
+        """assigners/atss_assigner.py:74-254 for one image (the batched targets of the training step come from the same
+        kernels through `GFLHead._targets`): per level the `topk` priors closest to each gt centre are candidates, the
+        threshold is mean + std of their IoUs, positives have their centre inside the gt, conflicts go to the larger
+        IoU.  Returns gt_inds / max_overlaps (-1e8 where unassigned, as the reference leaves it) / labels."""
+        priors = pred_instances.priors[:, :4].contiguous()
+        gt_bboxes, gt_labels = gt_instances.bboxes, gt_instances.labels
+        _gpu_only(priors, "ATSSAssigner.assign")
+        A, G = priors.shape[0], gt_bboxes.shape[0]
+        if sum(int(v) for v in num_level_priors) != A:
+            raise ValueError("num_level_priors does not add up to the number of priors")
+        dev = priors.device
+        if G == 0 or A == 0:          # atss_assigner.py:120-134
+            return AssignResult(G, torch.zeros(A, dtype=torch.int64, device=dev), torch.zeros(A, dtype=torch.float32, device=dev),
+                                torch.full((A,), -1, dtype=torch.int64, device=dev))
+        gt_off = torch.tensor([0, G], dtype=torch.int32, device=dev)
+        glab = gt_labels.to(torch.int64).contiguous()
+        K.atss_assign(priors, None, [(int(v), 1) for v in num_level_priors], gt_bboxes.float().contiguous(), glab, gt_off, 1, G,
+                      num_classes=1 << 30, topk=self.topk)
+        ws = K.workspace("atss", A * 8, dev)         # the (IoU, gt) keys the assignment leaves behind
+        gt_inds = torch.empty(A, dtype=torch.int64, device=dev)
+        max_ov = torch.empty(A, dtype=torch.float32, device=dev)
+        labels = torch.empty(A, dtype=torch.int64, device=dev)
+        K.call("erd_atss_result", K._p(ws), K._p(glab), A, K._p(gt_inds), K._p(max_ov), K._p(labels), K._stream())
+        return AssignResult(G, gt_inds, max_ov, labels)
 
 
 @TASK_UTILS.register_module()
 class BboxOverlaps2D:
     def __init__(self, scale: float = 1.0, dtype=None):
-        pass
+        if scale != 1.0 or dtype not in (None, "fp32"):
+            raise NotImplementedError("BboxOverlaps2D(scale, dtype='fp16') is outside the ERD hot path")
+
+    def __call__(self, bboxes1: Tensor, bboxes2: Tensor, mode: str = "iou", is_aligned: bool = False) -> Tensor:
+        """assigners/iou2d_calculator.py:16-62: [m, 4|5] x [n, 4|5] -> [m, n] (or [m] aligned)"""
+        from . import leaf
+        return leaf.bbox_overlaps(bboxes1, bboxes2, mode, is_aligned)
 
 
 @TASK_UTILS.register_module()
 class DistancePointBBoxCoder:
     def __init__(self, clip_border: bool = True, use_box_type: bool = False):
+        if use_box_type:
+            raise NotImplementedError("box-type outputs are outside the ERD hot path")
         self.clip_border = clip_border
+
+    def encode(self, points: Tensor, gt_bboxes: Tensor, max_dis: Optional[float] = None, eps: float = 0.1) -> Tensor:
+        """coders/distance_point_bbox_coder.py:28-51 -> bbox2distance (transforms.py:201-230)"""
+        from . import leaf
+        assert points.size(0) == gt_bboxes.size(0) and points.size(-1) == 2 and gt_bboxes.size(-1) == 4
+        return leaf.bbox2distance(points, gt_bboxes, max_dis, eps)
+
+    def decode(self, points: Tensor, pred_bboxes: Tensor, max_shape=None) -> Tensor:
+        """coders/distance_point_bbox_coder.py:53-85 -> distance2bbox (transforms.py:147-198)"""
+        from . import leaf
+        assert points.size(0) == pred_bboxes.size(0) and points.size(-1) == 2 and pred_bboxes.size(-1) == 4
+        return leaf.distance2bbox(points, pred_bboxes, max_shape if self.clip_border else None)
 
 
 @TASK_UTILS.register_module()
@@ -450,44 +528,79 @@ class PseudoSampler:
     def __init__(self, **kwargs):
         pass
 
+    def sample(self, assign_result: AssignResult, pred_instances, gt_instances, *args, **kwargs) -> SamplingResult:
+        """samplers/pseudo_sampler.py:26-60: every assigned prior is a positive, every other one a negative (index
+        plumbing: `nonzero` reads the counts back, exactly as the reference's own call does)"""
+        gt_bboxes, priors = gt_instances.bboxes, pred_instances.priors
+        pos = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        flags = priors.new_zeros(priors.shape[0], dtype=torch.uint8)
+        return SamplingResult(pos, neg, priors, gt_bboxes, assign_result, flags, avg_factor_with_neg=False)
+
 
 class _LossCfg(nn.Module):
-    """Loss modules only carry their hyper-parameters here: their arithmetic is inside the fused HIP loss
-    kernels (erd_gfl_losses_*, erd_kd_kl*), which read these values."""
+    """The loss modules carry their hyper-parameters for the fused HIP loss kernels of the training step
+    (erd_gfl_losses_*, erd_kd_kl*), and a `forward` with the reference's signature for callers that invoke them one at a
+    time (erd_amd/leaf.py -> erd_amd/csrc/leaf_ops.hip)."""
+
+    reduction = "mean"
+
+    def _reduction(self, override):
+        assert override in (None, "none", "mean", "sum")
+        return override if override else self.reduction
 
 
 @MODELS.register_module()
 class QualityFocalLoss(_LossCfg):
     def __init__(self, use_sigmoid=True, beta=2.0, reduction="mean", loss_weight=1.0, activated=False):
         super().__init__()
-        if not use_sigmoid or beta != 2.0 or reduction != "mean" or activated:
-            raise NotImplementedError("QFL kernel is built for use_sigmoid=True, beta=2.0, reduction='mean'")
-        self.beta, self.loss_weight = beta, loss_weight
+        if not use_sigmoid or beta != 2.0 or activated:
+            raise NotImplementedError("QFL kernel is built for use_sigmoid=True, beta=2.0, activated=False")
+        self.beta, self.loss_weight, self.reduction = beta, loss_weight, reduction
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        """losses/gfocal_loss.py:205-249: pred [n, C] logits, target = (labels [n] with C = background, scores [n])"""
+        from . import leaf
+        return leaf.quality_focal_loss(pred, target, weight, self.beta, self._reduction(reduction_override), avg_factor,
+                                       self.loss_weight)
 
 
 @MODELS.register_module()
 class DistributionFocalLoss(_LossCfg):
     def __init__(self, reduction="mean", loss_weight=1.0):
         super().__init__()
-        assert reduction == "mean"
-        self.loss_weight = loss_weight
+        self.loss_weight, self.reduction = loss_weight, reduction
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        """losses/gfocal_loss.py:271-295: pred [m, reg_max + 1] logits, target [m] distances in [0, reg_max)"""
+        from . import leaf
+        return leaf.distribution_focal_loss(pred, target, weight, self._reduction(reduction_override), avg_factor, self.loss_weight)
 
 
 @MODELS.register_module()
 class GIoULoss(_LossCfg):
     def __init__(self, eps=1e-6, reduction="mean", loss_weight=1.0):
         super().__init__()
-        if eps != 1e-6 or reduction != "mean":
-            raise NotImplementedError("GIoU kernel is built for eps=1e-6 (module default), reduction='mean'")
-        self.eps, self.loss_weight = eps, loss_weight
+        self.eps, self.loss_weight, self.reduction = eps, loss_weight, reduction
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        """losses/iou_loss.py:482-528: pred / target [n, 4] xyxy"""
+        from . import leaf
+        return leaf.giou_loss(pred, target, weight, self.eps, self._reduction(reduction_override), avg_factor, self.loss_weight)
 
 
 @MODELS.register_module()
 class KnowledgeDistillationKLDivLoss(_LossCfg):
     def __init__(self, reduction="mean", loss_weight=1.0, T=10):
         super().__init__()
-        assert reduction == "mean" and T >= 1
-        self.loss_weight, self.T = loss_weight, T
+        assert T >= 1
+        self.loss_weight, self.T, self.reduction = loss_weight, T, reduction
+
+    def forward(self, pred, soft_label, weight=None, avg_factor=None, reduction_override=None):
+        """losses/kd_loss.py:61-95: pred / soft_label [m, bins] logits"""
+        from . import leaf
+        return leaf.knowledge_distillation_kl_div_loss(pred, soft_label, weight, self._reduction(reduction_override), avg_factor,
+                                                       self.T, self.loss_weight)
 
 
 @MODELS.register_module()
@@ -499,13 +612,18 @@ class CrossEntropyLoss(_LossCfg):
 
 
 class Integral(nn.Module):
-    """holds the `integral.project` buffer of the checkpoint ABI (gfl_head.py:29-62); the expectation itself
-    is computed inside the loss / NMS kernels."""
+    """holds the `integral.project` buffer of the checkpoint ABI (gfl_head.py:29-62).  Inside the training step the
+    expectation is computed by the fused loss / NMS kernels; `forward` is the stand-alone operator."""
 
     def __init__(self, reg_max: int = 16):
         super().__init__()
         self.reg_max = reg_max
         self.register_buffer("project", torch.linspace(0, reg_max, reg_max + 1))
+
+    def forward(self, x: Tensor) -> Tensor:
+        """gfl_head.py:47-62: [n, 4 (reg_max + 1)] side distributions -> [n, 4] = softmax . (0, 1, ..., reg_max)"""
+        from . import leaf
+        return leaf.integral(x, self.reg_max)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -537,6 +655,13 @@ class GFLHead(nn.Module):
         self.loss_cls = MODELS.build(loss_cls)
         self.loss_bbox = MODELS.build(loss_bbox)
         self.loss_dfl = MODELS.build(loss_dfl)
+        # the fused loss kernels of the training step are built for the ERD configs' settings (the modules' own
+        # `forward` accepts every reduction)
+        for m in (self.loss_cls, self.loss_bbox, self.loss_dfl):
+            if getattr(m, "reduction", "mean") != "mean":
+                raise NotImplementedError(f"{type(m).__name__}(reduction={m.reduction!r}) in a GFL head: the fused step kernels use 'mean'")
+        if getattr(self.loss_bbox, "eps", 1e-6) != 1e-6:
+            raise NotImplementedError("GIoULoss(eps != 1e-6) in a GFL head: the fused step kernels use the module default")
         if train_cfg:
             self.assigner = TASK_UTILS.build(train_cfg["assigner"])
             if train_cfg.get("allowed_border", -1) >= 0 or train_cfg.get("pos_weight", -1) > 0:

@@ -174,7 +174,7 @@ int erd_preprocess_image(const void* img, int is_uint8, int h, int w, float* out
                          erd_stream_t stream);
 
 /* Resize(keep_ratio, bilinear) + RandomFlip + DetDataPreprocessor in one pass over the padded output slot
- * (configs/gfl_increment/*:13-19 pipeline; mmcv.imrescale backend cv2, restated and UNPINNED vs cv2): src is the decoded
+ * (configs/gfl_increment/ *.py:13-19 pipeline; mmcv.imrescale backend cv2, restated and UNPINNED vs cv2): src is the decoded
  * uint8 image [sh][sw][3] on the device, {x,y}ofs / {x,y}coef the per-output-pixel source index and the two 11-bit
  * fixed-point weights along each axis (host-built, device arrays), (nh, nw) the resized size inside the (H, W) slot. */
 int erd_resize_normalize(const void* src_hwc_u8, int sh, int sw, const int* xofs, const short* xcoef,
@@ -312,6 +312,46 @@ int erd_predict_nms(const float* boxes, const float* scores, const int32_t* labe
                     int N, int max_cols, const float* inv_scale, float min_bbox_size, float iou_thr,
                     int max_per_img, float* dets, int64_t* det_labels, int32_t* det_num, void* ws,
                     size_t ws_bytes, erd_stream_t stream);
+
+/* ---- stand-alone leaf operators: what the registered loss / coder / assigner MODULES run when a caller invokes them
+ * directly (the training step itself uses the fused erd_gfl_losses_* / erd_kd_kl* kernels above).  Row-parallel; every
+ * loss comes as `rows` (the reference's reduction='none' value, after the per-row sum / mean the reference applies) plus
+ * a backward that takes coef[i] = upstream * loss_weight * weight[i] / denominator.
+ *   erd_qfl_rows / erd_qfl_bwd   quality_focal_loss, beta = 2 (losses/gfocal_loss.py:12-53): rows[i] = sum_k loss[i][k]
+ *   erd_dfl                      distribution_focal_loss over nb bins (gfocal_loss.py:143-165); rows and/or dpred
+ *   erd_kd_kl_rows               knowledge_distillation_kl_div_loss, temperature T (kd_loss.py:12-37)
+ *   erd_giou                     giou_loss rows 1 - GIoU and d/dpred (iou_loss.py:110-126; eps as bbox_overlaps clamps it)
+ *   erd_bbox_overlaps            bbox_overlaps mode 0 'iou' / 1 'giou', aligned [A] or pairwise [A][G] (bbox_overlaps.py:13-199)
+ *   erd_integral                 Integral: softmax over nb bins . [0..nb-1] (gfl_head.py:29-62); y and/or dx
+ *   erd_distance2bbox            DistancePointBBoxCoder.decode / distance2bbox (transforms.py:147-198), max_w < 0: no clamp;
+ *                                out and/or the gradient w.r.t. the distances
+ *   erd_bbox2distance            encode / bbox2distance (transforms.py:201-230), max_dis < 0: no clamp
+ *   erd_weighted_sum             out[0] = scale * sum rows[i] * weight[i]  (weight_reduce_loss, losses/utils.py:30-65), f64 sums
+ *   erd_loss_coef                coef[i] = upstream[0] * scale * weight[i]
+ *   erd_rows_mul                 out[i] = rows[i] * scale * weight[i]  (reduction='none' and its backward)
+ *   erd_atss_result              AssignResult fields (gt_inds 0 / g+1, max_overlaps with -1e8 for unassigned priors, labels
+ *                                -1 / class) of ONE image from the key workspace erd_atss_assign leaves behind
+ *                                (atss_assigner.py:238-254) */
+int erd_qfl_rows(const float* pred, const int64_t* label, const float* score, int64_t n, int C, float* rows, erd_stream_t stream);
+int erd_qfl_bwd(const float* pred, const int64_t* label, const float* score, const float* coef, int64_t n, int C, float* dpred,
+                erd_stream_t stream);
+int erd_dfl(const float* pred, const float* target, const float* coef, int64_t m, int nb, float* rows, float* dpred,
+            erd_stream_t stream);
+int erd_kd_kl_rows(const float* pred, const float* soft, const float* coef, int64_t m, int nb, float T, float* rows, float* dpred,
+                   erd_stream_t stream);
+int erd_giou(const float* pred, const float* target, const float* coef, int64_t n, float eps, float* rows, float* dpred,
+             erd_stream_t stream);
+int erd_bbox_overlaps(const float* b1, const float* b2, int64_t A, int64_t G, int aligned, int mode, float eps, float* out,
+                      erd_stream_t stream);
+int erd_integral(const float* x, const float* dy, int64_t m, int nb, float* y, float* dx, erd_stream_t stream);
+int erd_distance2bbox(const float* points, const float* dist, const float* dout, int64_t n, float max_h, float max_w, float* out,
+                      float* ddist, erd_stream_t stream);
+int erd_bbox2distance(const float* points, const float* boxes, int64_t n, float max_dis, float eps, float* out, erd_stream_t stream);
+int erd_weighted_sum(const float* rows, const float* weight, int64_t n, double scale, float* out, erd_stream_t stream);
+int erd_loss_coef(const float* upstream, const float* weight, int64_t n, float scale, float* coef, erd_stream_t stream);
+int erd_rows_mul(const float* rows, const float* weight, int64_t n, float scale, float* out, erd_stream_t stream);
+int erd_atss_result(const void* assign_ws, const int64_t* gt_labels, int64_t A, int64_t* gt_inds, float* max_overlaps,
+                    int64_t* labels, erd_stream_t stream);
 
 #ifdef __cplusplus
 }
