@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
                     help="f32: fp32 matrix cores (BASELINE configs[1], the headline).  bf16: the 1x1/3x3 convolutions on the "
                          "bf16 matrix cores, fp32 accumulation and storage (BASELINE configs[2])")
+    ap.add_argument("--no-streamk", action="store_true",
+                    help="A/B aid: tile-parallel implicit-GEMM launches instead of the stream-K split (every world size uses "
+                         "stream-K by default, so the N = 1 point of a scaling curve is the sibling of the N > 1 points)")
     ap.add_argument("--serial", action="store_true",
                     help="no stream concurrency in the timed region either (the rocprofv3 companion run)")
     args = ap.parse_args()
@@ -209,6 +212,8 @@ def main():
     from erd_amd import kernels as K
     from erd_amd.engine import ERDTrainer
     K.set_compute(args.compute)
+    if args.no_streamk:
+        K.STREAMK = False
     model, cfg = build_model(device, rank)
     opt = cfg.optim_wrapper.optimizer
     trainer = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
@@ -256,8 +261,12 @@ def main():
         ktime = K.timing_end()
         set_serial(args.serial)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    devices = [f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
     dt = float(tmax.item())
     loss = float(log["loss"].detach()) if log is not None else float("nan")
 
@@ -275,6 +284,10 @@ def main():
             "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
             "teacher": "hipGraph replay" if args.teacher_graph else "eager launches",
         }
+        out["collectives"] = {"backend": "nccl (RCCL)" if dist.is_initialized() else None,
+                              "world_size": dist.get_world_size() if dist.is_initialized() else 1, "devices": devices}
+        out["kernel_config"] = "stream-K implicit GEMM" if (K.STREAMK and (K.STREAMK_MULTIRANK or not K._multi_rank())) \
+            else "tile-parallel implicit GEMM"
         shared = bool(getattr(model, "shares_trunk", lambda: False)()) and not args.teacher_graph
         # student and teacher hold the same frozen stem + layer1: computed once per step and fed to both.  The skipped
         # launches are the student's copy (2.53 + 14.31 GMAC per image, BASELINE.md section 3 / SURVEY Appendix A);

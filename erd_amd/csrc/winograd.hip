@@ -53,7 +53,10 @@ constexpr int KS = 16;                        // input channels per K slice
 constexpr int BN = 64;                        // output channels per workgroup item
 constexpr int RCS = 6;                        // LDS chunks per raw pixel: 4 data + 2 pad -> the strided 4x4-patch reads of the
                                               // transform are bank-conflict free (4 would be 8-way)
-constexpr int NCH = 4;                        // staged chunks of 256 float4 (= 64 pixels x 16 channels) per slice
+#ifndef ERD_WINO_NCH
+#define ERD_WINO_NCH 4
+#endif
+constexpr int NCH = ERD_WINO_NCH;             // staged chunks of 256 float4 (= 64 pixels x 16 channels) per slice
 constexpr int MAXPIX = 64 * NCH;              // raw pixel slots (a 2x16 block needs 6 x 34 = 204; 1x32 blocks are not used)
 constexpr int RAW_LDS_F4 = MAXPIX * RCS;
 constexpr int V_F4 = 16 * 32 * (KS / 4);      // float4s of the 16 transformed tiles
@@ -434,30 +437,43 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         unsigned rd0 = 0, rd1 = 0, rd2 = 0;                    // this thread's three patch rows (LDS bytes inside a raw buffer)
         unsigned nrd0 = 0, nrd1 = 0, nrd2 = 0;                 // ... of the item the look-ahead pointer has entered
         int tr_left = 0;                                       // slices the transform still has to do in its current item
-        // entering item k of the sequence: its buffer resource and patch offsets, its scale / shift slice, the claim of item k + 1
-        auto enter_item = [&]() {
-            const WinoSeg& sg = p.seg[la.s];
-            rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4),
-                                                      0x00020000);
-            const int lbw = la.lbw, bw = 1 << lbw, bh = 32 >> lbw;
+        // Entering an item costs ~200 instructions (decode, four patch offsets, the transform's patch rows): done in one
+        // iteration it made that iteration longer than a slice and the matrix waves waited at the barrier (10 k cycles
+        // per item).  It is therefore STAGED over the iterations before the pointer gets there: the id of item k + 1 is
+        // readable two iterations after the pointer entered item k (claim -> flush -> barrier), so
+        //   la_ks == 3: decode(item k + 1)        la_ks == 4: its offsets / patch rows / buffer resource
+        //   la_ks == nks: switch (register moves), request its scale / shift slice and claim item k + 2.
+        WinoItem nx_it = la;
+        bool nx_valid = false;
+        unsigned nx_roff[NCH], nx_rd0 = 0, nx_rd1 = 0, nx_rd2 = 0;
+        __amdgpu_buffer_rsrc_t nx_rs = rs_in;
+        auto item_geometry = [&](const WinoItem& it, unsigned (&ro)[NCH], unsigned& g0, unsigned& g1, unsigned& g2,
+                                 __amdgpu_buffer_rsrc_t& rs) {
+            const WinoSeg& sg = p.seg[it.s];
+            rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+            const int lbw = it.lbw, bw = 1 << lbw, bh = 32 >> lbw;
             const int pc_n = 2 * bw + 2, npix = (2 * bh + 2) * pc_n;
             const int recip = (65536 + pc_n - 1) / pc_n;              // (scalar)
+            const unsigned base_n = (unsigned)(it.n * sg.in_nstride);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int idx = dt + 256 * i;
                 const int chunk = idx & 3, pix = idx >> 2;
                 const int pr = (pix * recip) >> 16, pc = pix - pr * pc_n;         // = pix / pc_n for pix < 512 (checked for every pitch)
-                const int iy = la.y0 - 1 + pr, ix = la.x0 - 1 + pc;
-                roff[i] = OOBV;
+                const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
+                ro[i] = OOBV;
                 if (pix < npix && (unsigned)iy < (unsigned)sg.H && (unsigned)ix < (unsigned)sg.W)
-                    roff[i] = (unsigned)(la.n * sg.in_nstride + ((int64_t)iy * sg.W + ix) * Cin + chunk * 4) * 4u;
+                    ro[i] = (base_n + (unsigned)((iy * sg.W + ix) * Cin + chunk * 4)) * 4u;       // (< 2^31: checked by the host)
             }
             const int t_ty = t_tile >> lbw, t_tx = t_tile & (bw - 1);
-            nrd0 = (unsigned)((((2 * t_ty + t_half) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
-            nrd1 = nrd0 + (unsigned)(pc_n * RCS * 16);
-            nrd2 = nrd1 + (unsigned)(pc_n * RCS * 16);
-            // requested here, written to LDS one slice later (flush_pending, after the wait the raw slice needs anyway):
-            // neither the atomic's round trip nor the two loads ever stall the data waves
+            g0 = (unsigned)((((2 * t_ty + t_half) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
+            g1 = g0 + (unsigned)(pc_n * RCS * 16);
+            g2 = g1 + (unsigned)(pc_n * RCS * 16);
+        };
+        // its scale / shift slice and the claim of the following item are REQUESTED on entry and written to LDS one slice
+        // later (flush_pending, after the wait the raw slice needs anyway): neither the atomic's round trip nor the two
+        // loads ever stall the data waves
+        auto request_item_data = [&]() {
             if (dt < 64) {
                 const int co = la.cout0 + dt;
                 pend_sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
@@ -482,15 +498,25 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
                 la_soff += KS * 4;
-                if (++la_ks == nks) {                         // the pointer leaves item k_la
+                ++la_ks;
+                if (la_ks == 3) {                             // stage 1: which item comes next
                     const int nx = __builtin_amdgcn_readfirstlane(sh_item[(k_la + 1) & 1]);
-                    if (nx < nitems) {
-                        la = decode(nx);
+                    nx_valid = nx < nitems;
+                    if (nx_valid) nx_it = decode(nx);
+                }
+                if (la_ks == 4 && nx_valid) item_geometry(nx_it, nx_roff, nx_rd0, nx_rd1, nx_rd2, nx_rs);    // stage 2
+                if (la_ks == nks) {                           // the pointer leaves item k_la
+                    if (nx_valid) {
+                        la = nx_it;
+                        rs_in = nx_rs;
+#pragma unroll
+                        for (int i = 0; i < NCH; ++i) roff[i] = nx_roff[i];
+                        nrd0 = nx_rd0; nrd1 = nx_rd1; nrd2 = nx_rd2;
                         la_ks = 0;
                         la_soff = 0;
                         ++k_la;
                         slices_total += nks;
-                        enter_item();
+                        request_item_data();
                     } else la_valid = false;
                 }
             }
@@ -541,7 +567,8 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         auto run = [&](auto half_tag) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) { rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rvb[i] = rv[i]; }
-            enter_item();
+            item_geometry(la, roff, nrd0, nrd1, nrd2, rs_in);
+            request_item_data();
             rd0 = nrd0;
             rd1 = nrd1;
             rd2 = nrd2;

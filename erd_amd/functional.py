@@ -517,9 +517,8 @@ class ERDLossFn(Function):
                                            t.sizes, t.strides, t.c_old, c_all)
         avg = K.loss_avg(t.num_pos, sums)
         if t.world_size > 1:       # reduce_mean x2 (dist_utils.py:59-65) fused into one 2-float all-reduce
-            import torch.distributed as dist
-            avg.div_(t.world_size)
-            dist.all_reduce(avg, op=dist.ReduceOp.SUM)
+            from .dist_utils import reduce_mean
+            avg = reduce_mean(avg)
         l2s = kds = None
         nd = 0
         if t.distill:

@@ -235,16 +235,24 @@ STREAMK = _os.environ.get('ERD_STREAMK', '1') != '0'     # stream-K work decompo
 _SK_TILES = 1 << 16
 
 
+# Stream-K in data-parallel runs.  Round 1 switched it off at world size > 1 (a static split over 2 x #CU workgroups: CUs
+# taken by RCCL channels make some workgroups start late and hold their tiles' hand-over back).  Measured in round 2 with a
+# dummy kernel holding k half-CUs for the whole launch (tools/bench_wgrad_sensitivity.py, 1024->256 1x1 on 4 x 50 x 84):
+# stream-K 119 / 124 / 125 / 139 us at k = 0 / 4 / 16 / 32 against 162 us for the tile-parallel launch at every k -- the
+# split degrades gracefully and stays ahead even with an eighth of the chip taken, so every world size runs the SAME kernel
+# configuration (ERD_STREAMK_MULTIRANK=0 restores the old behaviour; the N = 1 point of a scaling curve is then NOT the
+# sibling of the N > 1 points).
+STREAMK_MULTIRANK = _os.environ.get("ERD_STREAMK_MULTIRANK", "1") != "0"
+
+
 def _multi_rank() -> bool:
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def _attach_sk_ws(d: ConvDesc, device) -> None:
-    # The stream-K grid is a STATIC split over 2 x #CU co-resident workgroups: when RCCL channels (or anything else)
-    # occupy CUs, late workgroups hold their tiles' fix-up back.  At one GPU it measures equal to tile-parallel launches
-    # end to end (the two compute streams already fill each other's ragged rounds), so data-parallel runs do without it.
-    if not STREAMK or _multi_rank():
+    # (one zero-initialised ticket / slab workspace per stream; see STREAMK_MULTIRANK above for the multi-rank policy)
+    if not STREAMK or (_multi_rank() and not STREAMK_MULTIRANK):
         d.sk_ws, d.sk_ws_bytes = 0, 0
         return
     nbytes = int(_lib.load().erd_conv_igemm_ws_bytes(_SK_TILES))

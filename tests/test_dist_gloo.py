@@ -40,10 +40,13 @@ def _worker(rank, world, port, q):
         dist.all_gather(loc, flat.grad.clone())
         ref = sum(loc) / world
         ok = torch.allclose(mine, ref, rtol=1e-6, atol=1e-8)
-        # reduce_mean of the two loss normalisers: div by world, then SUM
-        avg = torch.tensor([3.0 + rank, 10.0 * (rank + 1)])
-        avg.div_(world); dist.all_reduce(avg)
-        ok = ok and torch.allclose(avg, torch.tensor([3.5, 15.0]))
+        # reduce_mean of the two loss normalisers -- the product's own function (erd_amd/dist_utils.py), as the ERD
+        # loss calls it on its 2-float vector [sum num_pos, sum weight_targets]
+        from erd_amd.dist_utils import reduce_mean, world_size
+        local = torch.tensor([3.0 + rank, 10.0 * (rank + 1)])
+        avg = reduce_mean(local)
+        ok = ok and world_size() == world and torch.allclose(avg, torch.tensor([3.5, 15.0]))
+        ok = ok and torch.equal(local, torch.tensor([3.0 + rank, 10.0 * (rank + 1)]))       # the input is not modified
         q.put((rank, bool(ok), len(flat.buckets)))
     finally:
         dist.destroy_process_group()

@@ -245,3 +245,53 @@ def test_head_loss_reference_signature_with_empty_ground_truth(golden, case):
         for got, want in ((s_cls[l].grad, g[f"c{case}_g_cls{l}"]), (s_bbox[l].grad, g[f"c{case}_g_bbox{l}"])):
             want = torch.from_numpy(want)
             assert float((got.cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-9, (l, case)
+
+
+def test_empty_ers_selection_gives_zero_distillation_terms(K):
+    """D10 (deliberate deviation): the reference leaves an empty ERS selection undefined -- `torch.mean` of an
+    empty tensor is NaN (gfl_head_increment_erd.py:329-331) and `batched_nms` on zero boxes raises in `boxes.max()`
+    (:202).  Here an image whose selection is empty contributes exactly 0 to both distillation terms (value and
+    gradient), the other images and the supervised losses are untouched, and nothing is NaN.  An empty selection arises
+    e.g. from constant teacher logits: std = 0 and `>` is strict (:149-151)."""
+    import e2e_util as U
+    from erd_amd import Config, MODELS, parse_losses
+    sizes, t_cls, t_bbox, s_cls, s_bbox, gtb, gtl, metas = G.f10_inputs(0)
+    # the ERS kernel itself: constant logits -> nothing exceeds mean + 2 std
+    A = sum(h * w for h, w in [tuple(t.shape[-2:]) for t in t_cls])
+    flat_c = torch.full((1, A, 40), -3.0).cuda()
+    flat_b = torch.full((1, A, 68), 0.25).cuda()
+    r = K.ers_select(flat_c, flat_b)
+    assert r["counts"].cpu().tolist() == [[0, 0]] and int(r["mask_cls"].sum()) == 0 and int(r["mask_bbox"].sum()) == 0
+    cfg = Config.fromfile(U.CFG_INCRE)
+    hc = dict(cfg.model.bbox_head)
+    hc["train_cfg"] = cfg.model.train_cfg
+    head = MODELS.build(hc).cuda()
+
+    def run(idx_c, idx_b):
+        sc = [t.cuda().requires_grad_(True) for t in s_cls]
+        sb = [t.cuda().requires_grad_(True) for t in s_bbox]
+        losses = head.loss(([t.cuda() for t in t_cls], [t.cuda() for t in t_bbox]), (sc, sb), U.make_samples(gtb, gtl, metas),
+                           idx_c, None, idx_b, None, 40, 1, None)
+        total, _ = parse_losses(losses)
+        total.backward()
+        return {k: [float(v) for v in vs] for k, vs in losses.items()}, sc, sb
+
+    full_c, full_b = [], []
+    for i in range(2):
+        ic, ib, _, _ = O.ers_select_single(O.flatten_levels([t[i:i + 1] for t in t_cls])[0],
+                                           O.flatten_levels([t[i:i + 1] for t in t_bbox])[0])
+        full_c.append(ic.cuda()); full_b.append(ib.cuda())
+    ref, _, _ = run(full_c, full_b)
+    empty = torch.zeros((0,), dtype=torch.long).cuda()
+    got, sc, sb = run([empty, full_c[1]], [empty, full_b[1]])          # image 0 selects nothing
+    assert got["loss_dist_cls"][0] == 0.0 and got["loss_dist_bbox"][0] == 0.0
+    assert got["loss_dist_cls"][1] == pytest.approx(ref["loss_dist_cls"][1], rel=1e-6)
+    assert got["loss_dist_bbox"][1] == pytest.approx(ref["loss_dist_bbox"][1], rel=1e-6)
+    for k in ("loss_cls", "loss_bbox", "loss_dfl"):
+        assert got[k] == pytest.approx(ref[k], rel=1e-6)
+    assert all(np.isfinite(v) for vs in got.values() for v in vs)
+    assert all(torch.isfinite(t.grad).all() for t in sc + sb)
+    both, sc2, sb2 = run([empty, empty], [empty, empty])               # nothing selected anywhere: only the supervised terms
+    assert both["loss_dist_cls"] == [0.0, 0.0] and both["loss_dist_bbox"] == [0.0, 0.0]
+    # with no distillation term the OLD-class logits get no gradient at all (the supervised losses read channels [40:])
+    assert all(float(t.grad[:, :40].abs().max()) == 0.0 for t in sc2)
