@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import functional as Fn
 from . import kernels as K
 from .modules import GFLIncrementERD, parse_losses
 from .structures import unpack_gt_instances
@@ -218,7 +219,8 @@ class ERDTrainer:
         self.sync = None
         if self.distributed:
             from . import functional as Fn
-            self.sync = BucketedGradSync(self.flat, streams=[torch.cuda.current_stream(dev), Fn.aux_stream(dev)])
+            self.sync = BucketedGradSync(self.flat, streams=[torch.cuda.current_stream(dev), Fn.aux_stream(dev),
+                                                             Fn.trail_stream(dev)])
         self.is_erd = isinstance(model, GFLIncrementERD)
         self.overlap_teacher = overlap_teacher and self.is_erd
         self.side = torch.cuda.Stream(device=dev) if self.overlap_teacher else None
@@ -317,6 +319,7 @@ class ERDTrainer:
         if self.sync is not None:
             self.sync.arm()
         total.backward()
+        Fn.trail_join(self.device)        # the trailing weight gradients of the backbone (functional._Trail)
         K.zero_arena_end()
         self._pending = True
         self._pending_lr = self.last_lr = self.lr_at(self.iter, self.epoch_factor)
