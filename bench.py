@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
                     help="f32: fp32 matrix cores (BASELINE configs[1], the headline).  bf16: the 1x1/3x3 convolutions on the "
                          "bf16 matrix cores, fp32 accumulation and storage (BASELINE configs[2])")
+    ap.add_argument("--step-graph", action="store_true",
+                    help="replay the whole step (everything between two SGD updates) from one hipGraph; same arithmetic")
     ap.add_argument("--no-streamk", action="store_true",
                     help="A/B aid: tile-parallel implicit-GEMM launches instead of the stream-K split (every world size uses "
                          "stream-K by default, so the N = 1 point of a scaling curve is the sibling of the N > 1 points)")
@@ -218,13 +220,17 @@ def main():
     opt = cfg.optim_wrapper.optimizer
     trainer = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
                          base_batch_size=cfg.auto_scale_lr.base_batch_size, batch_size_per_gpu=args.batch,
-                         auto_scale_lr=cfg.auto_scale_lr.enable, teacher_graph=args.teacher_graph)
+                         auto_scale_lr=cfg.auto_scale_lr.enable, teacher_graph=args.teacher_graph,
+                         step_graph=args.step_graph)
     batches = [synthetic_gpu_batch(args.batch, seed=rank * 1000 + i, device=device, cfg=cfg) for i in range(2)]
+
+    graph_mode = trainer.step_graph
 
     def set_serial(flag: bool):
         """serial = one HIP stream, kernels back to back: per-launch durations are then well defined"""
         trainer.flush()
         trainer.overlap_teacher = (not flag) and trainer.is_erd
+        trainer.step_graph = graph_mode and not flag          # (per-launch events cannot be taken inside a replayed graph)
         Fn.TOWERS_ON_TWO_STREAMS = not flag
     if args.serial:
         set_serial(True)
@@ -283,6 +289,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
             "teacher": "hipGraph replay" if args.teacher_graph else "eager launches",
+            "step_graph": bool(trainer.step_graph),
         }
         out["collectives"] = {"backend": "nccl (RCCL)" if dist.is_initialized() else None,
                               "world_size": dist.get_world_size() if dist.is_initialized() else 1, "devices": devices}

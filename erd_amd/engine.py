@@ -193,7 +193,7 @@ class ERDTrainer:
     def __init__(self, model: nn.Module, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 1e-4,
                  base_batch_size: int = 16, batch_size_per_gpu: Optional[int] = None, auto_scale_lr: bool = True,
                  warmup_iters: int = 500, warmup_start_factor: float = 0.001, bucket_mb: int = 32,
-                 overlap_teacher: bool = True, teacher_graph: bool = False):
+                 overlap_teacher: bool = True, teacher_graph: bool = False, step_graph: bool = False):
         self.model = model
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
@@ -224,6 +224,13 @@ class ERDTrainer:
         self.is_erd = isinstance(model, GFLIncrementERD)
         self.overlap_teacher = overlap_teacher and self.is_erd
         self.side = torch.cuda.Stream(device=dev) if self.overlap_teacher else None
+        # whole-step hipGraph (one per input shape): everything between two SGD updates -- teacher, ERS, NMS, targets,
+        # student forward, losses, backward on all streams -- is recorded once and replayed as ONE launch; the step is
+        # free of host synchronisation, so nothing in it depends on the host.  ~800 launches of Python / ctypes issue work
+        # per step disappear (the bf16 matrix-core mode is bound by exactly that: 30 ms of issue time for a 30 ms step).
+        # Single-GPU ERD steps only (a captured RCCL all-reduce could not be tested on this pool).
+        self.step_graph = bool(step_graph) and self.overlap_teacher and not self.distributed
+        self._step_graphs: Dict[tuple, tuple] = {}
         if teacher_graph and not self.overlap_teacher:
             raise ValueError("teacher_graph needs the ERD detector with overlap_teacher=True")
         self.teacher_graphs = TeacherGraphs(model) if teacher_graph else None
@@ -281,9 +288,100 @@ class ERDTrainer:
         self._first = loaded == 0
 
     # -- the step ------------------------------------------------------------------------------------------------------
+    GT_CAPACITY = 64          # ground-truth boxes per image a captured step has room for (more: that batch runs eagerly)
+
+    def _graph_body(self, st) -> Tensor:
+        """one step minus the SGD update on the static buffers `st` (captured by _train_step_graph); returns the vector
+        of logged scalars"""
+        model, dev = self.model, self.device
+        cur = torch.cuda.current_stream(dev)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side), torch.no_grad():
+            t = model.teacher_pass(st.x)
+            t.targets = model.bbox_head._targets_packed(t.sizes, st.gb, st.gl, st.goff, self.GT_CAPACITY, st.metas, dev)
+        self.flat.zero_grad()
+        K.zero_arena_begin(dev)
+        if t.trunk is not None:
+            cur.wait_event(t.trunk_event)
+            t.trunk[0].record_stream(cur)
+        with K.distillation_forward(K.WINO_FROZEN_TRUNK):
+            s_cls, s_bbox, sizes = model._forward_cat(st.x, trunk=t.trunk)
+        cur.wait_stream(self.side)
+        for v in t.tensors():
+            v.record_stream(cur)
+        losses = model.bbox_head.loss_cat(t.t_cls, t.t_bbox, s_cls, s_bbox, sizes, None, t.ers, t.keep,
+                                          model.ori_num_classes, model.dist_loss_weight, targets=t.targets)
+        total, log_vars = parse_losses(losses)
+        total.backward()
+        Fn.trail_join(dev)
+        K.zero_arena_end()
+        st.names = list(log_vars.keys())
+        return torch.stack([v.reshape(()) for v in log_vars.values()])
+
+    def _train_step_graph(self, inputs: Tensor, data_samples):
+        """-> log_vars, or None when this batch does not fit the captured form (too many boxes): the caller runs it eagerly"""
+        from types import SimpleNamespace
+        dev = self.device
+        gts, _, metas = unpack_gt_instances(data_samples)
+        N = inputs.shape[0]
+        counts = [int(g.bboxes.shape[0]) for g in gts]
+        if max(counts + [0]) > self.GT_CAPACITY:
+            return None
+        key = (tuple(inputs.shape), tuple(tuple(m["pad_shape"][:2]) for m in metas), inputs.device.index, K.COMPUTE)
+        ent = self._step_graphs.get(key)
+        cur = torch.cuda.current_stream(dev)
+        if ent is None:
+            st = SimpleNamespace(x=torch.empty_like(inputs), gb=torch.zeros((N * self.GT_CAPACITY, 4), device=dev),
+                                 gl=torch.zeros((N * self.GT_CAPACITY,), dtype=torch.long, device=dev),
+                                 goff=torch.zeros((N + 1,), dtype=torch.int32, device=dev),
+                                 metas=[dict(pad_shape=tuple(m["pad_shape"])) for m in metas], names=None)
+            self._fill_static(st, inputs, gts, counts)
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(cur)
+            Fn.CAPTURE_ORIGIN = s.cuda_stream        # joins only into the origin stream: see functional.CAPTURE_ORIGIN
+            try:
+                with torch.cuda.stream(s):   # eager warm-up on the capture stream: workspaces, caches, auxiliary streams
+                    for _ in range(2):
+                        self._graph_body(st)
+                s.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=s):
+                    out = self._graph_body(st)
+            finally:
+                Fn.CAPTURE_ORIGIN = None
+            cur.wait_stream(s)
+            if len(self._step_graphs) >= 8:
+                self._step_graphs.pop(next(iter(self._step_graphs)))
+            ent = self._step_graphs[key] = (graph, st, out)
+        graph, st, out = ent
+        self._fill_static(st, inputs, gts, counts)
+        graph.replay()
+        vals = out.clone()                   # (the static output is overwritten by the next replay)
+        return {k: vals[i] for i, k in enumerate(st.names)}
+
+    @staticmethod
+    def _fill_static(st, inputs: Tensor, gts, counts) -> None:
+        import numpy as np
+        st.x.copy_(inputs, non_blocking=True)
+        off = np.zeros(len(counts) + 1, dtype=np.int32)
+        off[1:] = np.cumsum(counts)
+        if off[-1] > 0:
+            dev = st.gb.device
+            st.gb[:off[-1]].copy_(torch.cat([g.bboxes.reshape(-1, 4).float() for g in gts], 0).to(dev, non_blocking=True))
+            st.gl[:off[-1]].copy_(torch.cat([g.labels.reshape(-1).long() for g in gts], 0).to(dev, non_blocking=True))
+        st.goff.copy_(torch.from_numpy(off), non_blocking=True)
+
     def train_step(self, inputs: Tensor, data_samples) -> Dict[str, Tensor]:
         model = self.model
         cur = torch.cuda.current_stream(self.device)
+        if self.step_graph:
+            self._apply_pending()            # the SGD update of the previous step: one eager launch (its learning rate is a host value)
+            log_vars = self._train_step_graph(inputs, data_samples)
+            if log_vars is not None:
+                self._pending = True
+                self._pending_lr = self.last_lr = self.lr_at(self.iter, self.epoch_factor)
+                self.iter += 1
+                return log_vars
         if self.overlap_teacher:
             # The frozen teacher (forward + ERS + NMS) runs on the side stream, concurrently with (a) the tail of the
             # previous step's gradient all-reduce + the deferred SGD launch and (b) the student's forward on the

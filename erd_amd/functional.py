@@ -42,13 +42,26 @@ TOWERS_ON_TWO_STREAMS = _os.environ.get('ERD_TOWER_AUX', '1') != '0'
 
 _TOWER = {}
 
+# Stream capture (ERDTrainer(step_graph=True)): the HIP runtime of this ROCm registers the waiting stream as a "parallel
+# capture stream" of the event's stream on EVERY hipStreamWaitEvent issued by a stream other than the capture's origin
+# (hip::Stream::EndCapture then recurses over those lists).  A join back into a forked stream -- or a stream waiting on
+# its own event -- therefore closes a cycle and hipStreamEndCapture recurses until the stack is gone.  Forking from any
+# stream is fine, joining is only safe INTO the origin stream.  While a capture is under way CAPTURE_ORIGIN holds the
+# origin's handle and the helpers below do not fork from any other stream (the work runs in line there instead).
+CAPTURE_ORIGIN = None
+
+
+def _may_fork(cur) -> bool:
+    return CAPTURE_ORIGIN is None or cur.cuda_stream == CAPTURE_ORIGIN
+
+
 # Trailing weight gradients (backbone backward): the input-gradient chain dz3 -> dz2 -> dz1 -> dx of a bottleneck is the
 # critical path of the backward pass, the weight gradients (partial slabs, reduce, d gamma: ~10 launches per block, half of
 # them tiny) hang off it.  With TRAIL on they are queued on ONE auxiliary stream that only ever waits for the main stream
-# (an event per convolution) and is joined ONCE, at the end of the backward pass (`trail_join`, called by the trainer and
-# by an autograd end-of-backward callback) -- the chain never waits for a reduce or a 5-microsecond d gamma launch.
-# Only with gradient sinks (ERDTrainer): the results land in the flat gradient buffer, nothing is handed back to autograd
-# from the auxiliary stream.
+# (an event per convolution) and is joined ONCE, at the end of the backward pass (`trail_join`, called by the trainer on
+# the stream the optimizer step is queued on) -- the chain never waits for a reduce or a 5-microsecond d gamma launch.
+# Only with gradient sinks (ERDTrainer, which owns the join): the results land in the flat gradient buffer, nothing is
+# handed back to autograd from the auxiliary stream.
 WGRAD_TRAIL = _os.environ.get('ERD_WGRAD_TRAIL', '1') != '0'
 _TRAIL = {}
 _TRAIL_ACTIVE = set()
@@ -78,30 +91,29 @@ class _Trail:
         self.aux = trail_stream(device)
         self.tensors = [t for t in tensors if t is not None]
         self.key = str(torch.device(device))
+        self.inline = not _may_fork(self.cur)
 
     def __enter__(self):
+        if self.inline:
+            return self
         self.aux.wait_stream(self.cur)
         for t in self.tensors:
             t.record_stream(self.aux)
-        if self.key not in _TRAIL_ACTIVE:
-            _TRAIL_ACTIVE.add(self.key)
-            try:      # join at the end of this backward pass even when no trainer does it
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: trail_join(self.key))
-            except RuntimeError:
-                pass
+        _TRAIL_ACTIVE.add(self.key)
         self.ctx = torch.cuda.stream(self.aux)
         self.ctx.__enter__()
         return self
 
     def __exit__(self, *a):
-        self.ctx.__exit__(*a)
+        if not self.inline:
+            self.ctx.__exit__(*a)
         return False
 
 
 def aux_stream(device) -> "torch.cuda.Stream":
     """the auxiliary stream paired with the current stream (used for the head's second tower)"""
     cur = torch.cuda.current_stream(device)
-    if not TOWERS_ON_TWO_STREAMS:
+    if not TOWERS_ON_TWO_STREAMS or not _may_fork(cur):
         return cur
     key = (str(device), cur.cuda_stream)
     if key not in _TOWER:
@@ -115,7 +127,7 @@ class _Fork:
         key = (str(device), self.cur.cuda_stream)
         if key not in _AUX:
             _AUX[key] = torch.cuda.Stream(device=device)
-        self.aux = _AUX[key] if WGRAD_ON_AUX_STREAM else None
+        self.aux = _AUX[key] if WGRAD_ON_AUX_STREAM and _may_fork(self.cur) else None
 
     def __enter__(self):
         if self.aux is not None:

@@ -691,7 +691,9 @@ class GFLHead(nn.Module):
         # backward on that stream too), so both directions keep two MFMA-bound kernel streams in flight
         cur = torch.cuda.current_stream(p_cat.device)
         aux = Fn.aux_stream(p_cat.device)
-        aux.wait_stream(cur)
+        forked = aux.cuda_stream != cur.cuda_stream      # (a stream never waits on itself: see functional.CAPTURE_ORIGIN)
+        if forked:
+            aux.wait_stream(cur)
         with torch.cuda.stream(aux):
             r = p_cat
             for m in self.reg_convs:
@@ -703,8 +705,9 @@ class GFLHead(nn.Module):
         for m in self.cls_convs:
             c = Fn.HeadConvGN.apply(c, m.conv.weight, m.gn.weight, m.gn.bias, sizes, m.gn.eps)
         cls = Fn.HeadConvBias.apply(c, self.gfl_cls.weight, self.gfl_cls.bias, sizes)
-        cur.wait_stream(aux)
-        bbox.record_stream(cur)
+        if forked:
+            cur.wait_stream(aux)
+            bbox.record_stream(cur)
         return cls, bbox
 
     def forward(self, x: Sequence[Tensor]):
@@ -776,7 +779,6 @@ class GFLHead(nn.Module):
     def _targets(self, sizes, batch_gt_instances, batch_img_metas, device) -> SimpleNamespace:
         """anchors + ATSS assignment for the batch (gfl_head.py:504-669) -- all on the GPU, no host sync."""
         N = len(batch_img_metas)
-        anchors = self.prior_generator.grid_priors_cat(sizes, device)
         boxes = [g.bboxes for g in batch_gt_instances]
         labels = [g.labels for g in batch_gt_instances]
         counts = [int(b.shape[0]) for b in boxes]
@@ -789,6 +791,14 @@ class GFLHead(nn.Module):
             gb = torch.zeros((1, 4), device=device)
             gl = torch.zeros((1,), dtype=torch.long, device=device)
         goff = torch.from_numpy(off).to(device, non_blocking=True)
+        return self._targets_packed(sizes, gb, gl, goff, max(counts + [0]), batch_img_metas, device)
+
+    def _targets_packed(self, sizes, gb: Tensor, gl: Tensor, goff: Tensor, max_gt: int, batch_img_metas, device) -> SimpleNamespace:
+        """the device half of `_targets`: packed ground truth (boxes [G,4], labels [G], per-image offsets [N+1], all on the
+        device; `max_gt` >= the largest per-image count, it only sizes the assignment grid) -> anchors + ATSS targets.
+        A captured training step (engine.StepGraphs) calls this with static buffers."""
+        N = len(batch_img_metas)
+        anchors = self.prior_generator.grid_priors_cat(sizes, device)
         valid = None
         full = all(all(min(int(np.ceil(m["pad_shape"][0] / s)), fh) == fh and min(int(np.ceil(m["pad_shape"][1] / s)), fw) == fw
                        for (fh, fw), s in zip(sizes, self.prior_generator.strides)) for m in batch_img_metas)
@@ -799,8 +809,7 @@ class GFLHead(nn.Module):
                     raise ValueError("There is no valid anchor inside the image boundary. Please check the image "
                                      "size and anchor sizes, or set ``allowed_border`` to -1 to skip the condition.")
             valid = torch.stack(flags).to(device, non_blocking=True)
-        lab, lw, bt, npos = K.atss_assign(anchors, valid, sizes, gb, gl, goff, N, max(counts + [0]),
-                                          self.num_classes, self.assigner.topk)
+        lab, lw, bt, npos = K.atss_assign(anchors, valid, sizes, gb, gl, goff, N, max_gt, self.num_classes, self.assigner.topk)
         return SimpleNamespace(anchors=anchors, labels=lab, label_weights=lw, bbox_targets=bt, num_pos=npos,
                                sizes=[tuple(s) for s in sizes], strides=list(self.prior_generator.strides))
 

@@ -341,3 +341,38 @@ def test_shared_frozen_trunk_feeds_both_networks(monkeypatch):
     assert not model.shares_trunk()
     with torch.no_grad():
         assert model.teacher_pass(x.cuda()).trunk is None
+
+
+def test_whole_step_hipgraph_replay_follows_the_eager_trainer():
+    """`ERDTrainer(step_graph=True)`: everything between two SGD updates (teacher, ERS, NMS, ATSS targets, student forward,
+    losses, backward on all streams) is captured once per input shape and replayed.  Same logged losses and the same
+    weights after four steps on alternating batches as the eager trainer (the captured kernels are the eager ones)."""
+    from erd_amd.engine import ERDTrainer
+    tsd, ssd = f7_state_dicts()
+    batches = []
+    for seed in (0, 5):
+        imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=seed)
+        x, metas = O.preprocess(imgs)
+        batches.append((x.cuda(), make_samples(boxes, labels, metas)))
+
+    def run(step_graph):
+        model = build_erd(tsd, ssd)
+        tr = ERDTrainer(model, lr=0.02, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0, step_graph=step_graph)
+        logs = []
+        for i in range(4):
+            lv = tr.train_step(*batches[i % 2])
+            logs.append({k: float(v) for k, v in lv.items()})
+        tr.flush()
+        torch.cuda.synchronize()
+        return logs, {k: v.detach().clone() for k, v in model.state_dict().items() if v.dtype == torch.float32}, tr
+
+    eager_logs, eager_w, _ = run(False)
+    graph_logs, graph_w, tr = run(True)
+    assert tr.step_graph and len(tr._step_graphs) == 1
+    for a, b in zip(eager_logs, graph_logs):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=1e-5, abs=1e-7), (k, a[k], b[k])
+    num = sum(float((graph_w[k] - eager_w[k]).double().pow(2).sum()) for k in eager_w)
+    den = sum(float(eager_w[k].double().pow(2).sum()) for k in eager_w)
+    assert (num / den) ** 0.5 < 1e-6, (num / den) ** 0.5
