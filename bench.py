@@ -225,6 +225,7 @@ def main():
     batches = [synthetic_gpu_batch(args.batch, seed=rank * 1000 + i, device=device, cfg=cfg) for i in range(2)]
 
     graph_mode = trainer.step_graph
+    trail_mode = Fn.WGRAD_TRAIL
 
     def set_serial(flag: bool):
         """serial = one HIP stream, kernels back to back: per-launch durations are then well defined"""
@@ -232,6 +233,7 @@ def main():
         trainer.overlap_teacher = (not flag) and trainer.is_erd
         trainer.step_graph = graph_mode and not flag          # (per-launch events cannot be taken inside a replayed graph)
         Fn.TOWERS_ON_TWO_STREAMS = not flag
+        Fn.WGRAD_TRAIL = trail_mode and not flag              # (trailing weight gradients overlap the input-gradient chain)
     if args.serial:
         set_serial(True)
 

@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS), ("wk", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32), ("colsum", C.c_void_p),
-                ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("w_bf16", C.c_void_p), ("colsum_copies", i32)]
+                ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("w_bf16", C.c_void_p), ("colsum_copies", i32),
+                ("in_bf16", i32), ("out_bf16", i32)]
 
 
 class WgradSeg(C.Structure):
@@ -48,7 +49,8 @@ class WgradDesc(C.Structure):
                 ("Cin", i32), ("Cout", i32), ("ntaps", i32),
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
-                ("part", C.c_void_p), ("nsplit", i32), ("bf16_multiplicands", i32)]
+                ("part", C.c_void_p), ("nsplit", i32), ("bf16_multiplicands", i32),
+                ("x_bf16", i32), ("dz_bf16", i32)]
 
 
 class Levels(C.Structure):
@@ -70,15 +72,15 @@ _SIGNATURES = {
     "erd_weight_transpose": [P, P, P, i32, i32, i32, i32, P],
     "erd_weight_transpose_bf16": [P, P, P, i32, i32, i32, i32, P],
     "erd_stem_conv7x7_bn_relu": [P, P, P, P, P, i32, i32, i32, P],
-    "erd_maxpool3x3s2": [P, P, i32, i32, i32, i32, P],
+    "erd_maxpool3x3s2": [P, P, i32, i32, i32, i32, i32, P],
     "erd_bn_fold": [P, P, P, P, f32, P, P, i64, P],
-    "erd_relu_bwd_colsum": [P, P, P, i64, i32, i64, i64, P, i32, P],
+    "erd_relu_bwd_colsum": [P, P, P, i64, i32, i64, i64, P, i32, i32, P],
     "erd_bn_dgamma": [P, P, i32, P, P, f32, P, P, i32, i32, P],
-    "erd_gn_relu_fwd": [P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), f32, P],
-    "erd_gn_relu_bwd": [P, P, P, P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), P],
-    "erd_upsample2x_add": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, P],
-    "erd_upsample2x_add_bwd": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, P],
-    "erd_colsum": [P, i64, i32, P, i32, P],
+    "erd_gn_relu_fwd": [P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), f32, i32, P],
+    "erd_gn_relu_bwd": [P, P, P, P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), i32, P],
+    "erd_upsample2x_add": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, i32, P],
+    "erd_upsample2x_add_bwd": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, i32, P],
+    "erd_colsum": [P, i64, i32, P, i32, i32, P],
     "erd_level_scale": [P, P, P, i32, i64, i32, C.POINTER(Levels), P],
     "erd_level_scale_bwd": [P, P, P, P, P, i32, i64, i32, C.POINTER(Levels), P],
     "erd_sgd_momentum": [P, P, P, i64, f32, f32, f32, f32, i32, P],
@@ -140,7 +142,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t if name.endswith(("_ws_bytes", "_elems")) else C.c_int
-    if lib.erd_abi_version() != 1:
+    if lib.erd_abi_version() != 2:
         raise ErdHipError("liberd_hip.so ABI version mismatch")
     _lib = lib
     return lib

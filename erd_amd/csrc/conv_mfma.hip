@@ -18,6 +18,7 @@
 // Forward conv, stride-1 input-gradient and the 4 parity classes of a stride-2 input-gradient are
 // all expressed through the tap list of erd_conv_desc (include/erd_hip.h).
 #include <algorithm>
+#include <type_traits>
 #include "erd_common.h"
 #include <stdlib.h>
 #ifndef ERD_SGB
@@ -90,7 +91,11 @@ int xcd_order_enabled() {
 // k-values instead of 4 floats (a K-slice is CH*8 values), activations are read as fp32 (two 16-B loads per chunk)
 // and rounded to bf16 on their way into LDS, weights come pre-rounded (erd_conv_desc::w_bf16); accumulation, the
 // stream-K hand-over and the epilogue stay fp32.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false, bool ST = false>
+// AB / OB (bf16 mode only): the input maps / the output, residual and mask maps are STORED as bf16 (erd_conv_desc::
+// in_bf16 / out_bf16): a 16-B load then carries a whole 8-value LDS chunk and needs no conversion, and the epilogue
+// moves 8-B groups of four channels.  Accumulation, scale/shift, the stream-K slabs and the column sums stay fp32.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false,
+          bool OB = false>
 __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
                                                                      const SkWs ws) {
     constexpr int FM = BM / (WAVES_M * 32);
@@ -103,6 +108,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     constexpr int BK = CH * KPC;             // k-values per K-slice
     constexpr bool SGB = ERD_SGB;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(BF || (!AB && !OB), "bf16 storage only with the bf16 matrix cores");
+    constexpr unsigned ABYTES = AB ? 2u : 4u;   // bytes per stored input value
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*CH]
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const RowInfo ri = rows[r0 + RPP * j];
-            a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk * KPC) * 4u;
+            a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk * KPC) * ABYTES;
             unsigned m = 0;
             for (int t = 0; t < nt_s; ++t) {
                 const int ih = ri.ih0 + p.dy[tap_lo + t], iw = ri.iw0 + p.dx[tap_lo + t];
@@ -221,13 +228,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             b_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunk * KPC) * (BF ? 2u : 4u) : OOB;
         }
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+            const_cast<float*>(in), 0, (int)((long long)sg.N * sg.in_nstride * ABYTES), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
             BF ? const_cast<void*>(p.w_bf16) : (void*)const_cast<float*>(w), 0,
             (int)((long long)p.Cout * p.wrow * (BF ? 2 : 4)), 0x00020000);
 
         float4 ra[AJ], rb[BJ];
-        float4 ra1[BF ? AJ : 1];     // bf16 mode: the second half (k+4..k+7) of each 8-value chunk
+        float4 ra1[(BF && !AB) ? AJ : 1];     // bf16 mode on fp32 maps: the second half (k+4..k+7) of each 8-value chunk
         int tap = ks / cpt, cc = ks - tap * cpt;
         // wave-uniform description of the K-slice being fetched
         int adelta = 0, bdelta = 0, ctap = 0;
@@ -235,16 +242,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         auto slice_begin = [&]() {
             const int cb = cc * BK;
             ctap = tap;
-            adelta = ((p.dy[tap_lo + tap] * IW + p.dx[tap_lo + tap]) * Cin + cb) * 4;    // bytes, relative to tap (0,0)
+            adelta = ((p.dy[tap_lo + tap] * IW + p.dx[tap_lo + tap]) * Cin + cb) * (int)ABYTES;    // bytes, relative to tap (0,0)
             bdelta = (p.wk[tap_lo + tap] + cb) * (BF ? 2 : 4);
             cok = cb + chunk * KPC < Cin;   // Cin % 4 == 0: a 4-value group is all-in or all-out
-            cok1 = BF && cb + chunk * KPC + 4 < Cin;
+            cok1 = BF && !AB && cb + chunk * KPC + 4 < Cin;
             if (++cc == cpt) { cc = 0; ++tap; }
         };
         auto load_a = [&](int j) {
             const bool ok = cok && ((a_mask[j] >> ctap) & 1u);
             ra[j] = buf_load16(rs_in, ok ? a_base[j] + (unsigned)adelta : OOB);
-            if (BF) ra1[j] = buf_load16(rs_in, (ok && cok1) ? a_base[j] + (unsigned)adelta + 16u : OOB);
+            if (BF && !AB) ra1[j] = buf_load16(rs_in, (ok && cok1) ? a_base[j] + (unsigned)adelta + 16u : OOB);
         };
         auto load_b = [&](int j) {
             rb[j] = buf_load16(rs_w, cok ? b_base[j] + (unsigned)bdelta : OOB);
@@ -253,10 +260,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const int row = r0 + RPP * j;
-                if (BF)      // (weights past Cin inside the chunk meet zeros here, so partial chunks are exact)
+                if (BF && !AB)      // (weights past Cin inside the chunk meet zeros here, so partial chunks are exact)
                     As[buf * BM * CH + row * CH + swzc(row, chunk)] =
                         make_float4(pack_bf16(ra[j].x, ra[j].y), pack_bf16(ra[j].z, ra[j].w),
-                                    pack_bf16(ra1[j].x, ra1[j].y), pack_bf16(ra1[j].z, ra1[j].w));
+                                    pack_bf16(ra1[(BF && !AB) ? j : 0].x, ra1[(BF && !AB) ? j : 0].y),
+                                    pack_bf16(ra1[(BF && !AB) ? j : 0].z, ra1[(BF && !AB) ? j : 0].w));
                 else
                     As[buf * BM * CH + row * CH + swzc(row, chunk)] = ra[j];
             }
@@ -419,9 +427,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         // A lane owns one output column, so direct stores would be 64 dword stores per lane (store-issue bound).
         // Staging the tile through the (now idle) operand LDS turns them into 16-B stores of whole 512-B rows and
         // lets scale/shift/residual/mask be applied on float4s.
-        float* __restrict__ out = sg.out;
-        const float* res = sg.res;
-        const float* msk = sg.mask;
+        using OutT = typename std::conditional<OB, erd::bf16s, float>::type;      // storage cell of out / res / mask
+        OutT* __restrict__ out = reinterpret_cast<OutT*>(sg.out);
+        const OutT* res = reinterpret_cast<const OutT*>(sg.res);
+        const OutT* msk = reinterpret_cast<const OutT*>(sg.mask);
         const float alpha = sg.alpha ? *sg.alpha : 1.f;
         const bool has_alpha = sg.alpha != nullptr;
         float* stage = reinterpret_cast<float*>(smem);          // [64][BN + 4]
@@ -436,12 +445,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             constexpr int NPF = (FM * 32) / RPS;
             constexpr bool PREFETCH = MINW <= 3;                // (four workgroups per CU: 128 registers, no room)
             float4 pf[PREFETCH ? NPF : 1];                      // residual rows, or mask rows when there is no residual
-            const float* pf_src = res ? res : msk;
+            const OutT* pf_src = res ? res : msk;
             if (PREFETCH && pf_src && (p.Cout & 3) == 0 && n0 + (tid % C4N) * 4 < p.Cout) {
 #pragma unroll
                 for (int q = 0; q < NPF; ++q) {
                     const int oo = rows[half * FM * 32 + tid / C4N + q * RPS].out_off;
-                    if (oo >= 0) pf[PREFETCH ? q : 0] = *reinterpret_cast<const float4*>(pf_src + oo + n0 + (tid % C4N) * 4);
+                    if (oo >= 0) pf[PREFETCH ? q : 0] = erd::ld4(pf_src + oo + n0 + (tid % C4N) * 4);
                 }
             }
             if (wm == half) {
@@ -471,10 +480,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                         float x = stage[rr * SLD + c4 * 4 + e];
                         x = x * (p.scale ? p.scale[co + e] : 1.f) + (p.shift ? p.shift[co + e] : 0.f);
                         if (has_alpha) x *= alpha;
-                        if (res) x += res[oo + co + e];
+                        if (res) x += erd::ld1(res + oo + co + e);
                         if (p.relu) x = fmaxf(x, 0.f);
-                        if (msk) x = msk[oo + co + e] > 0.f ? x : 0.f;
-                        out[oo + co + e] = x;
+                        if (msk) x = erd::ld1(msk + oo + co + e) > 0.f ? x : 0.f;
+                        erd::st1(out + oo + co + e, x);
                         csum[e] += x;
                     }
                 }
@@ -493,16 +502,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                     if (has_alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
                     if (res) {
-                        const float4 rv = PREFETCH ? pf[PREFETCH ? q : 0] : *reinterpret_cast<const float4*>(res + oo + co);
+                        const float4 rv = PREFETCH ? pf[PREFETCH ? q : 0] : erd::ld4(res + oo + co);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (msk) {      // gradient of the ReLU that produced this tensor's forward twin (fused dz = dy*(y>0))
-                        const float4 mv = (PREFETCH && !res) ? pf[PREFETCH ? q : 0] : *reinterpret_cast<const float4*>(msk + oo + co);
+                        const float4 mv = (PREFETCH && !res) ? pf[PREFETCH ? q : 0] : erd::ld4(msk + oo + co);
                         v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
                         v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
                     }
-                    *reinterpret_cast<float4*>(out + oo + co) = v;
+                    erd::st4(out + oo + co, v);
                     csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
                 }
                 if (p.colsum) csum_keep = csum;
@@ -875,6 +884,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
 // 128-B-row XOR swizzle; fragments are then single ds_read_b128s and one v_mfma_f32_32x32x16_bf16 covers 16 pixels.
 // Partial slabs, split-K and the reduce kernel are shared with the fp32 path.
 // -------------------------------------------------------------------------------------------------
+// XB / DB: x / dz are STORED as bf16 (erd_wgrad_desc::x_bf16 / dz_bf16): the micro-tile is then eight 8-B loads (4 channels of
+// one pixel each) and the register transpose is a v_perm_b32 per pixel pair instead of a v_cvt_pk_bf16_f32.
+template <bool XB, bool DB>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(const erd_wgrad_desc p) {
     constexpr int BM = 128, BN = 128, BK = 64;          // BK pixels per K-slice = 8 chunks of 8 pixels
     constexpr int FM = 2, FN = 2;
@@ -933,16 +945,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(const erd_
     };
 
     const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.dz), 0, (int)(p.dz_elems * 4), 0x00020000);
+        const_cast<float*>(p.dz), 0, (int)(p.dz_elems * (DB ? 2 : 4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (int)(p.x_elems * 4), 0x00020000);
-    float4 ra[8], rb[8];
+        const_cast<float*>(p.x), 0, (int)(p.x_elems * (XB ? 2 : 4)), 0x00020000);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    float4 ra[DB ? 1 : 8], rb[XB ? 1 : 8];          // fp32-stored operand: 4 channels of one pixel per load
+    u32x2 ua[DB ? 8 : 1], ub[XB ? 8 : 1];           // bf16-stored operand: the same 4 channels in 8 bytes
     auto load_global = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int2 o = offs[slot * BK + pg * 8 + i];
-            ra[i] = buf_load16(rs_dz, (o.x >= 0 && a_cok) ? (unsigned)(o.x + a_col) * 4u : OOB);
-            rb[i] = buf_load16(rs_x, (o.y >= 0 && b_cok) ? (unsigned)(o.y + b_col) * 4u : OOB);
+            if (DB) ua[DB ? i : 0] = __builtin_amdgcn_raw_buffer_load_b64(rs_dz, (o.x >= 0 && a_cok) ? (unsigned)(o.x + a_col) * 2u : OOB, 0, 0);
+            else ra[DB ? 0 : i] = buf_load16(rs_dz, (o.x >= 0 && a_cok) ? (unsigned)(o.x + a_col) * 4u : OOB);
+            if (XB) ub[XB ? i : 0] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, (o.y >= 0 && b_cok) ? (unsigned)(o.y + b_col) * 2u : OOB, 0, 0);
+            else rb[XB ? 0 : i] = buf_load16(rs_x, (o.y >= 0 && b_cok) ? (unsigned)(o.y + b_col) * 4u : OOB);
         }
     };
     auto swz8 = [](int row, int c) { return c ^ ((row >> 1) & 7); };
@@ -951,15 +967,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(const erd_
         float4* Bd = Bs + buf * BN * 8;
 #define ERD_T4(v, m) make_float4(pack_bf16(v[0].m, v[1].m), pack_bf16(v[2].m, v[3].m), pack_bf16(v[4].m, v[5].m), \
                                  pack_bf16(v[6].m, v[7].m))
+        // bf16-stored: dword m of pixel i holds channels (2m, 2m+1); channel vectors gather the low / high halves of
+        // the eight pixels (v_perm_b32: bytes 0-3 come from the second operand, 4-7 from the first)
+#define ERD_P4(u, m, sel) make_float4(__uint_as_float(__builtin_amdgcn_perm(u[1].m, u[0].m, sel)),   \
+                                      __uint_as_float(__builtin_amdgcn_perm(u[3].m, u[2].m, sel)),   \
+                                      __uint_as_float(__builtin_amdgcn_perm(u[5].m, u[4].m, sel)),   \
+                                      __uint_as_float(__builtin_amdgcn_perm(u[7].m, u[6].m, sel)))
+        constexpr unsigned LO = 0x05040100u, HI = 0x07060302u;
         const int r = cc * 4;
-        Ad[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_T4(ra, x);
-        Ad[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_T4(ra, y);
-        Ad[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_T4(ra, z);
-        Ad[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_T4(ra, w);
-        Bd[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_T4(rb, x);
-        Bd[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_T4(rb, y);
-        Bd[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_T4(rb, z);
-        Bd[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_T4(rb, w);
+        if constexpr (DB) {
+            Ad[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_P4(ua, x, LO);
+            Ad[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_P4(ua, x, HI);
+            Ad[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_P4(ua, y, LO);
+            Ad[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_P4(ua, y, HI);
+        } else {
+            Ad[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_T4(ra, x);
+            Ad[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_T4(ra, y);
+            Ad[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_T4(ra, z);
+            Ad[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_T4(ra, w);
+        }
+        if constexpr (XB) {
+            Bd[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_P4(ub, x, LO);
+            Bd[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_P4(ub, x, HI);
+            Bd[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_P4(ub, y, LO);
+            Bd[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_P4(ub, y, HI);
+        } else {
+            Bd[(r + 0) * 8 + swz8(r + 0, pg)] = ERD_T4(rb, x);
+            Bd[(r + 1) * 8 + swz8(r + 1, pg)] = ERD_T4(rb, y);
+            Bd[(r + 2) * 8 + swz8(r + 2, pg)] = ERD_T4(rb, z);
+            Bd[(r + 3) * 8 + swz8(r + 3, pg)] = ERD_T4(rb, w);
+        }
+#undef ERD_P4
 #undef ERD_T4
     };
 
@@ -1113,7 +1151,7 @@ int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false>
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false, bool OB = false>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     constexpr int BK = (BKT / 4) * (BF ? 8 : 4);
     int tiles = 0;
@@ -1127,7 +1165,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
     const size_t oper = (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4), stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
     const size_t lds = (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1176,6 +1214,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d->Cin > 0 && d->Cin % 4 == 0, "conv: Cin=%d must be a multiple of 4", d->Cin);
     ERD_REQUIRE(d->Cout > 0 && d->wrow % 4 == 0, "conv: Cout=%d wrow=%d", d->Cout, d->wrow);
     ERD_REQUIRE(d->w_bf16 || d->w, "conv: no weights");
+    ERD_REQUIRE(d->w_bf16 || !(d->in_bf16 || d->out_bf16), "conv: bf16 maps need the bf16 matrix-core mode (w_bf16)");
+    ERD_REQUIRE(!d->in_bf16 || d->Cin % 8 == 0, "conv: bf16 input maps need Cin %% 8 == 0 (Cin=%d)", d->Cin);
     ERD_REQUIRE(d->colsum_copies >= 0 && (d->colsum_copies & (d->colsum_copies - 1)) == 0, "conv: colsum_copies=%d must be a power of two",
                 d->colsum_copies);
     for (int s = 0; s < d->nseg; ++s) {
@@ -1193,13 +1233,22 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     static const int variant = getenv("ERD_IGEMM_VARIANT") ? atoi(getenv("ERD_IGEMM_VARIANT")) : 0;   // tuning aid
     bool seg_taps_any = false;
     for (int s = 0; s < d->nseg; ++s) seg_taps_any |= d->seg[s].ntaps > 0;
-    if (seg_taps_any)   // per-segment tap sets (merged parity classes): one dedicated instantiation per precision
-        return d->w_bf16 ? launch_igemm<128, 128, 2, 2, 32, 2, true, true>(d, st) : launch_igemm<128, 128, 2, 2, 32, 2, false, true>(d, st);
     if (d->w_bf16) {    // bf16 matrix cores: the loaders, not the MFMAs, set the pace -> the plain 2-workgroup variant
-        if (variant == 2) return launch_igemm<128, 128, 2, 2, 16, 4, true>(d, st);
-        if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2, true>(d, st);
-        return launch_igemm<128, 128, 2, 2, 32, 2, true>(d, st);
+        // storage of the maps (in_bf16 / out_bf16) picks the instantiation: 0 = fp32 in HBM, 1 = bf16 in HBM
+#define ERD_BF_LAUNCH(AB_, OB_)                                                                       \
+        do {                                                                                          \
+            if (seg_taps_any) return launch_igemm<128, 128, 2, 2, 32, 2, true, true, AB_, OB_>(d, st);  \
+            if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2, true, false, AB_, OB_>(d, st); \
+            return launch_igemm<128, 128, 2, 2, 32, 2, true, false, AB_, OB_>(d, st);                   \
+        } while (0)
+        if (d->in_bf16 && d->out_bf16) ERD_BF_LAUNCH(true, true);
+        if (d->in_bf16) ERD_BF_LAUNCH(true, false);
+        if (d->out_bf16) ERD_BF_LAUNCH(false, true);
+        ERD_BF_LAUNCH(false, false);
+#undef ERD_BF_LAUNCH
     }
+    if (seg_taps_any)   // per-segment tap sets (merged parity classes of a stride-2 input gradient): a dedicated instantiation
+        return launch_igemm<128, 128, 2, 2, 32, 2, false, true>(d, st);
     if (variant == 9) return launch_igemm<128, 128, 2, 2, 32, 1>(d, st);
     if (variant == 1) return launch_igemm<128, 128, 2, 2, 16, 3>(d, st);
     if (variant == 2) return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
@@ -1280,17 +1329,26 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
                 "wgrad: tensors must stay below 2 GiB (32-bit buffer byte offsets)");
     // K-slices of 16 pixels: half the LDS / staging registers of a 32-pixel slice -> four workgroups per CU hide each
     // other's staging and barrier phases (measured +10 % over 32-pixel slices at two per CU, tools/bench_conv.py)
+    ERD_REQUIRE(d->bf16_multiplicands || !(d->x_bf16 || d->dz_bf16), "wgrad: bf16-stored maps need bf16_multiplicands");
     if (d->bf16_multiplicands) {
         const int nci = (d->Cin + 127) / 128, nco = (d->Cout + 127) / 128;
         const size_t lds = (size_t)2 * (128 + 128) * 8 * sizeof(float4) + 2 * 64 * sizeof(int2);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(nci * d->ntaps * nco * d->nsplit), dim3(NTHREADS), lds,
-                           (hipStream_t)stream, *d);
+        const dim3 grid(nci * d->ntaps * nco * d->nsplit);
+#define ERD_WG_LAUNCH(XB_, DB_)                                                                                        \
+        do {                                                                                                           \
+            static bool attr_done = false;                                                                             \
+            if (!attr_done) {                                                                                          \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<XB_, DB_>),             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+                attr_done = true;                                                                                      \
+            }                                                                                                          \
+            hipLaunchKernelGGL((conv_wgrad_bf16_kernel<XB_, DB_>), grid, dim3(NTHREADS), lds, (hipStream_t)stream, *d); \
+        } while (0)
+        if (d->x_bf16 && d->dz_bf16) ERD_WG_LAUNCH(true, true);
+        else if (d->x_bf16) ERD_WG_LAUNCH(true, false);
+        else if (d->dz_bf16) ERD_WG_LAUNCH(false, true);
+        else ERD_WG_LAUNCH(false, false);
+#undef ERD_WG_LAUNCH
         return erd::check_launch("conv_wgrad_bf16");
     }
     static const int variant = getenv("ERD_WGRAD_VARIANT") ? atoi(getenv("ERD_WGRAD_VARIANT")) : 1;   // tuning aid

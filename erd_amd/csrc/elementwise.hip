@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int N,
+template <typename T>      // T: storage cell of the output map (float | erd::bf16s)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float4* __restrict__ in, T* __restrict__ out, int N,
                                                       int H, int W, int C4, int OH, int OW) {
     const int64_t total = (int64_t)N * OH * OW * C4;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float4* __restrict__
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        out[i] = m;
+        erd::st4(out + i * 4, m);
     }
 }
 
@@ -190,7 +191,8 @@ __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restr
 // float4s down its column, 4 rows in flight; the block combines its row lanes through LDS and issues ONE atomic per
 // channel.  Same-address float atomics retire at ~6 per microsecond, so the grid is cut into 64-channel column groups
 // x long row ranges (a few hundred adds per channel) rather than into many short full-width row ranges.
-__global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __restrict__ y, const float* dy, float* dz,
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const T* __restrict__ y, const T* dy, T* dz,
                                                                int64_t npix, int C, int64_t nstride,
                                                                int64_t rows_per_img, float* __restrict__ colsum,
                                                                int use_relu, int rows_per_block, int C4w) {
@@ -216,27 +218,27 @@ __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __res
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     o[q] = offset(r + q * lanes);
-                    g[q] = *reinterpret_cast<const float4*>(dy + o[q]);
-                    if (use_relu) yy[q] = *reinterpret_cast<const float4*>(y + o[q]);
+                    g[q] = erd::ld4(dy + o[q]);
+                    if (use_relu) yy[q] = erd::ld4(y + o[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (use_relu) {
                         g[q].x = yy[q].x > 0.f ? g[q].x : 0.f; g[q].y = yy[q].y > 0.f ? g[q].y : 0.f;
                         g[q].z = yy[q].z > 0.f ? g[q].z : 0.f; g[q].w = yy[q].w > 0.f ? g[q].w : 0.f;
-                        *reinterpret_cast<float4*>(dz + o[q]) = g[q];
+                        erd::st4(dz + o[q], g[q]);
                     }
                     s.x += g[q].x; s.y += g[q].y; s.z += g[q].z; s.w += g[q].w;
                 }
             }
             for (; r < r_end; r += lanes) {
                 const int64_t o = offset(r);
-                float4 g = *reinterpret_cast<const float4*>(dy + o);
+                float4 g = erd::ld4(dy + o);
                 if (use_relu) {
-                    const float4 yy = *reinterpret_cast<const float4*>(y + o);
+                    const float4 yy = erd::ld4(y + o);
                     g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                     g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-                    *reinterpret_cast<float4*>(dz + o) = g;
+                    erd::st4(dz + o, g);
                 }
                 s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
             }
@@ -308,8 +310,8 @@ __device__ __forceinline__ void gn_chunk(const erd_levels& lv, const GnChunks& c
 // Statistics kernels: grid (row chunks, N, 4 column groups).  A block owns 16 float4 columns (64 channels = 8 groups)
 // and 16 row lanes over a long row range: the same bytes in flight as a full-width block over a quarter of the rows,
 // but a quarter of the same-address atomics (those retire at ~6 per microsecond and were the limiter).
-template <int C, int G>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ c, double* __restrict__ stats,
+template <int C, int G, typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ c, double* __restrict__ stats,
                                                        int64_t A, erd_levels lv, GnChunks ch) {
     constexpr int CPG = C / G;         // channels per group (8)
     static_assert(CPG == 8 && C == 256, "tuned for C=256, G=32");
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     for (; r + 48 < r1; r += 64) {
         float4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(c + ((int64_t)n * A + r + 16 * q) * C + c4 * 4);
+        for (int q = 0; q < 4; ++q) v[q] = erd::ld4(c + ((int64_t)n * A + r + 16 * q) * C + c4 * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             sum += v[q].x + v[q].y + v[q].z + v[q].w;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         }
     }
     for (; r < r1; r += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(c + ((int64_t)n * A + r) * C + c4 * 4);
+        const float4 v = erd::ld4(c + ((int64_t)n * A + r) * C + c4 * 4);
         sum += v.x + v.y + v.z + v.w;
         sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
@@ -365,8 +367,8 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, float* __re
     }
 }
 
-template <int C, int G>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ c, float* __restrict__ y,
+template <int C, int G, typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ c, T* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean_rstd, int64_t A, erd_levels lv,
                                                        GnChunks ch) {
@@ -380,20 +382,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const float4 be = reinterpret_cast<const float4*>(beta)[c4];
     for (int64_t r = r0 + rl; r < r1; r += 4) {
         const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
-        const float4 v = *reinterpret_cast<const float4*>(c + off);
+        const float4 v = erd::ld4(c + off);
         float4 o;
         o.x = fmaxf((v.x - mr.x) * mr.y * ga.x + be.x, 0.f);
         o.y = fmaxf((v.y - mr.x) * mr.y * ga.y + be.y, 0.f);
         o.z = fmaxf((v.z - mr.x) * mr.y * ga.z + be.z, 0.f);
         o.w = fmaxf((v.w - mr.x) * mr.y * ga.w + be.w, 0.f);
-        *reinterpret_cast<float4*>(y + off) = o;
+        erd::st4(y + off, o);
     }
 }
 
 // backward pass 1: per (n,level,group) s1 = sum dyh, s2 = sum dyh*xhat (dyh = dy*mask*gamma);
 // per channel dgamma += sum dy*mask*xhat, dbeta += sum dy*mask
-template <int C, int G>
-__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ c, const float* __restrict__ dy,
+template <int C, int G, typename T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ c, const T* __restrict__ dy,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ mean_rstd,
@@ -424,15 +426,15 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
     int64_t r = r0 + rl;
     for (; r + 16 < r1; r += 32) {          // two rows in flight per thread
         const int64_t off0 = ((int64_t)n * A + r) * C + c4 * 4, off1 = off0 + (int64_t)16 * C;
-        const float4 v0 = *reinterpret_cast<const float4*>(c + off0), d0 = *reinterpret_cast<const float4*>(dy + off0);
-        const float4 v1 = *reinterpret_cast<const float4*>(c + off1), d1 = *reinterpret_cast<const float4*>(dy + off1);
+        const float4 v0 = erd::ld4(c + off0), d0 = erd::ld4(dy + off0);
+        const float4 v1 = erd::ld4(c + off1), d1 = erd::ld4(dy + off1);
         { const float4 v = v0, d = d0; GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w) }
         { const float4 v = v1, d = d1; GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w) }
     }
     for (; r < r1; r += 16) {
         const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
-        const float4 v = *reinterpret_cast<const float4*>(c + off);
-        const float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 v = erd::ld4(c + off);
+        const float4 d = erd::ld4(dy + off);
         GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w)
     }
 #undef GN_ONE
@@ -467,12 +469,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 }
 
 // backward pass 2: dc = rstd * (dyh - (s1 + xhat*s2)/m)
-template <int C, int G>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ c, const float* __restrict__ dy,
+template <int C, int G, typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ c, const T* __restrict__ dy,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ mean_rstd,
-                                                           const double* __restrict__ stats, float* __restrict__ dc,
+                                                           const double* __restrict__ stats, T* __restrict__ dc,
                                                            int64_t A, erd_levels lv, GnChunks ch) {
     const int n = blockIdx.y;
     int s; int64_t r0, r1;
@@ -487,8 +489,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float4 be = reinterpret_cast<const float4*>(beta)[c4];
     for (int64_t r = r0 + rl; r < r1; r += 4) {
         const int64_t off = ((int64_t)n * A + r) * C + c4 * 4;
-        const float4 v = *reinterpret_cast<const float4*>(c + off);
-        const float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 v = erd::ld4(c + off);
+        const float4 d = erd::ld4(dy + off);
         float4 o;
 #define GN_ONE(F)                                                          \
         {                                                                  \
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         }
         GN_ONE(x) GN_ONE(y) GN_ONE(z) GN_ONE(w)
 #undef GN_ONE
-        *reinterpret_cast<float4*>(dc + off) = o;
+        erd::st4(dc + off, o);
     }
 }
 
@@ -516,7 +518,8 @@ GnChunks make_chunks(const erd_levels* lv, int rows = GN_ROWS) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void upsample_add_kernel(float4* __restrict__ fine, const float4* __restrict__ coarse,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_kernel(T* __restrict__ fine, const T* __restrict__ coarse,
                                                            int N, int H, int W, int C4, int h, int w, int64_t fns,
                                                            int64_t cns) {
     const int64_t total = (int64_t)N * H * W * C4;
@@ -528,17 +531,18 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(float4* __restrict__ 
         const int n = r / H;
         // F.interpolate(mode='nearest', size=(H,W)): src = floor(dst * (h/H)); exact 2x => dst>>1
         const int sy = min((int)((int64_t)y * h / H), h - 1), sx = min((int)((int64_t)x * w / W), w - 1);
-        float4* f = fine + (n * fns + ((int64_t)y * W + x) * C4 * 4) / 4 + c;
-        const float4 cv = coarse[(n * cns + ((int64_t)sy * w + sx) * C4 * 4) / 4 + c];
-        float4 v = *f;
+        T* f = fine + n * fns + (((int64_t)y * W + x) * C4 + c) * 4;
+        const float4 cv = erd::ld4(coarse + n * cns + (((int64_t)sy * w + sx) * C4 + c) * 4);
+        float4 v = erd::ld4(f);
         v.x += cv.x; v.y += cv.y; v.z += cv.z; v.w += cv.w;
-        *f = v;
+        erd::st4(f, v);
     }
 }
 
 // adjoint: dcoarse[sy,sx] += sum of dfine over the pixels that map to it
-__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float4* __restrict__ dfine,
-                                                               float4* __restrict__ dcoarse, int N, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const T* __restrict__ dfine,
+                                                               T* __restrict__ dcoarse, int N, int H, int W,
                                                                int C4, int h, int w, int64_t fns, int64_t cns) {
     const int64_t total = (int64_t)N * h * w * C4;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -553,22 +557,23 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float4* __r
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int y = y0; y < min(y1, H); ++y)
             for (int x = x0; x < min(x1, W); ++x) {
-                const float4 v = dfine[(n * fns + ((int64_t)y * W + x) * C4 * 4) / 4 + c];
+                const float4 v = erd::ld4(dfine + n * fns + (((int64_t)y * W + x) * C4 + c) * 4);
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
-        float4* d = dcoarse + (n * cns + ((int64_t)sy * w + sx) * C4 * 4) / 4 + c;
-        float4 o = *d;
+        T* d = dcoarse + n * cns + (((int64_t)sy * w + sx) * C4 + c) * 4;
+        float4 o = erd::ld4(d);
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-        *d = o;
+        erd::st4(d, o);
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t rows, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, int C,
                                                      float* __restrict__ out, int rows_per_block) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += x[r * C + c];
+        for (int64_t r = r0; r < r1; ++r) s += erd::ld1(x + r * C + c);
         atomicAdd(out + c, s);
     }
 }
@@ -647,12 +652,20 @@ extern "C" int erd_stem_conv7x7_bn_relu(const float* x, const float* w, const fl
     return erd::check_launch("stem");
 }
 
-extern "C" int erd_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, erd_stream_t stream) {
-    ERD_REQUIRE(in && out && C % 4 == 0, "maxpool: bad args");
+// map_type dispatch of the templated kernels: ERD_MAP(T, statement using T)
+#define ERD_MAP(map_type, ...)                                   \
+    do {                                                         \
+        if ((map_type) == ERD_BF16) { using T = erd::bf16s; __VA_ARGS__; } \
+        else { using T = float; __VA_ARGS__; }                   \
+    } while (0)
+#define ERD_MAP_OK(map_type) ((map_type) == ERD_F32 || (map_type) == ERD_BF16)
+
+extern "C" int erd_maxpool3x3s2(const float* in, void* out, int N, int H, int W, int C, int out_type, erd_stream_t stream) {
+    ERD_REQUIRE(in && out && C % 4 == 0 && ERD_MAP_OK(out_type), "maxpool: bad args");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), N, H, W, C / 4, OH, OW);
+    ERD_MAP(out_type, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                                         reinterpret_cast<const float4*>(in), reinterpret_cast<T*>(out), N, H, W, C / 4, OH, OW));
     return erd::check_launch("maxpool");
 }
 
@@ -794,10 +807,10 @@ extern "C" int erd_bn_fold(const float* gamma, const float* beta, const float* m
     return erd::check_launch("bn_fold");
 }
 
-extern "C" int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, int64_t npix, int C,
+extern "C" int erd_relu_bwd_colsum(const void* y, const void* dy, void* dz, int64_t npix, int C,
                                    int64_t nstride_rows, int64_t rows_per_img, float* colsum, int use_relu,
-                                   erd_stream_t stream) {
-    ERD_REQUIRE(dy && C % 4 == 0 && (!use_relu || (y && dz)), "relu_bwd: bad args");
+                                   int map_type, erd_stream_t stream) {
+    ERD_REQUIRE(dy && C % 4 == 0 && (!use_relu || (y && dz)) && ERD_MAP_OK(map_type), "relu_bwd: bad args");
     if (npix == 0) return 0;
     const int C4 = C / 4;
     ERD_REQUIRE(C4 % 16 == 0 || 256 % C4 == 0, "relu_bwd: C=%d unsupported", C);
@@ -807,8 +820,9 @@ extern "C" int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, i
     const int unit = 4 * lanes;                                     // rows one pass of the unrolled loop covers
     int64_t rpb = (npix + (want / gy > 0 ? want / gy : 1) - 1) / (want / gy > 0 ? want / gy : 1);
     rpb = (rpb + unit - 1) / unit * unit;
-    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((unsigned)((npix + rpb - 1) / rpb), gy), dim3(256), 0,
-                       (hipStream_t)stream, y, dy, dz, npix, C, nstride_rows, rows_per_img, colsum, use_relu, (int)rpb, cw4);
+    ERD_MAP(map_type, hipLaunchKernelGGL(relu_bwd_colsum_kernel<T>, dim3((unsigned)((npix + rpb - 1) / rpb), gy), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)y, (const T*)dy, (T*)dz, npix, C, nstride_rows,
+                                         rows_per_img, colsum, use_relu, (int)rpb, cw4));
     return erd::check_launch("relu_bwd_colsum");
 }
 
@@ -820,69 +834,70 @@ extern "C" int erd_bn_dgamma(const float* rowdot, const float* dbeta, int copies
     return erd::check_launch("bn_dgamma");
 }
 
-extern "C" int erd_gn_relu_fwd(const float* c, float* y, const float* gamma, const float* beta, double* stats_ws,
+extern "C" int erd_gn_relu_fwd(const void* c, void* y, const float* gamma, const float* beta, double* stats_ws,
                                float* mean_rstd, int N, int64_t A, int C, int G, const erd_levels* lv, float eps,
-                               erd_stream_t stream) {
-    ERD_REQUIRE(c && y && gamma && beta && stats_ws && mean_rstd && lv, "gn_fwd: null");
+                               int map_type, erd_stream_t stream) {
+    ERD_REQUIRE(c && y && gamma && beta && stats_ws && mean_rstd && lv && ERD_MAP_OK(map_type), "gn_fwd: bad args");
     ERD_REQUIRE(C == 256 && G == 32, "gn_fwd: only C=256,G=32 (gfl_head.py:109-110) is built");
     hipStream_t st = (hipStream_t)stream;
     const GnChunks ch = make_chunks(lv);
     const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
-    hipLaunchKernelGGL((gn_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st, c, stats_ws, A, *lv, chs);
+    ERD_MAP(map_type, hipLaunchKernelGGL((gn_stats_kernel<256, 32, T>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st,
+                                         (const T*)c, stats_ws, A, *lv, chs));
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nst + 255) / 256), dim3(256), 0, st, stats_ws, mean_rstd, N, G, *lv,
                        C / G, eps);
-    hipLaunchKernelGGL((gn_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, y, gamma, beta,
-                       mean_rstd, A, *lv, ch);
+    ERD_MAP(map_type, hipLaunchKernelGGL((gn_apply_kernel<256, 32, T>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st,
+                                         (const T*)c, (T*)y, gamma, beta, mean_rstd, A, *lv, ch));
     return erd::check_launch("gn_relu_fwd");
 }
 
-extern "C" int erd_gn_relu_bwd(const float* c, const float* dy, const float* gamma, const float* beta,
-                               const float* mean_rstd, double* stats_ws, float* dc, float* dgamma, float* dbeta, int N,
-                               int64_t A, int C, int G, const erd_levels* lv, erd_stream_t stream) {
-    ERD_REQUIRE(c && dy && gamma && beta && mean_rstd && stats_ws && dc && dgamma && dbeta && lv, "gn_bwd: null");
+extern "C" int erd_gn_relu_bwd(const void* c, const void* dy, const float* gamma, const float* beta,
+                               const float* mean_rstd, double* stats_ws, void* dc, float* dgamma, float* dbeta, int N,
+                               int64_t A, int C, int G, const erd_levels* lv, int map_type, erd_stream_t stream) {
+    ERD_REQUIRE(c && dy && gamma && beta && mean_rstd && stats_ws && dc && dgamma && dbeta && lv && ERD_MAP_OK(map_type),
+                "gn_bwd: bad args");
     ERD_REQUIRE(C == 256 && G == 32, "gn_bwd: only C=256,G=32 is built");
     hipStream_t st = (hipStream_t)stream;
     const GnChunks ch = make_chunks(lv);
     const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
-    hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st, c, dy, gamma,
-                       beta, mean_rstd, stats_ws, dgamma, dbeta, A, *lv, chs);
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<256, 32>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st, c, dy, gamma,
-                       beta, mean_rstd, stats_ws, dc, A, *lv, ch);
+    ERD_MAP(map_type, hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32, T>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st,
+                                         (const T*)c, (const T*)dy, gamma, beta, mean_rstd, stats_ws, dgamma, dbeta, A, *lv, chs));
+    ERD_MAP(map_type, hipLaunchKernelGGL((gn_bwd_apply_kernel<256, 32, T>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st,
+                                         (const T*)c, (const T*)dy, gamma, beta, mean_rstd, stats_ws, (T*)dc, A, *lv, ch));
     return erd::check_launch("gn_relu_bwd");
 }
 
-extern "C" int erd_upsample2x_add(float* fine, const float* coarse, int N, int H, int W, int C, int h, int w,
-                                  int64_t fns, int64_t cns, erd_stream_t stream) {
-    ERD_REQUIRE(fine && coarse && C % 4 == 0 && fns % 4 == 0 && cns % 4 == 0, "upsample_add: bad args");
+extern "C" int erd_upsample2x_add(void* fine, const void* coarse, int N, int H, int W, int C, int h, int w,
+                                  int64_t fns, int64_t cns, int map_type, erd_stream_t stream) {
+    ERD_REQUIRE(fine && coarse && C % 4 == 0 && fns % 4 == 0 && cns % 4 == 0 && ERD_MAP_OK(map_type), "upsample_add: bad args");
     const int64_t total = (int64_t)N * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<float4*>(fine), reinterpret_cast<const float4*>(coarse), N, H, W, C / 4, h, w,
-                       fns, cns);
+    ERD_MAP(map_type, hipLaunchKernelGGL(upsample_add_kernel<T>, dim3(grid_for(total, 4096)), dim3(256), 0, (hipStream_t)stream,
+                                         (T*)fine, (const T*)coarse, N, H, W, C / 4, h, w, fns, cns));
     return erd::check_launch("upsample_add");
 }
 
-extern "C" int erd_upsample2x_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int C, int h, int w,
-                                      int64_t fns, int64_t cns, erd_stream_t stream) {
-    ERD_REQUIRE(dfine && dcoarse && C % 4 == 0 && fns % 4 == 0 && cns % 4 == 0, "upsample_add_bwd: bad args");
+extern "C" int erd_upsample2x_add_bwd(const void* dfine, void* dcoarse, int N, int H, int W, int C, int h, int w,
+                                      int64_t fns, int64_t cns, int map_type, erd_stream_t stream) {
+    ERD_REQUIRE(dfine && dcoarse && C % 4 == 0 && fns % 4 == 0 && cns % 4 == 0 && ERD_MAP_OK(map_type), "upsample_add_bwd: bad args");
     const int64_t total = (int64_t)N * h * w * (C / 4);
-    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for(total, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(dfine), reinterpret_cast<float4*>(dcoarse), N, H, W, C / 4, h, w,
-                       fns, cns);
+    ERD_MAP(map_type, hipLaunchKernelGGL(upsample_add_bwd_kernel<T>, dim3(grid_for(total, 4096)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)dfine, (T*)dcoarse, N, H, W, C / 4, h, w, fns, cns));
     return erd::check_launch("upsample_add_bwd");
 }
 
-extern "C" int erd_colsum(const float* x, int64_t rows, int C, float* out, int accumulate, erd_stream_t stream) {
-    ERD_REQUIRE(x && out && C > 0, "colsum: bad args");
+extern "C" int erd_colsum(const void* x, int64_t rows, int C, float* out, int accumulate, int map_type, erd_stream_t stream) {
+    ERD_REQUIRE(x && out && C > 0 && ERD_MAP_OK(map_type), "colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * C, st);
     if (rows == 0) return 0;
     int rpb = 64;
     while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x, rows, C, out, rpb);
+    ERD_MAP(map_type, hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st,
+                                         (const T*)x, rows, C, out, rpb));
     return erd::check_launch("colsum");
 }
 

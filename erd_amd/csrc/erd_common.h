@@ -43,4 +43,31 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- bf16 storage (BASELINE.json configs[2]: activations and their gradients live in HBM as bf16) ----------------
+// Values are rounded to nearest even on the way out (v_cvt_pk_bf16_f32) and widened exactly on the way in.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {      // a -> bits 0..15 (lower address), b -> 16..31
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float4 unpack4_bf16(uint2 u) {
+    return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+}
+__device__ __forceinline__ uint2 pack4_bf16(float4 v) { return make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w)); }
+
+// Element type of a map: float or erd::bf16s (a 16-bit storage cell).  ld4 / st4 move four consecutive values
+// (16-B / 8-B aligned), ld1 / st1 one.
+struct bf16s { unsigned short bits; };
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16s* p) { return unpack4_bf16(*reinterpret_cast<const uint2*>(p)); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16s* p, float4 v) { *reinterpret_cast<uint2*>(p) = pack4_bf16(v); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16s* p) { return __uint_as_float((unsigned)p->bits << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16s* p, float v) { p->bits = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu); }
+
 }  // namespace erd

@@ -222,7 +222,7 @@ class ConvBNAct(Function):
         scale, shift = _bn_fold_cached(gamma, beta, mean, var, eps)
         N, H, W_, _ = x.shape
         OH, OW = K.conv_out_size(H, k, stride, pad), K.conv_out_size(W_, k, stride, pad)
-        out = torch.empty((N, OH, OW, wk.shape[0]), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, OH, OW, wk.shape[0]), dtype=x.dtype, device=x.device)      # maps keep their storage type
         K.conv_forward([x], wk, [out], k, stride, pad, scale=scale, shift=shift,
                        res=None if res is None else [res], relu=relu)
         ctx.cfg = (k, stride, pad, relu, eps, res is not None)
@@ -280,7 +280,7 @@ class BottleneckFn(Function):
             scale, shift = _bn_fold_cached(g, b, m, v, eps)
             N, H, W_, _ = inp.shape
             out = torch.empty((N, K.conv_out_size(H, k, s, pad), K.conv_out_size(W_, k, s, pad), wk.shape[0]),
-                              dtype=torch.float32, device=dev)
+                              dtype=inp.dtype, device=dev)
             K.conv_forward([inp], wk, [out], k, s, pad, scale=scale, shift=shift,
                            res=None if res is None else [res], relu=relu)
             return out, scale
@@ -400,7 +400,7 @@ class ConvBias(Function):
         wk = ohwi(w)
         N, H, W_, _ = x.shape
         OH, OW = K.conv_out_size(H, k, stride, pad), K.conv_out_size(W_, k, stride, pad)
-        out = torch.empty((N, OH, OW, wk.shape[0]), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, OH, OW, wk.shape[0]), dtype=x.dtype, device=x.device)
         K.conv_forward([x], wk, [out], k, stride, pad, shift=b.detach())
         ctx.cfg = (k, stride, pad)
         ctx.save_for_backward(x, w)
@@ -438,7 +438,7 @@ class UpsampleAdd(Function):
         dout = dout.contiguous()
         dcoarse = None
         if ctx.needs_input_grad[1]:
-            dcoarse = torch.zeros(ctx.cshape, dtype=torch.float32, device=dout.device)
+            dcoarse = torch.zeros(ctx.cshape, dtype=dout.dtype, device=dout.device)
             K.upsample_add_bwd_(dout, dcoarse)
         return dout, dcoarse
 
@@ -462,7 +462,7 @@ class FPNOutputs(Function):
             sizes.append((h, w_))
         A = sum(a * b for a, b in sizes)
         Cc = w0.shape[0]
-        cat = torch.empty((N, A, Cc), dtype=torch.float32, device=l3.device)
+        cat = torch.empty((N, A, Cc), dtype=l3.dtype, device=l3.device)
         views = K.level_views(cat, sizes)
         for i in range(3):
             K.conv_forward([lats[i]], ohwi(ws[i]), [views[i]], 3, 1, 1, shift=bs[i].detach())
@@ -513,7 +513,7 @@ class HeadConvGN(Function):
     def forward(ctx, x_cat, w, gamma, beta, sizes, eps: float):
         K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         wk = ohwi(w)
-        c = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=torch.float32, device=x_cat.device)
+        c = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=x_cat.dtype, device=x_cat.device)
         K.conv_forward(K.level_views(x_cat, sizes), wk, K.level_views(c, sizes), 3, 1, 1)
         y, mr = K.gn_relu_forward(c, gamma.detach(), beta.detach(), sizes, 32, eps)
         ctx.sizes = sizes
@@ -543,6 +543,7 @@ class HeadConvBias(Function):
     def forward(ctx, x_cat, w, b, sizes):
         K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
         wk = ohwi(w)
+        # the head outputs feed the losses, ERS and NMS: always fp32 (gfl_head.py:224-229; autocast keeps the losses fp32)
         out = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=torch.float32, device=x_cat.device)
         K.conv_forward(K.level_views(x_cat, sizes), wk, K.level_views(out, sizes), 3, 1, 1, shift=b.detach())
         ctx.sizes = sizes

@@ -127,7 +127,7 @@ def ws_float(name: str, n: int, device) -> Tensor:
 # the image stride may be larger (level views of a [N,A,C] buffer).
 # ---------------------------------------------------------------------------------------------
 def _check_map(t: Tensor) -> None:
-    assert t.dtype == torch.float32 and t.dim() == 4, (t.dtype, t.shape)
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4, (t.dtype, t.shape)
     N, H, W, Cc = t.shape
     st = t.stride()
     assert st[3] == 1 and st[2] == Cc and st[1] == W * Cc, f"map is not NHWC-dense: {t.shape} {st}"
@@ -168,6 +168,23 @@ def set_compute(mode: str) -> None:
     if mode not in ("f32", "bf16"):
         raise ValueError(f"compute mode {mode!r}: 'f32' or 'bf16'")
     COMPUTE = mode
+
+
+def act_dtype() -> torch.dtype:
+    """storage type of feature maps and their gradients: bf16 in the bf16 mode (BASELINE.json configs[2]; the reference's
+    AMP switch, tools/train.py:85-97), fp32 otherwise.  The image, the head outputs (gfl_head.py:224-229 feed the losses),
+    every statistic / reduction / parameter / parameter gradient stay fp32 in both modes."""
+    return torch.bfloat16 if COMPUTE == "bf16" and BF16_STORAGE else torch.float32
+
+
+BF16_STORAGE = _os.environ.get("ERD_BF16_STORAGE", "1") != "0"    # 0: the round-1 form (bf16 multiplicands, fp32 maps): A/B aid
+
+
+def _mt(*ts: Tensor) -> int:
+    """erd_hip.h map_type of a group of maps that must share it (ERD_F32 = 0 | ERD_BF16 = 1)"""
+    dts = {t.dtype for t in ts if t is not None}
+    assert len(dts) == 1 and dts <= {torch.float32, torch.bfloat16}, f"maps must share one storage type: {dts}"
+    return 1 if dts.pop() == torch.bfloat16 else 0
 
 
 def to_bf16(t: Tensor) -> Tensor:
@@ -229,6 +246,16 @@ def _fill_seg(sg, x: Tensor, out: Tensor, GH: int, GW: int, res: Optional[Tensor
         _check_map(res)
         assert res.shape == out.shape and res.stride(0) == out.stride(0), "residual must share the output geometry"
         sg.res_nstride = res.stride(0)
+
+
+def _stored_bf16(*groups) -> int:
+    """1 when the maps of these groups are stored as bf16, 0 for fp32; one launch never mixes the two within a role
+    (inputs | outputs + residuals + masks)."""
+    dts = {t.dtype for g in groups if g is not None for t in g if t is not None}
+    assert len(dts) == 1, f"maps of one role must share a storage type: {dts}"
+    bf = dts.pop() == torch.bfloat16
+    assert not bf or COMPUTE == "bf16", "bf16-stored maps need set_compute('bf16')"
+    return 1 if bf else 0
 
 
 STREAMK = _os.environ.get('ERD_STREAMK', '1') != '0'     # stream-K work decomposition of the implicit-GEMM launches (see conv_mfma.hip)
@@ -301,6 +328,7 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     if COMPUTE == "bf16":
         wb = _weights_bf16(w)          # (kept alive by this frame until the launch is queued; stream-ordered free)
         d.w_bf16 = wb.data_ptr()
+    d.in_bf16, d.out_bf16 = _stored_bf16(xs), _stored_bf16(outs, res)
     _attach_sk_ws(d, w.device)
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
     nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel()) if _TIMING is not None else 0.0
@@ -480,6 +508,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.colsum_copies = 0 if colsum is None else colsum.numel() // Cin        # [copies, Cin of the forward conv]
         if wtb is not None:
             d.w_bf16 = wtb.data_ptr()
+        d.in_bf16, d.out_bf16 = _stored_bf16(dzs), _stored_bf16(dxs, res, relu_mask)
         _attach_sk_ws(d, wt.device)
         flop = 2.0 * sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg)) * Cin * len(taps) * Cout
         # (stride 2: each parity class reads dz once and writes a quarter of dx)
@@ -529,6 +558,7 @@ def _dgrad_s2_merged(dz: Tensor, wt: Tensor, wtb, dx: Tensor, pad: int, Cin: int
     d.colsum_copies = 0 if colsum is None else colsum.numel() // Cin
     if wtb is not None:
         d.w_bf16 = wtb.data_ptr()
+    d.in_bf16, d.out_bf16 = _stored_bf16([dz]), _stored_bf16([dx], res, relu_mask)
     d.sk_ws, d.sk_ws_bytes = 0, 0
     nbytes = 4.0 * (dz.numel() + dx.numel() + wt.numel()) if _TIMING is not None else 0.0
     _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes,
@@ -572,7 +602,7 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
         sg = d.seg[i]
         px, nx = _extent(x)
         pz, nz = _extent(dz)
-        sg.x_off, sg.dz_off = (px - xb) // 4, (pz - zb) // 4
+        sg.x_off, sg.dz_off = (px - xb) // x.element_size(), (pz - zb) // dz.element_size()
         xe, ze = max(xe, sg.x_off + nx), max(ze, sg.dz_off + nz)
         sg.N, sg.IH, sg.IW = x.shape[0], x.shape[1], x.shape[2]
         sg.GH, sg.GW, sg.OH, sg.OW = dz.shape[1], dz.shape[2], dz.shape[1], dz.shape[2]
@@ -584,6 +614,7 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
             d.dy[kh * k + kw], d.dx[kh * k + kw] = kh - pad, kw - pad
     d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
     d.bf16_multiplicands = 1 if COMPUTE == "bf16" else 0
+    d.x_bf16, d.dz_bf16 = _stored_bf16(xs), _stored_bf16(dzs)
     row3 = int(_lib.load().erd_wgrad_row3_slices(C.byref(d))) if _os.environ.get("ERD_WGRAD_ROW3", "1") != "0" else 0
     if row3:      # three taps per workgroup, two workgroups per CU: ONE whole dispatch round of (cout, cin, ky, split) workgroups
         # (measured best: 2 or 3 rounds pay more partial-slab traffic than they gain; a ragged extra round costs 15-40 %)
@@ -620,11 +651,11 @@ def stem(x_nchw: Tensor, w_ohwi: Tensor, scale: Tensor, shift: Tensor) -> Tensor
     assert x_nchw.is_contiguous() and x_nchw.shape[1] == 3 and w_ohwi.shape == (64, 7, 7, 3) and w_ohwi.is_contiguous()
     N, _, H, W = x_nchw.shape
     OH, OW = conv_out_size(H, 7, 2, 3), conv_out_size(W, 7, 2, 3)
-    y = torch.empty((N, OH, OW, 64), dtype=torch.float32, device=x_nchw.device)
+    y = torch.empty((N, OH, OW, 64), dtype=torch.float32, device=x_nchw.device)      # (stem output: fp32 scratch, pooled once)
     call("erd_stem_conv7x7_bn_relu", _p(x_nchw), _p(w_ohwi), _p(scale), _p(shift), _p(y), N, H, W, _stream())
     PH, PW = conv_out_size(OH, 3, 2, 1), conv_out_size(OW, 3, 2, 1)
-    z = torch.empty((N, PH, PW, 64), dtype=torch.float32, device=x_nchw.device)
-    call("erd_maxpool3x3s2", _p(y), _p(z), N, OH, OW, 64, _stream())
+    z = torch.empty((N, PH, PW, 64), dtype=act_dtype(), device=x_nchw.device)
+    call("erd_maxpool3x3s2", _p(y), _p(z), N, OH, OW, 64, _mt(z), _stream())
     return z
 
 
@@ -674,7 +705,7 @@ def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum
         assert y.is_contiguous() and dy.is_contiguous(), "relu backward runs on dense maps"
         dz = torch.empty_like(dy)
     call("erd_relu_bwd_colsum", _p(y), _p(dy), _p(dz), N * H * W, Cc, dy.stride(0), H * W, _p(colsum),
-         1 if use_relu else 0, _stream())
+         1 if use_relu else 0, _mt(dy, y if use_relu else None), _stream())
     return dz, colsum
 
 
@@ -697,7 +728,7 @@ def colsum(x2d: Tensor) -> Tensor:
     assert x2d.is_contiguous()
     rows, Cc = x2d.shape[:-1].numel(), x2d.shape[-1]
     out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
-    call("erd_colsum", _p(x2d), rows, Cc, _p(out), 0, _stream())
+    call("erd_colsum", _p(x2d), rows, Cc, _p(out), 0, _mt(x2d), _stream())
     return out
 
 
@@ -712,7 +743,7 @@ def gn_relu_forward(c: Tensor, gamma: Tensor, beta: Tensor, sizes, G: int = 32, 
     stats = workspace("gn_stats", nst * 16, c.device)
     mr = torch.empty((N, lv.nseg, G, 2), dtype=torch.float32, device=c.device)
     call("erd_gn_relu_fwd", _p(c), _p(y), _p(gamma), _p(beta), _p(stats), _p(mr), N, A, Cc, G, C.byref(lv), eps,
-         _stream())
+         _mt(c), _stream())
     return y, mr
 
 
@@ -725,7 +756,7 @@ def gn_relu_backward(c: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mr: Ten
     dgamma = zeros_f32(gamma.numel(), c.device)
     dbeta = zeros_f32(beta.numel(), c.device)
     call("erd_gn_relu_bwd", _p(c), _p(dy), _p(gamma), _p(beta), _p(mr), _p(stats), _p(dc), _p(dgamma), _p(dbeta), N, A,
-         Cc, G, C.byref(lv), _stream())
+         Cc, G, C.byref(lv), _mt(c, dy), _stream())
     return dc, dgamma, dbeta
 
 
@@ -734,7 +765,7 @@ def upsample_add_(fine: Tensor, coarse: Tensor) -> None:
     _check_map(coarse)
     N, H, W, Cc = fine.shape
     call("erd_upsample2x_add", _p(fine), _p(coarse), N, H, W, Cc, coarse.shape[1], coarse.shape[2], fine.stride(0),
-         coarse.stride(0), _stream())
+         coarse.stride(0), _mt(fine, coarse), _stream())
 
 
 def upsample_add_bwd_(dfine: Tensor, dcoarse: Tensor) -> None:
@@ -743,7 +774,7 @@ def upsample_add_bwd_(dfine: Tensor, dcoarse: Tensor) -> None:
     _check_map(dcoarse)
     N, H, W, Cc = dfine.shape
     call("erd_upsample2x_add_bwd", _p(dfine), _p(dcoarse), N, H, W, Cc, dcoarse.shape[1], dcoarse.shape[2],
-         dfine.stride(0), dcoarse.stride(0), _stream())
+         dfine.stride(0), dcoarse.stride(0), _mt(dfine, dcoarse), _stream())
 
 
 def level_scale(x: Tensor, alphas: Tensor, sizes) -> Tensor:

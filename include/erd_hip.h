@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERD_ABI_VERSION 1
+#define ERD_ABI_VERSION 2
 #define ERD_MAX_SEG 5   /* FPN levels batched in one launch */
 #define ERD_MAX_TAPS 9
 
@@ -35,6 +35,13 @@ extern "C" {
 #define ERD_EUNSUPPORTED (-2)
 
 typedef void* erd_stream_t; /* hipStream_t */
+
+/* Storage type of feature maps and their gradients in HBM.  ERD_F32: the headline configuration.  ERD_BF16: BASELINE.json
+ * configs[2] -- what the reference's AMP switch does to conv outputs (tools/train.py:85-97): values are rounded to
+ * nearest even when stored, widened exactly when loaded; every reduction, statistic, scale/shift and loss stays fp32
+ * (GroupNorm statistics in fp64 as before).  Entry points that take maps as `void*` take a map_type next to them;
+ * strides, offsets and extents are always in ELEMENTS. */
+enum { ERD_F32 = 0, ERD_BF16 = 1 };
 
 int erd_abi_version(void);
 const char* erd_last_error(void);
@@ -87,6 +94,11 @@ typedef struct {
     /* 0 / 1: one row of sums.  2^k: workgroup b adds into row (b mod 2^k) -- same-address float atomics retire at about
      * six per microsecond, a 1000-tile launch would otherwise wait for them; the consumer folds the rows (erd_bn_dgamma). */
     int colsum_copies;
+    /* bf16 storage of the maps (only with w_bf16): in_bf16 = every seg.in holds bf16 values, out_bf16 = every seg.out /
+     * seg.res / seg.mask holds bf16 values (round to nearest even on store).  Strides and extents stay in ELEMENTS.
+     * 0 / 0 = fp32 maps.  Cin % 8 == 0 with in_bf16.  The reference's AMP switch (tools/train.py:85-97) stores conv
+     * outputs in the low-precision type the same way. */
+    int in_bf16, out_bf16;
 } erd_conv_desc;
 
 /* replaces: F.conv2d dispatches at resnet.py:268-283, res_layer.py:57-63, fpn.py:196,215-220,
@@ -138,6 +150,8 @@ typedef struct {
     float* part;         /* [nsplit][Cout][ntaps][Cin] */
     int nsplit;
     int bf16_multiplicands; /* 1: round dz and x to bf16 as they are staged and use the bf16 matrix cores (fp32 partials) */
+    int x_bf16, dz_bf16;    /* 1: the x / dz maps are stored as bf16 (offsets, strides, extents stay in elements); only
+                             * with bf16_multiplicands */
 } erd_wgrad_desc;
 int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream);
 /* > 0: the layer takes the three-taps-per-workgroup kernel (3x3, stride 1, pad 1, fp32) and this is its number of
@@ -164,7 +178,8 @@ int erd_weight_transpose_bf16(const float* w, const float* rowscale, void* dst, 
 int erd_stem_conv7x7_bn_relu(const float* x_nchw, const float* w_ohwi, const float* scale,
                              const float* shift, float* out_nhwc, int N, int H, int W,
                              erd_stream_t stream);
-int erd_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, erd_stream_t stream);
+int erd_maxpool3x3s2(const float* in, void* out, int N, int H, int W, int C, int out_type /* ERD_F32 | ERD_BF16 */,
+                     erd_stream_t stream);
 
 /* ---- DetDataPreprocessor (data_preprocessor.py:110-183; mmengine ImgDataPreprocessor): one CHW image (uint8 or
  * fp32, device) -> out[3][H][W]: optional channel flip (bgr_to_rgb), (x - mean) / std, pad_value outside (h, w).
@@ -188,9 +203,9 @@ int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const 
                 float eps, float* scale, float* shift, int64_t n, erd_stream_t stream);
 /* use_relu: dz = dy * (y > 0) (dz may alias dy); else dz is not written (dz == dy semantically);
  * colsum[c] += sum_p dz[p,c].  Rows are [npix][C] with an image stride (level views). */
-int erd_relu_bwd_colsum(const float* y, const float* dy, float* dz, int64_t npix, int C,
+int erd_relu_bwd_colsum(const void* y, const void* dy, void* dz, int64_t npix, int C,
                         int64_t nstride_rows, int64_t rows_per_img, float* colsum, int use_relu,
-                        erd_stream_t stream);
+                        int map_type /* of y, dy, dz */, erd_stream_t stream);
 /* dbeta_sum = sum over the `copies` rows of dbeta[copies][C] (stored to dbeta_out when given);
  * dgamma = rsqrt(var+eps) * (rowdot - mean*dbeta_sum) */
 int erd_bn_dgamma(const float* rowdot, const float* dbeta, int copies, const float* mean, const float* var,
@@ -202,21 +217,22 @@ typedef struct {
     int64_t off[ERD_MAX_SEG]; /* first row of the level inside an image's A rows */
     int64_t cnt[ERD_MAX_SEG]; /* rows (pixels) of the level per image */
 } erd_levels;
-int erd_gn_relu_fwd(const float* c, float* y, const float* gamma, const float* beta, double* stats_ws,
+int erd_gn_relu_fwd(const void* c, void* y, const float* gamma, const float* beta, double* stats_ws,
                     float* mean_rstd, int N, int64_t A, int C, int G, const erd_levels* lv, float eps,
+                    int map_type /* of c, y */, erd_stream_t stream);
+int erd_gn_relu_bwd(const void* c, const void* dy, const float* gamma, const float* beta,
+                    const float* mean_rstd, double* stats_ws, void* dc, float* dgamma, float* dbeta,
+                    int N, int64_t A, int C, int G, const erd_levels* lv, int map_type /* of c, dy, dc */,
                     erd_stream_t stream);
-int erd_gn_relu_bwd(const float* c, const float* dy, const float* gamma, const float* beta,
-                    const float* mean_rstd, double* stats_ws, float* dc, float* dgamma, float* dbeta,
-                    int N, int64_t A, int C, int G, const erd_levels* lv, erd_stream_t stream);
 
 /* ---- FPN top-down (fpn.py:181-191): lat[l-1] += nearest2x(lat[l]) and its adjoint -------------- */
-int erd_upsample2x_add(float* fine, const float* coarse, int N, int H, int W, int C, int h, int w,
-                       int64_t fine_nstride, int64_t coarse_nstride, erd_stream_t stream);
-int erd_upsample2x_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int C, int h, int w,
-                           int64_t fine_nstride, int64_t coarse_nstride, erd_stream_t stream);
+int erd_upsample2x_add(void* fine, const void* coarse, int N, int H, int W, int C, int h, int w,
+                       int64_t fine_nstride, int64_t coarse_nstride, int map_type, erd_stream_t stream);
+int erd_upsample2x_add_bwd(const void* dfine, void* dcoarse, int N, int H, int W, int C, int h, int w,
+                           int64_t fine_nstride, int64_t coarse_nstride, int map_type, erd_stream_t stream);
 
 /* ---- small dense helpers -------------------------------------------------------------------- */
-int erd_colsum(const float* x, int64_t rows, int C, float* out, int accumulate, erd_stream_t stream);
+int erd_colsum(const void* x, int64_t rows, int C, float* out, int accumulate, int map_type /* of x */, erd_stream_t stream);
 /* y[n][a][:] = x[n][a][:] * alphas[level(a)] (gfl_head.py:229, one learnable Scale per level) and adjoint */
 int erd_level_scale(const float* x, const float* alphas, float* y, int N, int64_t A, int C,
                     const erd_levels* lv, erd_stream_t stream);
