@@ -233,8 +233,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             BF ? const_cast<void*>(p.w_bf16) : (void*)const_cast<float*>(w), 0,
             (int)((long long)p.Cout * p.wrow * (BF ? 2 : 4)), 0x00020000);
 
-        float4 ra[AJ], rb[BJ];
-        float4 ra1[(BF && !AB) ? AJ : 1];     // bf16 mode on fp32 maps: the second half (k+4..k+7) of each 8-value chunk
+        // bf16 matrix cores: a K-slice is ~250 ns of MFMA work, far less than the latency of the global loads that
+        // feed the next one -> TWO slices are kept in flight in registers (set = slice parity): slice kt+2 is requested
+        // while slice kt is multiplied and slice kt+1 waits in its registers for the LDS buffer that slice kt-1 has left.
+        constexpr bool PD2 = BF && MINW <= 2;      // (the four-per-CU tuning variant has no registers to spare)
+        constexpr int NSET = PD2 ? 2 : 1;
+        float4 ra[NSET][AJ], rb[NSET][BJ];
+        float4 ra1[NSET][(BF && !AB) ? AJ : 1];     // bf16 mode on fp32 maps: the second half (k+4..k+7) of each 8-value chunk
         int tap = ks / cpt, cc = ks - tap * cpt;
         // wave-uniform description of the K-slice being fetched
         int adelta = 0, bdelta = 0, ctap = 0;
@@ -248,30 +253,30 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             cok1 = BF && !AB && cb + chunk * KPC + 4 < Cin;
             if (++cc == cpt) { cc = 0; ++tap; }
         };
-        auto load_a = [&](int j) {
+        auto load_a = [&](int j, const int set) {
             const bool ok = cok && ((a_mask[j] >> ctap) & 1u);
-            ra[j] = buf_load16(rs_in, ok ? a_base[j] + (unsigned)adelta : OOB);
-            if (BF && !AB) ra1[j] = buf_load16(rs_in, (ok && cok1) ? a_base[j] + (unsigned)adelta + 16u : OOB);
+            ra[set][j] = buf_load16(rs_in, ok ? a_base[j] + (unsigned)adelta : OOB);
+            if (BF && !AB) ra1[set][j] = buf_load16(rs_in, (ok && cok1) ? a_base[j] + (unsigned)adelta + 16u : OOB);
         };
-        auto load_b = [&](int j) {
-            rb[j] = buf_load16(rs_w, cok ? b_base[j] + (unsigned)bdelta : OOB);
+        auto load_b = [&](int j, const int set) {
+            rb[set][j] = buf_load16(rs_w, cok ? b_base[j] + (unsigned)bdelta : OOB);
         };
-        auto store_lds = [&](int buf) {
+        auto store_lds = [&](int buf, const int set) {
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const int row = r0 + RPP * j;
                 if (BF && !AB)      // (weights past Cin inside the chunk meet zeros here, so partial chunks are exact)
                     As[buf * BM * CH + row * CH + swzc(row, chunk)] =
-                        make_float4(pack_bf16(ra[j].x, ra[j].y), pack_bf16(ra[j].z, ra[j].w),
-                                    pack_bf16(ra1[(BF && !AB) ? j : 0].x, ra1[(BF && !AB) ? j : 0].y),
-                                    pack_bf16(ra1[(BF && !AB) ? j : 0].z, ra1[(BF && !AB) ? j : 0].w));
+                        make_float4(pack_bf16(ra[set][j].x, ra[set][j].y), pack_bf16(ra[set][j].z, ra[set][j].w),
+                                    pack_bf16(ra1[set][(BF && !AB) ? j : 0].x, ra1[set][(BF && !AB) ? j : 0].y),
+                                    pack_bf16(ra1[set][(BF && !AB) ? j : 0].z, ra1[set][(BF && !AB) ? j : 0].w));
                 else
-                    As[buf * BM * CH + row * CH + swzc(row, chunk)] = ra[j];
+                    As[buf * BM * CH + row * CH + swzc(row, chunk)] = ra[set][j];
             }
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int row = r0 + RPP * j;
-                Bs[buf * BN * CH + row * CH + swzc(row, chunk)] = rb[j];
+                Bs[buf * BN * CH + row * CH + swzc(row, chunk)] = rb[set][j];
             }
         };
 
@@ -285,20 +290,30 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 
         slice_begin();
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) load_a(j);
+        for (int j = 0; j < AJ; ++j) load_a(j, 0);
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) load_b(j);
-        store_lds(0);
+        for (int j = 0; j < BJ; ++j) load_b(j, 0);
+        if (PD2 && ks + 1 < ke) {
+            slice_begin();
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) load_a(j, NSET - 1);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) load_b(j, NSET - 1);
+        }
+        store_lds(0, 0);
         __syncthreads();
 
         IG_ACC(2, t_pro);
         IG_T0(t_loop);
         constexpr int KSTEPS = CH / 2;      // one k-step = the two chunks (h = 0 / 1) a wave's lanes read
         constexpr int APS = (AJ + KSTEPS - 1) / KSTEPS, BPS = (BJ + KSTEPS - 1) / KSTEPS;   // loads per k-step
-        for (int kt = ks; kt < ke; ++kt) {
-            const int buf = (kt - ks) & 1;
+        // one K-slice; par = (kt - ks) & 1 selects the LDS buffer (and, with two slices in flight, the register set)
+        auto k_slice = [&](const int kt, const int par) {
+            const int buf = par;
             const bool more = kt + 1 < ke;
-            if (more) slice_begin();
+            const bool fetch = PD2 ? kt + 2 < ke : more;       // is there a slice left to request?
+            const int fset = PD2 ? par : 0;                    // its register set: the one slice kt came through
+            if (fetch) slice_begin();
             const float4* Ab = As + buf * BM * CH;
             const float4* Bb = Bs + buf * BN * CH;
             // fragment reads run one k-step ahead of the MFMAs that consume them (register double buffer)
@@ -322,13 +337,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 const int cur = kk & 1;
                 if (kk + 1 < KSTEPS) read_frags(kk + 1, cur ^ 1);
                 // next slice's global loads, a few per k-step, issued under this step's MFMAs
-                if (more) {
+                if (fetch) {
 #pragma unroll
                     for (int q = 0; q < APS; ++q)
-                        if (kk * APS + q < AJ) load_a(kk * APS + q);
+                        if (kk * APS + q < AJ) load_a(kk * APS + q, fset);
 #pragma unroll
                     for (int q = 0; q < BPS; ++q)
-                        if (kk * BPS + q < BJ) load_b(kk * BPS + q);
+                        if (kk * BPS + q < BJ) load_b(kk * BPS + q, fset);
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
@@ -351,8 +366,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                     __builtin_amdgcn_sched_group_barrier(0x8, FM * FN * 4, 0);    // then this step's MFMAs
                 }
             }
-            if (more) store_lds(buf ^ 1);
+            if (more) store_lds(buf ^ 1, PD2 ? (par ^ 1) : 0);
             __syncthreads();
+        };
+        if constexpr (PD2) {
+            for (int kt = ks; kt < ke; kt += 2) {       // unrolled by two: register sets are named at compile time
+                k_slice(kt, 0);
+                if (kt + 1 < ke) k_slice(kt + 1, 1);
+            }
+        } else {
+            for (int kt = ks; kt < ke; ++kt) k_slice(kt, (kt - ks) & 1);
         }
 
         IG_ACC(3, t_loop);
@@ -1238,6 +1261,7 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
 #define ERD_BF_LAUNCH(AB_, OB_)                                                                       \
         do {                                                                                          \
             if (seg_taps_any) return launch_igemm<128, 128, 2, 2, 32, 2, true, true, AB_, OB_>(d, st);  \
+            if (variant == 2) return launch_igemm<128, 128, 2, 2, 16, 4, true, false, AB_, OB_>(d, st); \
             if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2, true, false, AB_, OB_>(d, st); \
             return launch_igemm<128, 128, 2, 2, 32, 2, true, false, AB_, OB_>(d, st);                   \
         } while (0)

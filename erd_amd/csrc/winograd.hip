@@ -123,6 +123,8 @@ struct WinoSeg {
 struct WinoRegion {
     int seg, ty0, tx0, nby, nbx, lbw;
     int block0;              // first block (per cout block) of this region
+    int ty1, tx1;            // tiles at or beyond (ty1, tx1) belong to another region: computed (whole blocks) but not stored,
+                             // so every output pixel is written -- and column-summed, and read as a residual -- exactly once
 };
 struct WinoDesc {
     int nseg, nreg;
@@ -143,6 +145,7 @@ struct WinoDesc {
 // One (tile block, cout block) work item: where it lives.  All fields are wave-uniform (scalar registers).
 struct WinoItem {
     int s, n, y0, x0, cout0, lbw;       // y0, x0: first output pixel of the block; block = (32 >> lbw) x (1 << lbw) tiles
+    int yl, xl;                         // output pixels at or beyond (yl, xl) are not this item's to store
 };
 
 __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
@@ -178,6 +181,8 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         it.x0 = __builtin_amdgcn_readfirstlane(2 * (rg.tx0 + (bx << lbw)));
         it.cout0 = __builtin_amdgcn_readfirstlane(nb * BN);
         it.lbw = __builtin_amdgcn_readfirstlane(lbw);
+        it.yl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].H, 2 * rg.ty1));
+        it.xl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].W, 2 * rg.tx1));
         return it;
     };
     // item k + 1 of this workgroup's sequence: claimed from the launch's counter, or (no counter) a static stride
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
 #pragma unroll
                             for (int a = 0; a < 2; ++a) {
                                 const float4 yv = a == 0 ? f4add(f4add(z[0], z[1]), z[2]) : f4sub(f4sub(z[1], z[2]), z[3]);
-                                const bool ok = cok && oy0 + a < sg.H && ox0 + c < sg.W;
+                                const bool ok = cok && oy0 + a < cur.yl && ox0 + c < cur.xl;
                                 const unsigned off = ok ? off_t + (unsigned)a * row_b + (unsigned)c * px_b : OOBV;
                                 u32x4 v;
                                 v.x = __float_as_uint(fmaxf(yv.x * sc.x + sh.x, lo));
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
                         for (int a = 0; a < 2; ++a) {
                             const float4 yv = a == 0 ? f4add(f4add(z[0], z[1]), z[2]) : f4sub(f4sub(z[1], z[2]), z[3]);
                             const int oy = cur.y0 + 2 * ty + a, ox = cur.x0 + 2 * tx + c;
-                            if (oy < sg.H && ox < sg.W && co0 < p.Cout) {
+                            if (oy < cur.yl && ox < cur.xl && co0 < p.Cout) {
                                 const int64_t o = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout + co0;
                                 float4 v = make_float4(yv.x * sc.x + sh.x, yv.y * sc.y + sh.y, yv.z * sc.z + sh.z,
                                                        yv.w * sc.w + sh.w);
@@ -661,10 +666,10 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     ERD_REQUIRE(!colsum || Cout % 4 == 0, "wino: colsum needs Cout %% 4 == 0");
     static const int shapes = getenv("ERD_WINO_SHAPES") ? atoi(getenv("ERD_WINO_SHAPES")) : 1;   // 0: plain 4x8 cover (A/B aid)
     int blocks = 0, nreg = 0;
-    auto add_region = [&](int s, int N, int ty0, int tx0, int nby, int nbx, int lbw) {
+    auto add_region = [&](int s, int N, int ty0, int tx0, int nby, int nbx, int lbw, int ty1, int tx1) {
         if (nby <= 0 || nbx <= 0) return;
         WinoRegion& r = d.reg[nreg++];
-        r.seg = s; r.ty0 = ty0; r.tx0 = tx0; r.nby = nby; r.nbx = nbx; r.lbw = lbw;
+        r.seg = s; r.ty0 = ty0; r.tx0 = tx0; r.nby = nby; r.nbx = nbx; r.lbw = lbw; r.ty1 = ty1; r.tx1 = tx1;
         r.block0 = blocks;
         blocks += N * nby * nbx;
     };
@@ -686,22 +691,23 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
         w.out_nstride = g.out_nstride;
         const int TH = (g.IH + 1) / 2, TW = (g.IW + 1) / 2;          // 2x2-pixel tiles of the map
         if (!shapes) {
-            add_region(s, g.N, 0, 0, (TH + 3) / 4, (TW + 7) / 8, 3);
+            add_region(s, g.N, 0, 0, (TH + 3) / 4, (TW + 7) / 8, 3, TH, TW);
             continue;
         }
         // interior: 4x8 blocks; ragged bottom rows: the flattest block that still covers them (1x32 / 2x16 / 4x8);
         // ragged right columns: the narrowest (32x1 / 16x2 / 8x4 / 4x8)
         const int nby = TH / 4, nbx = TW / 8;
-        add_region(s, g.N, 0, 0, nby, nbx, 3);
+        add_region(s, g.N, 0, 0, nby, nbx, 3, 4 * nby, 8 * nbx);
         const int rb = TH - 4 * nby;
         if (rb > 0) {
             const int bh = rb <= 2 ? 2 : 4, bw = 32 / bh;        // (1x32 blocks would need a 4 x 66 patch: not staged)
-            add_region(s, g.N, 4 * nby, 0, 1, (TW + bw - 1) / bw, bw == 16 ? 4 : 3);
+            add_region(s, g.N, 4 * nby, 0, 1, (TW + bw - 1) / bw, bw == 16 ? 4 : 3, TH, TW);    // the bottom rows, full width
         }
         const int cbw = TW - 8 * nbx;
         if (cbw > 0 && nby > 0) {
             const int bw = cbw <= 2 ? 2 : cbw <= 4 ? 4 : 8, bh = 32 / bw;
-            add_region(s, g.N, 0, 8 * nbx, (4 * nby + bh - 1) / bh, 1, bw == 2 ? 1 : bw == 4 ? 2 : 3);
+            // the right columns of the interior rows only: a tall block may reach below them, into the bottom region
+            add_region(s, g.N, 0, 8 * nbx, (4 * nby + bh - 1) / bh, 1, bw == 2 ? 1 : bw == 4 ? 2 : 3, 4 * nby, TW);
         }
     }
     d.nreg = nreg;

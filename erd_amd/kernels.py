@@ -277,18 +277,45 @@ def _multi_rank() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+_SK_BYTES = None
+
+
 def _attach_sk_ws(d: ConvDesc, device) -> None:
     # (one zero-initialised ticket / slab workspace per stream; see STREAMK_MULTIRANK above for the multi-rank policy)
-    if not STREAMK or (_multi_rank() and not STREAMK_MULTIRANK):
+    global _SK_BYTES
+    if not STREAMK or (not STREAMK_MULTIRANK and _multi_rank()):
         d.sk_ws, d.sk_ws_bytes = 0, 0
         return
-    nbytes = int(_lib.load().erd_conv_igemm_ws_bytes(_SK_TILES))
-    key = ("streamk", str(device), torch.cuda.current_stream().cuda_stream)
+    if _SK_BYTES is None:
+        _SK_BYTES = int(_lib.load().erd_conv_igemm_ws_bytes(_SK_TILES))
+    nbytes = _SK_BYTES
+    key = ("streamk", device, torch.cuda.current_stream().cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)    # tickets must start at zero
         _WS[key] = ws
     d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), nbytes
+
+
+# Launch descriptors are cached per call-site geometry: the host side of a step is ~250 convolution launches, and
+# filling a ctypes erd_conv_desc field by field (taps, extents, strides, checks) cost ~25 us each -- more than the
+# launch itself (measured: 6 of the 20 ms of host time per bf16 step, tools/host_breakdown.py).  A cached descriptor
+# keeps everything that depends only on shapes / strides / storage types; a call rewrites the pointers and launches
+# (the C side copies the struct into the kernel arguments before it returns).  One cache per host thread: the backward
+# pass runs on autograd's thread.
+import threading as _threading
+_DESC = _threading.local()
+
+
+def _desc_cache() -> dict:
+    c = getattr(_DESC, "cache", None)
+    if c is None:
+        c = _DESC.cache = {}
+    return c
+
+
+def _geom(ts) -> tuple:
+    return tuple(None if t is None else (t.shape, t.stride(0), t.dtype) for t in ts)
 
 
 def conv_out_size(h: int, k: int, s: int, p: int) -> int:
@@ -305,35 +332,49 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     if alphas is None and wino_ok(Cin, k, stride, pad) and w.shape[1] == 3 and (WINO_TRAIN_FWD if RECORDED else WINO_NOGRAD_FWD):
         wino_conv3x3(xs, _wino_weights_cached(w), outs, Cout, scale=scale, shift=shift, relu=relu, res=res)
         return
-    assert w.is_contiguous() and w.shape[1] == k and w.shape[2] == k
-    d = ConvDesc()
-    d.nseg = len(xs)
-    for i, (x, o) in enumerate(zip(xs, outs)):
-        assert x.shape[3] == Cin and o.shape[3] == Cout
-        assert o.shape[1] == conv_out_size(x.shape[1], k, stride, pad) and o.shape[2] == conv_out_size(x.shape[2], k, stride, pad)
-        _fill_seg(d.seg[i], x, o, o.shape[1], o.shape[2], None if res is None else res[i],
-                  None if alphas is None else alphas[i])
+    cache = _desc_cache()
+    key = ("fwd", k, stride, pad, relu, w.shape, _geom(xs), _geom(outs), None if res is None else _geom(res), alphas is not None,
+           scale is not None, shift is not None, COMPUTE)
+    ent = cache.get(key)
+    if ent is None:
+        assert w.is_contiguous() and w.shape[1] == k and w.shape[2] == k
+        d = ConvDesc()
+        d.nseg = len(xs)
+        for i, (x, o) in enumerate(zip(xs, outs)):
+            assert x.shape[3] == Cin and o.shape[3] == Cout
+            assert o.shape[1] == conv_out_size(x.shape[1], k, stride, pad) and o.shape[2] == conv_out_size(x.shape[2], k, stride, pad)
+            _fill_seg(d.seg[i], x, o, o.shape[1], o.shape[2], None if res is None else res[i],
+                      None if alphas is None else alphas[i])
+        d.Cin, d.Cout, d.wrow = Cin, Cout, k * k * Cin
+        d.ntaps = k * k
+        for kh in range(k):
+            for kw in range(k):
+                t = kh * k + kw
+                d.dy[t], d.dx[t], d.wk[t] = kh - pad, kw - pad, t * Cin
+        d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
+        d.relu = 1 if relu else 0
+        d.colsum = 0
+        d.in_bf16, d.out_bf16 = _stored_bf16(xs), _stored_bf16(outs, res)
+        flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
+        nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel())
+        ent = cache[key] = (d, flop, nbytes, _shape_tag(d, k, stride))
+    d, flop, nbytes, tag = ent
+    for i in range(len(xs)):
+        sg = d.seg[i]
+        sg.inp, sg.out = xs[i].data_ptr(), outs[i].data_ptr()
+        if res is not None:
+            sg.res = 0 if res[i] is None else res[i].data_ptr()
+        if alphas is not None:
+            sg.alpha = alphas[i].data_ptr()
     d.w = w.data_ptr()
-    d.Cin, d.Cout, d.wrow = Cin, Cout, k * k * Cin
-    d.ntaps = k * k
-    for kh in range(k):
-        for kw in range(k):
-            t = kh * k + kw
-            d.dy[t], d.dx[t], d.wk[t] = kh - pad, kw - pad, t * Cin
-    d.in_stride, d.out_stride, d.oy, d.ox = stride, 1, 0, 0
     d.scale = 0 if scale is None else scale.data_ptr()
     d.shift = 0 if shift is None else shift.data_ptr()
-    d.relu = 1 if relu else 0
-    d.colsum = 0
     if COMPUTE == "bf16":
         wb = _weights_bf16(w)          # (kept alive by this frame until the launch is queued; stream-ordered free)
         d.w_bf16 = wb.data_ptr()
-    d.in_bf16, d.out_bf16 = _stored_bf16(xs), _stored_bf16(outs, res)
     _attach_sk_ws(d, w.device)
-    flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * k * k * Cin
-    nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel()) if _TIMING is not None else 0.0
-    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes,
-                tag=_shape_tag(d, k, stride) if TIMING_DETAIL else "")
+    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
+                tag=tag if TIMING_DETAIL else "")
 
 
 WINOGRAD = _os.environ.get("ERD_WINO", "1") != "0"     # F(2x2,3x3) for the fp32 3x3 stride-1 convolutions (winograd.hip)
@@ -425,6 +466,7 @@ def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: 
     Cin = xs[0].shape[3]
     for i, (x, o) in enumerate(zip(xs, outs)):
         assert x.shape[:3] == o.shape[:3] and o.shape[3] == Cout and x.shape[3] == Cin
+        assert x.dtype == torch.float32 and o.dtype == torch.float32, "the Winograd kernel is fp32 (maps and arithmetic)"
         _fill_seg(segs[i], x, o, x.shape[1], x.shape[2], None if res is None else res[i], None,
                   None if mask is None else mask[i])
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * 9 * Cin
@@ -470,6 +512,34 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
     if stride == 2 and k == 3 and len(dzs) == 1 and MERGE_PARITY:
         _dgrad_s2_merged(dzs[0], wt, wtb, dxs[0], pad, Cin, Cout, accumulate, res, relu_mask, colsum)
         return
+    cache = _desc_cache()
+    key = ("dgrad", k, stride, pad, accumulate, wt.shape, _geom(dzs), _geom(dxs), None if res is None else _geom(res),
+           None if relu_mask is None else _geom(relu_mask), None if colsum is None else colsum.numel(), COMPUTE)
+    ent = cache.get(key)
+    if ent is None:
+        ent = cache[key] = _dgrad_descs(dzs, wt, dxs, k, stride, pad, accumulate, res, relu_mask, colsum, Cin, Cout)
+    for d, flop, nbytes, tag in ent:
+        for i in range(len(dzs)):
+            sg = d.seg[i]
+            sg.inp, sg.out = dzs[i].data_ptr(), dxs[i].data_ptr()
+            if accumulate:
+                sg.res = dxs[i].data_ptr()
+            elif res is not None:
+                sg.res = res[i].data_ptr()
+            if relu_mask is not None:
+                sg.mask = relu_mask[i].data_ptr()
+        d.w = wt.data_ptr() if wtb is None else 0
+        d.colsum = 0 if colsum is None else colsum.data_ptr()
+        if wtb is not None:
+            d.w_bf16 = wtb.data_ptr()
+        _attach_sk_ws(d, wt.device)
+        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
+                    tag=tag if TIMING_DETAIL else "")
+
+
+def _dgrad_descs(dzs, wt, dxs, k, stride, pad, accumulate, res, relu_mask, colsum, Cin, Cout):
+    """the launch descriptors (one per output-parity class) of an input gradient, pointers left to the caller"""
+    out = []
     classes = [(0, 0)] if stride == 1 else [(py, px) for py in range(stride) for px in range(stride)]
     for (py, px) in classes:
         taps = []
@@ -495,7 +565,6 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
             _fill_seg(d.seg[i], dz, dx, max(GH, 0), max(GW, 0), r, None, None if relu_mask is None else relu_mask[i])
         if skip and len(dzs) == 1:
             continue
-        d.w = wt.data_ptr() if wtb is None else 0
         d.Cin, d.Cout, d.wrow = Cout, Cin, k * k * Cout     # roles swap: contraction over Cout
         d.ntaps = len(taps)
         for t, (dy, dx_, wk) in enumerate(taps):
@@ -504,18 +573,14 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.scale = 0
         d.shift = 0
         d.relu = 0
-        d.colsum = 0 if colsum is None else colsum.data_ptr()
         d.colsum_copies = 0 if colsum is None else colsum.numel() // Cin        # [copies, Cin of the forward conv]
-        if wtb is not None:
-            d.w_bf16 = wtb.data_ptr()
         d.in_bf16, d.out_bf16 = _stored_bf16(dzs), _stored_bf16(dxs, res, relu_mask)
-        _attach_sk_ws(d, wt.device)
         flop = 2.0 * sum(d.seg[i].N * d.seg[i].GH * d.seg[i].GW for i in range(d.nseg)) * Cin * len(taps) * Cout
         # (stride 2: each parity class reads dz once and writes a quarter of dx)
         nbytes = 4.0 * (sum(t.numel() for t in dzs) + sum(t.numel() for t in dxs) / (stride * stride) + wt.numel() /
-                        (stride * stride)) if _TIMING is not None else 0.0
-        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes,
-                    tag=(_shape_tag(d, k, stride) + f" class{py}{px}") if TIMING_DETAIL else "")
+                        (stride * stride))
+        out.append((d, flop, nbytes, _shape_tag(d, k, stride) + f" class{py}{px}"))
+    return out
 
 
 MERGE_PARITY = _os.environ.get("ERD_MERGE_PARITY", "1") != "0"
@@ -588,21 +653,38 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     """returns (part [S, Cout, k*k, Cin], S): split-K partial slabs.  All segments (maps sharing the weights, e.g.
     the head's five levels) are summed in ONE launch: their pixels are concatenated along the GEMM K axis."""
     _require_gpu(*xs, *dzs)
-    Cin, Cout = xs[0].shape[3], dzs[0].shape[3]
-    npix = sum(dz.shape[0] * dz.shape[1] * dz.shape[2] for dz in dzs)
     xb = min(x.data_ptr() for x in xs)
     zb = min(z.data_ptr() for z in dzs)
-    d = WgradDesc()
+    xoff = tuple((x.data_ptr() - xb) // x.element_size() for x in xs)
+    zoff = tuple((z.data_ptr() - zb) // z.element_size() for z in dzs)
+    cache = _desc_cache()
+    key = ("wgrad", k, stride, pad, _geom(xs), _geom(dzs), xoff, zoff, COMPUTE, _os.environ.get("ERD_WGRAD_ROW3", "1"))
+    ent = cache.get(key)
+    if ent is None:
+        ent = cache[key] = _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff)
+    d, S, flop, nbytes, tag, Cout, Cin = ent
     d.x, d.dz = xb, zb
+    part = ws_float("wgrad_part", S * Cout * k * k * Cin, xs[0].device)
+    d.part = part.data_ptr()
+    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
+                tag=tag if TIMING_DETAIL else "")
+    return part, S
+
+
+def _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff):
+    """the launch descriptor of a weight gradient (base pointers and the partial-slab pointer left to the caller)"""
+    Cin, Cout = xs[0].shape[3], dzs[0].shape[3]
+    npix = sum(dz.shape[0] * dz.shape[1] * dz.shape[2] for dz in dzs)
+    d = WgradDesc()
     xe = ze = 0
     d.nseg = len(xs)
     for i, (x, dz) in enumerate(zip(xs, dzs)):
         _check_map(x)
         _check_map(dz)
         sg = d.seg[i]
-        px, nx = _extent(x)
-        pz, nz = _extent(dz)
-        sg.x_off, sg.dz_off = (px - xb) // x.element_size(), (pz - zb) // dz.element_size()
+        _, nx = _extent(x)
+        _, nz = _extent(dz)
+        sg.x_off, sg.dz_off = xoff[i], zoff[i]
         xe, ze = max(xe, sg.x_off + nx), max(ze, sg.dz_off + nz)
         sg.N, sg.IH, sg.IW = x.shape[0], x.shape[1], x.shape[2]
         sg.GH, sg.GW, sg.OH, sg.OW = dz.shape[1], dz.shape[2], dz.shape[1], dz.shape[2]
@@ -624,14 +706,10 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
         S = int(max(1, min(target // groups, row3 // 16 if row3 >= 16 else 1, 512)))     # floor: whole dispatch rounds
     else:
         S = _pick_nsplit(npix, Cout, Cin, k * k)
-    part = ws_float("wgrad_part", S * Cout * k * k * Cin, xs[0].device)
-    d.part = part.data_ptr()
     d.nsplit = S
     flop = 2.0 * npix * Cout * Cin * k * k
-    nbytes = 4.0 * (sum(t.numel() for t in xs) + sum(t.numel() for t in dzs) + part.numel()) if _TIMING is not None else 0.0
-    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes,
-                tag=f"px{npix} {Cin}->{Cout} k{k}s{stride} S{S}" if TIMING_DETAIL else "")
-    return part, S
+    nbytes = 4.0 * (sum(t.numel() for t in xs) + sum(t.numel() for t in dzs) + S * Cout * k * k * Cin)
+    return d, S, flop, nbytes, f"px{npix} {Cin}->{Cout} k{k}s{stride} S{S}", Cout, Cin
 
 
 def wgrad_reduce(part: Tensor, S: int, w: Tensor, rowscale: Optional[Tensor], dW: Tensor, accumulate: bool,

@@ -372,7 +372,10 @@ def test_whole_step_hipgraph_replay_follows_the_eager_trainer():
     for a, b in zip(eager_logs, graph_logs):
         assert a.keys() == b.keys()
         for k in a:
-            assert b[k] == pytest.approx(a[k], rel=1e-5, abs=1e-7), (k, a[k], b[k])
+            # not bit-equal: the column sums and GroupNorm statistics are float atomics, whose order differs from run to
+            # run (and between the forked and the in-line tower schedule); two EAGER runs differ by the same amount
+            # (observed up to 2e-5 relative in a loss after four steps)
+            assert b[k] == pytest.approx(a[k], rel=2e-4, abs=1e-6), (k, a[k], b[k])
     num = sum(float((graph_w[k] - eager_w[k]).double().pow(2).sum()) for k in eager_w)
     den = sum(float(eager_w[k].double().pow(2).sum()) for k in eager_w)
-    assert (num / den) ** 0.5 < 1e-6, (num / den) ** 0.5
+    assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5

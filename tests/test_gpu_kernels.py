@@ -424,3 +424,24 @@ def test_winograd_conv3x3_multilevel_and_input_gradient(K):
     dx = torch.empty((1, 13, 21, Cc), device="cuda")
     K.wino_conv3x3([nhwc(dy)], K.wino_weights(wt), [dx], Cc)
     assert relerr(to_nchw(dx), gx) < 5e-5
+
+
+@pytest.mark.parametrize("H,W", [(13, 21), (50, 84), (25, 42), (7, 11), (100, 168), (27, 33)])
+def test_winograd_cover_stores_every_pixel_exactly_once(K, H, W):
+    """The block-shape regions of the Winograd cover (interior 4x8 blocks, flat bottom strips, narrow right strips) must
+    PARTITION the map: a tall right-strip block reaches below the interior rows, and before the regions carried their own
+    limits those tiles were stored twice -- invisible for a plain store, but a residual that aliases the output
+    (accumulate form) was added twice and the fused column sums counted the pixels twice (13x21, 50x84 and 27x33 overlap;
+    25x42, 7x11, 100x168 do not)."""
+    N, Cin, Cout = 1, 64, 64
+    x = G.randn(81, N, Cin, H, W)
+    w = G.randn(82, Cout, Cin, 3, 3, scale=(2.0 / (Cin * 9)) ** 0.5)
+    ref = F.conv2d(x, w, None, 1, 1)
+    U = K.wino_weights(w.permute(0, 2, 3, 1).contiguous().cuda())
+    base = G.randn(83, N, Cout, H, W)
+    for _ in range(3):          # (the double store was a race: repeat)
+        out = nhwc(base)
+        cs = torch.zeros(Cout, device="cuda")
+        K.wino_conv3x3([nhwc(x)], U, [out], Cout, res=[out], colsum=cs)
+        assert relerr(to_nchw(out), ref + base) < 2e-5
+        assert relerr(cs.cpu(), (ref + base).sum((0, 2, 3))) < 1e-4

@@ -19,6 +19,7 @@ tr = ERDTrainer(model, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight
 batches = [bench.synthetic_gpu_batch(4, seed=i, device=dev, cfg=cfg) for i in range(2)]
 tr.overlap_teacher = False
 Fn.TOWERS_ON_TWO_STREAMS = False
+Fn.WGRAD_TRAIL = False          # (trailing weight gradients would overlap the input-gradient launches being timed)
 for i in range(2):
     tr.train_step(*batches[i % 2])
 tr.flush(); torch.cuda.synchronize()
