@@ -367,15 +367,19 @@ def test_whole_step_hipgraph_replay_follows_the_eager_trainer():
         return logs, {k: v.detach().clone() for k, v in model.state_dict().items() if v.dtype == torch.float32}, tr
 
     eager_logs, eager_w, _ = run(False)
+    eager2_logs, _, _ = run(False)
+    noise = max(abs(a[k] - b[k]) / max(abs(a[k]), 1e-6) for a, b in zip(eager_logs, eager2_logs) for k in a)
+    print("eager vs eager (float-atomic order only): max relative loss difference %.2e" % noise)
     graph_logs, graph_w, tr = run(True)
     assert tr.step_graph and len(tr._step_graphs) == 1
-    for a, b in zip(eager_logs, graph_logs):
+    for i, (a, b) in enumerate(zip(eager_logs, graph_logs)):
         assert a.keys() == b.keys()
         for k in a:
-            # not bit-equal: the column sums and GroupNorm statistics are float atomics, whose order differs from run to
-            # run (and between the forked and the in-line tower schedule); two EAGER runs differ by the same amount
-            # (observed up to 2e-5 relative in a loss after four steps)
-            assert b[k] == pytest.approx(a[k], rel=2e-4, abs=1e-6), (k, a[k], b[k])
+            # Step 0 runs on identical weights: the captured kernels are the eager ones, only the order of the float atomics
+            # (column sums, GroupNorm statistics) differs -- the same noise two eager runs show (measured 1.3e-6 relative).
+            # From step 1 on the weights carry that noise through ReLU / top-k decisions: observed up to 2e-5 after four steps.
+            tol = 5e-6 if i == 0 else 2e-4
+            assert b[k] == pytest.approx(a[k], rel=tol, abs=1e-6), (i, k, a[k], b[k])
     num = sum(float((graph_w[k] - eager_w[k]).double().pow(2).sum()) for k in eager_w)
     den = sum(float(eager_w[k].double().pow(2).sum()) for k in eager_w)
     assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5

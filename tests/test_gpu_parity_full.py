@@ -94,10 +94,14 @@ def test_full_size_gradients_anchored_to_fp64(nets):
     reference's own arithmetic) and the HIP path.  Measured (profiles/r02 notes), relative L2 distance to fp64 as
     median over the 175 gradient tensors / all elements / worst tensor:
         seed   cpu fp32                      hip
-          7    4.7e-4  4.1e-4  2.5e-3        6.9e-4  4.2e-4  2.3e-3
-          8    3.4e-3  1.8e-3  4.8e-3        5.7e-4  5.9e-4  3.5e-3
-          9    4.9e-4  5.1e-4  3.1e-3        1.1e-3  7.8e-4  6.3e-3
-         10    8.7e-4  5.4e-4  1.7e-3        9.6e-4  5.9e-4  1.1e-2
+          7    4.7e-4  4.1e-4  2.5e-3        6.8e-4  4.2e-4  2.3e-3
+          8    3.4e-3  1.8e-3  4.8e-3        5.7e-4  5.9e-4  2.3e-3
+          9    4.9e-4  5.1e-4  3.1e-3        1.1e-3  7.8e-4  3.2e-3
+         10    8.7e-4  5.4e-4  1.7e-3        9.0e-4  5.9e-4  1.8e-3
+    (The worst-tensor column read 3.5e-3 / 6.3e-3 / 1.1e-2 on seeds 8-10 until the Winograd cover stopped storing some
+    tiles twice: the fused column sums of an input-gradient launch -- a BN bias gradient -- counted those pixels double.
+    This test's bound D was loose enough to pass with the bug; test_winograd_cover_stores_every_pixel_exactly_once is the
+    direct check, and D is now the measured 1.25x.)
     A ReLU whose pre-activation is ~1e-7 takes one side in one fp32 summation order and the other side in another; ONE such
     flip moves every gradient tensor upstream by ~1e-3 and a small-norm one (a BN bias gradient: a sum over a map with heavy
     cancellation) by up to 1e-2.  Which implementation owns the flip changes with the seed: the fp32 CPU reference on seed 8,
@@ -106,7 +110,7 @@ def test_full_size_gradients_anchored_to_fp64(nets):
       A. every seed: losses within 1e-3 of the fp32 reference and of fp64; the WHOLE gradient within 1e-3 of fp64;
       B. every seed: median per-tensor distance <= 1.5e-3, and <= max(1e-3, 1.25 x the reference's) on at least 3 of 4 seeds;
       C. over the seeds: this implementation's worst median / worst whole-gradient distance is not above the reference's worst;
-      D. worst single tensor: <= 2e-2 on every seed, and on average over the seeds within 3x of the reference's worst tensor."""
+      D. worst single tensor: <= 5e-3 on every seed and within 1.25x of the reference's worst tensor of the same seed."""
     from erd_amd import parse_losses
     tsd, ssd, _ = nets
     names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
@@ -152,4 +156,4 @@ def test_full_size_gradients_anchored_to_fp64(nets):
     assert (hip[:, 1] <= 1e-3).all(), hip[:, 1]                                                     # A
     assert (hip[:, 0] <= 1.5e-3).all() and int((hip[:, 0] <= np.maximum(1e-3, 1.25 * cpu[:, 0])).sum()) >= 3, (hip[:, 0], cpu[:, 0])   # B
     assert hip[:, 0].max() <= cpu[:, 0].max() and hip[:, 1].max() <= cpu[:, 1].max(), (hip, cpu)   # C
-    assert (hip[:, 2] <= 2e-2).all() and hip[:, 2].mean() <= 3.0 * cpu[:, 2].mean(), (hip[:, 2], cpu[:, 2])   # D
+    assert (hip[:, 2] <= 5e-3).all() and (hip[:, 2] <= 1.25 * cpu[:, 2]).all(), (hip[:, 2], cpu[:, 2])   # D
