@@ -1282,6 +1282,12 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     const int64_t tiles = mtiles * ((d->Cout + 127) / 128);
     // short K loops, or so many tiles that tile-granular dispatch is already balanced: four small workgroups per
     // CU hide each other's staging/barrier phases best (measured 136 vs 131 TF on 8192 tiles x K=2048)
+    // K = 256 onto >= 512 output channels (layer3's expanding 1x1 convolutions and the input gradients of its reducing ones):
+    // 1056 tiles of 128x128 run as one full dispatch round plus a 37 % full one whose workgroups do not run faster for
+    // being alone; 128x64 tiles halve that tail (121.7 -> 107.4 us per launch, +0.9 % on the step; K = 64 / 128 measured
+    // equal or worse).  ERD_IGEMM_SHORTK=0: off (A/B aid).
+    static const int shortk = getenv("ERD_IGEMM_SHORTK") ? atoi(getenv("ERD_IGEMM_SHORTK")) : 1;
+    if (shortk && d->ntaps * d->Cin == 256 && d->Cout >= 512) return launch_igemm<128, 64, 2, 2, 32, 2>(d, st);
     if (d->ntaps * d->Cin <= 256) {
         // Tile-parallel launches finish in whole dispatch rounds: pick the co-residency whose LAST round is fullest.
         // cost = rounds x (workgroups per CU / steady-state efficiency at that co-residency: 0.83 / 0.85 / 0.87 measured)

@@ -311,6 +311,8 @@ def _desc_cache() -> dict:
     c = getattr(_DESC, "cache", None)
     if c is None:
         c = _DESC.cache = {}
+    elif len(c) > 16384:      # (~60 input shapes of a mixed-resolution run; rebuilt on demand)
+        c.clear()
     return c
 
 

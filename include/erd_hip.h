@@ -111,9 +111,10 @@ int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
 
 /* ---- Winograd F(2x2,3x3) for the stride-1 3x3 convolutions (fp32 matrix cores, 2.25x fewer multiplications) ----
  * erd_wino_weights: U = G g G^T of w [Cout][3][3][Cin] in the tiled layout the kernel streams
- * ([16][ceil(Cout/32)][Cin/4][32][4], erd_wino_weights_elems floats).  erd_wino_conv3x3: out = epi(conv3x3(in)),
+ * ([16 positions][ceil(Cout/16)][Cin/16][4 k-quads][16 couts][4 k]: one MFMA B-fragment of a wave is 1 KB contiguous;
+ * erd_wino_weights_elems = 16 * ceil16(Cout) * Cin floats, rows past Cout are zero).  erd_wino_conv3x3: out = epi(conv3x3(in)),
  * stride 1, padding 1, over up to ERD_MAX_SEG maps sharing U (segments as in erd_conv_desc: in/out/N/IH/IW/
- * in_nstride/out_nstride; OH == IH, OW == IW).  Cin % 16 == 0.  The input gradient of such a layer is the same
+ * in_nstride/out_nstride; OH == IH, OW == IW).  Cin % 16 == 0, Cin >= 64, fp32 maps only.  The input gradient of such a layer is the same
  * call on dz with U built from the transposed weights ([Cin][3][3][Cout]) with flip = 1.
  * replaces: the F.conv2d dispatches of gfl_head.py:219-229 (towers), fpn.py:215 (outputs), resnet.py:270-274 (conv2). */
 size_t erd_wino_weights_elems(int Cout, int Cin);

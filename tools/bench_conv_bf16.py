@@ -24,7 +24,7 @@ def timeit(fn, iters=10):
     return s.elapsed_time(e) / iters * 1e3
 
 
-print(f"{'layer':12s} {'GFLOP':>6s} | fwd us: f32-stored  bf16-stored | dgrad us: f32-stored  bf16-stored | max err fwd (bf16 ulp) dgrad")
+print(f"{'layer':12s} {'GFLOP':>6s} | fwd us: f32-stored  bf16-stored | dgrad us: f32-stored  bf16-stored | wgrad us: f32-stored bf16-stored | max err fwd (bf16 ulp) dgrad")
 for name, Cin, Cout, H, W, k, s in SHAPES:
     p = k // 2
     OH, OW = K.conv_out_size(H, k, s, p), K.conv_out_size(W, k, s, p)
@@ -38,6 +38,8 @@ for name, Cin, Cout, H, W, k, s in SHAPES:
     t1 = timeit(lambda: K.conv_forward([xb], w, [yb], k, s, p, scale=sc, shift=sh, relu=True))
     t2 = timeit(lambda: K.conv_dgrad([dy], wt, [dx], k, s, p))
     t3 = timeit(lambda: K.conv_dgrad([dyb], wt, [dxb], k, s, p))
+    t4 = timeit(lambda: K.conv_wgrad_partials([x], [dy], k, s, p))
+    t5 = timeit(lambda: K.conv_wgrad_partials([xb], [dyb], k, s, p))
     # reference: products of bf16-rounded operands, fp32 accumulation, epilogue in fp32, one rounding on store
     ref = F.conv2d(xb.float().permute(0, 3, 1, 2), w.bfloat16().float().permute(0, 3, 1, 2), stride=s, padding=p)
     ref = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
@@ -48,4 +50,4 @@ for name, Cin, Cout, H, W, k, s in SHAPES:
         refd = F.pad(refd, (0, W - refd.shape[3], 0, H - refd.shape[2]))
     refd = refd.permute(0, 2, 3, 1)
     err_d = ((dxb.float() - refd).abs() / refd.abs().clamp_min(1.0)).max().item() * 256
-    print(f"{name:12s} {fl/1e9:6.1f} | {t0:10.1f} {t1:12.1f} ({fl/t1/1e6:5.0f} TF) | {t2:10.1f} {t3:12.1f} ({fl/t3/1e6:5.0f} TF) | {err_f:8.2f} {err_d:8.2f}")
+    print(f"{name:12s} {fl/1e9:6.1f} | {t0:10.1f} {t1:12.1f} ({fl/t1/1e6:5.0f} TF) | {t2:10.1f} {t3:12.1f} ({fl/t3/1e6:5.0f} TF) | {t4:8.1f} {t5:8.1f} ({fl/t5/1e6:5.0f} TF) | {err_f:8.2f} {err_d:8.2f}")
