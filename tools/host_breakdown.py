@@ -39,6 +39,27 @@ for name in ["conv_forward", "conv_dgrad", "conv_wgrad_partials", "wgrad_reduce"
              "relu_bwd_colsum", "gn_relu_forward", "gn_relu_backward", "wino_conv3x3", "wino_weights", "zeros_f32", "to_bf16",
              "_weights_bf16"]:
     wrap(name)
+# coarse sections of the step (host time spent inside each call)
+def wrap_method(obj, name, tag):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t = time.perf_counter()
+        r = f(*a, **k)
+        q = acc["S:" + tag]; q[0] += 1; q[1] += time.perf_counter() - t
+        return r
+    setattr(obj, name, g)
+wrap_method(model, "teacher_pass", "teacher_pass (forward + ERS + NMS + targets)")
+wrap_method(model, "_forward_cat", "student forward")
+wrap_method(model.bbox_head, "loss_cat", "loss_cat")
+wrap_method(tr, "_apply_pending", "sgd + shadow refresh")
+wrap_method(tr.flat, "zero_grad", "zero_grad")
+_bw = torch.Tensor.backward
+def timed_backward(self, *a, **k):
+    t = time.perf_counter()
+    r = _bw(self, *a, **k)
+    q = acc["S:backward (autograd thread, all Function.backward bodies)"]; q[0] += 1; q[1] += time.perf_counter() - t
+    return r
+torch.Tensor.backward = timed_backward
 n = 8
 t0 = time.perf_counter()
 for i in range(n):
@@ -51,5 +72,5 @@ c_calls = sum(v[0] for k, v in acc.items() if k.startswith("C:"))
 k_time = sum(v[1] for k, v in acc.items() if k.startswith("K:") and k not in ("K:zeros_f32", "K:_weights_bf16", "K:to_bf16", "K:wino_weights"))
 print(f"per step: host {1e3*host/n:.2f} ms; inside C-ABI calls {1e3*c_time/n:.2f} ms ({c_calls/n:.0f} calls, {1e6*c_time/c_calls:.1f} us each); "
       f"inside the listed kernels.py wrappers (incl. their C calls) {1e3*k_time/n:.2f} ms")
-for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:24]:
-    print(f"  {k:34s} {v[0]/n:7.1f} calls/step {1e3*v[1]/n:7.3f} ms/step {1e6*v[1]/v[0]:7.1f} us/call")
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:32]:
+    print(f"  {k:66s} {v[0]/n:7.1f} calls/step {1e3*v[1]/n:7.3f} ms/step {1e6*v[1]/v[0]:7.1f} us/call")
