@@ -328,7 +328,9 @@ def _desc_cache() -> dict:
 
 
 def _geom(ts) -> tuple:
-    return tuple(None if t is None else (t.shape, t.stride(0), t.dtype) for t in ts)
+    # (all strides: the NHWC-density check of _check_map runs when the descriptor is built, so a differently laid out
+    # tensor of the same shape must not hit an entry that was checked for another layout)
+    return tuple(None if t is None else (t.shape, t.stride(), t.dtype) for t in ts)
 
 
 def conv_out_size(h: int, k: int, s: int, p: int) -> int:
