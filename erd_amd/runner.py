@@ -10,6 +10,7 @@ from __future__ import annotations
 import bisect
 import json
 import os
+import math
 import time
 from collections import OrderedDict, deque
 from typing import Callable, Dict, Iterable, List, Optional
@@ -257,6 +258,12 @@ class Runner:
                     torch.cuda.synchronize()
                     keys = [k for k in window[0] if "loss" in k]
                     avg = {k: float(sum(float(w[k].detach()) for w in window) / len(window)) for k in keys}
+                    # the reference's CheckInvalidLossHook (mmdet/engine/hooks/checkloss_hook.py:11-42: `isfinite(loss)`
+                    # every `interval` iterations) rides on the logging read-back -- the values are on the host already
+                    bad = [k for k, v in avg.items() if not math.isfinite(v)]
+                    if bad:
+                        raise FloatingPointError(f"loss became infinite or NaN! ({', '.join(bad)} at epoch {self.epoch + 1}, "
+                                                 f"iteration {i + 1})")
                     dt = (time.perf_counter() - t0) / (i + 1)
                     rec = dict(epoch=self.epoch + 1, iter=i + 1, lr=self.trainer.last_lr, time=dt, **avg)
                     self.history.append(rec)
