@@ -286,7 +286,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
             "config": {"workload": "gfl_r50_fpn first_40_incre_last_40 ERD (BASELINE configs[1]), 1333x800 padded to "
-                                   "800x1344, " + ("fp32" if args.compute == "f32" else "bf16 multiplicands / fp32 accumulate+storage") +
+                                   "800x1344, " + ("fp32" if args.compute == "f32" else ("bf16 matrix cores, bf16-stored maps, fp32 accumulate / statistics / losses"
+                                                                                 if K.BF16_STORAGE else "bf16 multiplicands / fp32 accumulate+storage")) +
                                    ", procedural weights", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
