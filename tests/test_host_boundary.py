@@ -122,6 +122,29 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert lib.erd_conv_igemm(None, None) == -1 and b"null" in lib.erd_last_error()
 
 
+def test_ctypes_signatures_match_the_header_argument_for_argument():
+    """Every prototype of include/erd_hip.h against the ctypes binding the product uses (erd_amd/_lib.py): same number of
+    parameters, pointers bound as pointers, 64-bit integers as 64-bit, floats as floats.  An argument added on one side only
+    (the map_type parameters of ABI version 2 were such a change) would otherwise shift every later argument silently."""
+    import ctypes as C
+    from erd_amd import _lib
+    header = open(os.path.join(ROOT, "include", "erd_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)                 # comments carry commas and parentheses
+    protos = dict(re.findall(r"^(?:int|size_t)\s+(erd_\w+)\s*\(([^;]*?)\)\s*;", header, re.M | re.S))
+    assert set(protos) >= set(_lib._SIGNATURES), sorted(set(_lib._SIGNATURES) - set(protos))
+    for name, argtypes in _lib._SIGNATURES.items():
+        params = [p.strip() for p in protos[name].split(",")] if protos[name].strip() not in ("", "void") else []
+        assert len(params) == len(argtypes), (name, params, argtypes)
+        for prm, ct in zip(params, argtypes):
+            is_ptr = "*" in prm or prm.startswith("erd_stream_t")
+            bound_ptr = ct is C.c_void_p or (hasattr(ct, "_type_") and not isinstance(ct._type_, str))
+            assert is_ptr == bound_ptr, (name, prm, ct)
+            if not is_ptr:
+                base = prm.split()[0] if not prm.startswith("const") else prm.split()[1]
+                want = {"int": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "double": C.c_double, "size_t": C.c_size_t}[base]
+                assert C.sizeof(ct) == C.sizeof(want) and (ct in (C.c_float, C.c_double)) == (want in (C.c_float, C.c_double)), (name, prm, ct)
+
+
 def test_distillation_forward_scopes_the_unrecorded_winograd_switch():
     """kernels.distillation_forward(flag) sets where no-grad / frozen convolutions may use the Winograd kernels and
     restores the previous setting, also when the body raises; defaults: teacher on, student's frozen trunk off."""
