@@ -189,6 +189,8 @@ def main():
                          "bf16 matrix cores, fp32 accumulation and storage (BASELINE configs[2])")
     ap.add_argument("--step-graph", action="store_true",
                     help="replay the whole step (everything between two SGD updates) from one hipGraph; same arithmetic")
+    ap.add_argument("--no-teacher-ahead", action="store_true",
+                    help="do not hand the trainer the following batch (teacher of step t+1 then runs next to the forward of step t+1)")
     ap.add_argument("--no-streamk", action="store_true",
                     help="A/B aid: tile-parallel implicit-GEMM launches instead of the stream-K split (every world size uses "
                          "stream-K by default, so the N = 1 point of a scaling curve is the sibling of the N > 1 points)")
@@ -243,13 +245,18 @@ def main():
         torch.cuda.synchronize()
 
     log = None
+    # the loader hands the trainer the FOLLOWING batch as well (Runner.train does the same with a one-batch look-ahead): the
+    # frozen teacher's half of step t+1 is queued next to the backward pass of step t.  Every timed step still runs one
+    # teacher pass, one student forward / backward and one update (+0.65 % fp32, +6 % bf16; --no-teacher-ahead: off)
+    ahead = not args.no_teacher_ahead and not args.serial
+    nb = lambda i: batches[(i + 1) % len(batches)] if ahead else None
     for i in range(args.warmup):
-        log = trainer.train_step(*batches[i % len(batches)])
+        log = trainer.train_step(*batches[i % len(batches)], next_batch=nb(i))
     trainer.flush()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        log = trainer.train_step(*batches[i % len(batches)])
+        log = trainer.train_step(*batches[i % len(batches)], next_batch=nb(i))
     trainer.flush()                   # the deferred SGD of the last step belongs to the timed region
     barrier()
     dt = time.perf_counter() - t0
@@ -290,7 +297,8 @@ def main():
                                                                                  if K.BF16_STORAGE else "bf16 multiplicands / fp32 accumulate+storage")) +
                                    ", procedural weights", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-            "loss": round(loss, 6), "streams": "serial" if args.serial else "teacher||student, cls||reg towers",
+            "loss": round(loss, 6), "streams": "serial" if args.serial else ("teacher(t+1)||backward(t), cls||reg towers, trailing weight gradients" if ahead
+                                                             else "teacher||student, cls||reg towers, trailing weight gradients"),
             "teacher": "hipGraph replay" if args.teacher_graph else "eager launches",
             "step_graph": bool(trainer.step_graph),
         }

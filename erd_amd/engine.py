@@ -216,6 +216,7 @@ class ERDTrainer:
         self._pending_lr = self.base_lr
         self._first = True
         self._pending = False                # an un-applied gradient sits in flat.grad
+        self._teacher_ahead = None           # (inputs, TeacherOut) of the following step (train_step(next_batch=...))
         self.sync = None
         if self.distributed:
             from . import functional as Fn
@@ -371,7 +372,11 @@ class ERDTrainer:
             st.gl[:off[-1]].copy_(torch.cat([g.labels.reshape(-1).long() for g in gts], 0).to(dev, non_blocking=True))
         st.goff.copy_(torch.from_numpy(off), non_blocking=True)
 
-    def train_step(self, inputs: Tensor, data_samples) -> Dict[str, Tensor]:
+    def train_step(self, inputs: Tensor, data_samples, next_batch=None) -> Dict[str, Tensor]:
+        """`next_batch` = (inputs, data_samples) of the FOLLOWING step when the loader has it (a prefetching loader does):
+        the frozen teacher's half of that step is then queued on the side stream behind this step's losses, so it runs
+        next to this step's backward pass instead of next to the following forward pass (the teacher depends on no
+        parameter this step updates).  The following call must pass that same `inputs` object to pick the result up."""
         model = self.model
         cur = torch.cuda.current_stream(self.device)
         if self.step_graph:
@@ -386,14 +391,19 @@ class ERDTrainer:
             # The frozen teacher (forward + ERS + NMS) runs on the side stream, concurrently with (a) the tail of the
             # previous step's gradient all-reduce + the deferred SGD launch and (b) the student's forward on the
             # main stream: two independent kernel streams fill each other's partially filled dispatch rounds.
-            self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side), torch.no_grad():
-                if self.teacher_graphs is not None:
-                    teacher_out = self.teacher_graphs.run(inputs)
-                    gts, _, metas = unpack_gt_instances(data_samples)         # targets depend on the GT: eager
-                    teacher_out.targets = model.bbox_head._targets(teacher_out.sizes, gts, metas, self.device)
-                else:
-                    teacher_out = model.teacher_pass(inputs, data_samples)
+            ahead = self._teacher_ahead
+            self._teacher_ahead = None
+            if ahead is not None and ahead[0] is inputs:
+                teacher_out = ahead[1]                   # queued on the side stream during the previous step's backward
+            else:
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side), torch.no_grad():
+                    if self.teacher_graphs is not None:
+                        teacher_out = self.teacher_graphs.run(inputs)
+                        gts, _, metas = unpack_gt_instances(data_samples)         # targets depend on the GT: eager
+                        teacher_out.targets = model.bbox_head._targets(teacher_out.sizes, gts, metas, self.device)
+                    else:
+                        teacher_out = model.teacher_pass(inputs, data_samples)
             self._apply_pending()
             self.flat.zero_grad()
             K.zero_arena_begin(self.device)
@@ -414,6 +424,10 @@ class ERDTrainer:
             K.zero_arena_begin(self.device)
             losses = model(inputs, data_samples, mode="loss")
         total, log_vars = parse_losses(losses)
+        if next_batch is not None and self.overlap_teacher and self.teacher_graphs is None:
+            # the teacher of the following step: behind everything the side stream holds for this one, next to this backward
+            with torch.cuda.stream(self.side), torch.no_grad():
+                self._teacher_ahead = (next_batch[0], model.teacher_pass(next_batch[0], next_batch[1]))
         if self.sync is not None:
             self.sync.arm()
         total.backward()

@@ -191,6 +191,20 @@ class CocoTrainData:
 # ---------------------------------------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------------------------------------
+def _with_next(it, prepare):
+    """(item, following item or None) pairs of an iterable, every item passed through `prepare` exactly once"""
+    it = iter(it)
+    try:
+        cur = prepare(next(it))
+    except StopIteration:
+        return
+    for raw in it:
+        nxt = prepare(raw)
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class Runner:
     def __init__(self, cfg: Config, data=None, device: Optional[torch.device] = None, log: Callable[[str], None] = print):
         self.cfg = cfg
@@ -249,9 +263,11 @@ class Runner:
                 self.data.set_epoch(self.epoch)
             self.trainer.epoch_factor = self.schedule.epoch_factor(self.epoch)
             t0 = time.perf_counter()
-            for i, batch in enumerate(self.data):
-                out = batch if batch.get("preprocessed") else pre(batch, True)
-                logv = self.trainer.train_step(out["inputs"], out["data_samples"])
+            for i, (out, nxt) in enumerate(_with_next(self.data, lambda b: b if b.get("preprocessed") else pre(b, True))):
+                # one batch of look-ahead: the trainer queues the frozen teacher's half of the following step next to this
+                # step's backward pass (ERDTrainer.train_step)
+                logv = self.trainer.train_step(out["inputs"], out["data_samples"],
+                                               next_batch=None if nxt is None else (nxt["inputs"], nxt["data_samples"]))
                 window.append(logv)
                 done += 1
                 if (i + 1) % self.log_interval == 0 or (max_iters and done >= max_iters):

@@ -327,6 +327,55 @@ def test_bf16_matrix_core_mode_vs_oracle_bf16_multiplicands():
         K.set_compute("f32")
 
 
+def test_teacher_look_ahead_follows_the_plain_trainer():
+    """`train_step(..., next_batch=...)`: the frozen teacher's half of step t+1 is queued next to the backward pass of step t
+    (it depends on nothing step t updates).  (a) What is queued ahead is what an in-place teacher pass on that batch returns
+    (logits, ERS lists, NMS mask, ATSS targets), checked while the backward it overlapped is still fresh; (b) three steps on
+    alternating batches log the losses of the plain order (float-atomic-order noise, amplified by two updates at lr 0.02:
+    observed up to 2e-5); (c) a step whose `inputs` is not the announced tensor recomputes its teacher."""
+    from erd_amd.engine import ERDTrainer
+    tsd, ssd = f7_state_dicts()
+    batches = []
+    for seed in (0, 1):
+        imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=seed)
+        x, metas = O.preprocess(imgs)
+        batches.append((x.cuda(), make_samples(boxes, labels, metas)))
+
+    def run(ahead):
+        model = build_erd(tsd, ssd)
+        tr = ERDTrainer(model, lr=0.02, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0)
+        logs = []
+        for i in range(3):
+            lv = tr.train_step(*batches[i % 2], next_batch=batches[(i + 1) % 2] if ahead else None)
+            logs.append({k: float(v) for k, v in lv.items()})
+            if ahead:                                                        # (a)
+                inp, t = tr._teacher_ahead
+                assert inp is batches[(i + 1) % 2][0]
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    ref = model.teacher_pass(*batches[(i + 1) % 2])
+                assert torch.equal(t.t_cls, ref.t_cls) and torch.equal(t.t_bbox, ref.t_bbox) and torch.equal(t.keep, ref.keep)
+                assert torch.equal(t.ers["counts"], ref.ers["counts"])
+                cnt = ref.ers["counts"].cpu()
+                for n in range(cnt.shape[0]):                                # (entries past the counts are unspecified)
+                    for col, k in enumerate(("idx_cls", "idx_bbox")):
+                        assert torch.equal(t.ers[k][n, :int(cnt[n, col])], ref.ers[k][n, :int(cnt[n, col])]), (n, k)
+                assert torch.equal(t.targets.labels, ref.targets.labels) and torch.equal(t.targets.bbox_targets, ref.targets.bbox_targets)
+        if ahead:                                                            # (c)
+            stale = tr._teacher_ahead[1]
+            lv = tr.train_step(batches[1][0].clone(), batches[1][1])
+            assert tr._teacher_ahead is None and torch.isfinite(lv["loss"]).item() and stale is not None
+        tr.flush()
+        torch.cuda.synchronize()
+        return logs
+
+    plain_logs = run(False)
+    ahead_logs = run(True)
+    for i, (a, b) in enumerate(zip(plain_logs, ahead_logs)):                 # (b)
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=5e-6 if i == 0 else 2e-4, abs=1e-6), (i, k, a[k], b[k])
+
+
 def test_bf16_full_size_step_against_the_fp32_path():
     """BASELINE.json configs[2] at BASELINE size (800x1333, one image): the bf16 mode -- bf16 matrix cores, feature maps and
     their gradients STORED as bf16, fp32 statistics / head outputs / losses / parameter gradients -- against this package's
