@@ -63,6 +63,7 @@ def _may_fork(cur) -> bool:
 # Only with gradient sinks (ERDTrainer, which owns the join): the results land in the flat gradient buffer, nothing is
 # handed back to autograd from the auxiliary stream.
 WGRAD_TRAIL = _os.environ.get('ERD_WGRAD_TRAIL', '1') != '0'
+HEAD_TRAIL = _os.environ.get('ERD_HEAD_TRAIL', '0') != '0'      # the head towers' weight gradients too (A/B aid: see _wgrad_plain)
 _TRAIL = {}
 _TRAIL_ACTIVE = set()
 
@@ -529,7 +530,7 @@ class HeadConvGN(Function):
         dW = dx = None
         xv, dv = K.level_views(x_cat, sizes), K.level_views(dc, sizes)
         if ctx.needs_input_grad[1]:
-            dW = _wgrad_plain(w, xv, dv, 3, 1, 1, keep=(x_cat, dc), trail=False)
+            dW = _wgrad_plain(w, xv, dv, 3, 1, 1, keep=(x_cat, dc), trail=HEAD_TRAIL)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x_cat)
             K.conv_dgrad(dv, K.weight_transpose(wk), K.level_views(dx, sizes), 3, 1, 1)
@@ -559,7 +560,7 @@ class HeadConvBias(Function):
         dW = db = dx = None
         xv, dv = K.level_views(x_cat, sizes), K.level_views(dy, sizes)
         if ctx.needs_input_grad[1]:
-            dW = _wgrad_plain(w, xv, dv, 3, 1, 1, keep=(x_cat, dy), trail=False)
+            dW = _wgrad_plain(w, xv, dv, 3, 1, 1, keep=(x_cat, dy), trail=HEAD_TRAIL)
         if ctx.needs_input_grad[2]:
             db = K.colsum(dy)
         if ctx.needs_input_grad[0]:
