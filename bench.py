@@ -249,14 +249,15 @@ def main():
     # frozen teacher's half of step t+1 is queued next to the backward pass of step t.  Every timed step still runs one
     # teacher pass, one student forward / backward and one update (+0.65 % fp32, +6 % bf16; --no-teacher-ahead: off)
     ahead = not args.no_teacher_ahead and not args.serial
-    nb = lambda i: batches[(i + 1) % len(batches)] if ahead else None
-    for i in range(args.warmup):
-        log = trainer.train_step(*batches[i % len(batches)], next_batch=nb(i))
+    seq = lambda j: batches[j % len(batches)]                    # one batch sequence across warm-up and timed steps, so that
+    nb = lambda j: seq(j + 1) if ahead else None                 # the batch announced by the last warm-up step IS the first timed one
+    for j in range(args.warmup):
+        log = trainer.train_step(*seq(j), next_batch=nb(j))
     trainer.flush()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        log = trainer.train_step(*batches[i % len(batches)], next_batch=nb(i))
+    for j in range(args.warmup, args.warmup + args.steps):
+        log = trainer.train_step(*seq(j), next_batch=nb(j))
     trainer.flush()                   # the deferred SGD of the last step belongs to the timed region
     barrier()
     dt = time.perf_counter() - t0
