@@ -53,6 +53,11 @@ class WgradDesc(C.Structure):
                 ("x_bf16", i32), ("dz_bf16", i32)]
 
 
+class BnFoldItem(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("n", i32), ("eps", f32)]
+
+
 class Levels(C.Structure):
     _fields_ = [("nseg", i32), ("off", i64 * ERD_MAX_SEG), ("cnt", i64 * ERD_MAX_SEG)]
 
@@ -74,6 +79,7 @@ _SIGNATURES = {
     "erd_stem_conv7x7_bn_relu": [P, P, P, P, P, i32, i32, i32, P],
     "erd_maxpool3x3s2": [P, P, i32, i32, i32, i32, i32, P],
     "erd_bn_fold": [P, P, P, P, f32, P, P, i64, P],
+    "erd_bn_fold_batch": [P, i32, i32, P],
     "erd_relu_bwd_colsum": [P, P, P, i64, i32, i64, i64, P, i32, i32, P],
     "erd_bn_dgamma": [P, P, i32, P, P, f32, P, P, i32, i32, P],
     "erd_gn_relu_fwd": [P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), f32, i32, P],

@@ -807,6 +807,26 @@ extern "C" int erd_bn_fold(const float* gamma, const float* beta, const float* m
     return erd::check_launch("bn_fold");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void bn_fold_batch_kernel(const erd_bn_fold_item* __restrict__ items) {
+    const erd_bn_fold_item it = items[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < it.n) {
+        const float s = it.gamma[i] * (1.0f / sqrtf(it.var[i] + it.eps));      // (the arithmetic of bn_fold_kernel)
+        it.scale[i] = s;
+        it.shift[i] = it.beta[i] - it.mean[i] * s;
+    }
+}
+}  // namespace
+
+extern "C" int erd_bn_fold_batch(const erd_bn_fold_item* items_dev, int nitems, int max_n, erd_stream_t stream) {
+    ERD_REQUIRE(items_dev && nitems >= 0 && max_n >= 0, "bn_fold_batch: bad args");
+    if (nitems == 0 || max_n == 0) return 0;
+    hipLaunchKernelGGL(bn_fold_batch_kernel, dim3((unsigned)((max_n + 255) / 256), (unsigned)nitems), dim3(256), 0,
+                       (hipStream_t)stream, items_dev);
+    return erd::check_launch("bn_fold_batch");
+}
+
 extern "C" int erd_relu_bwd_colsum(const void* y, const void* dy, void* dz, int64_t npix, int C,
                                    int64_t nstride_rows, int64_t rows_per_img, float* colsum, int use_relu,
                                    int map_type, erd_stream_t stream) {

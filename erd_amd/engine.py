@@ -17,6 +17,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence
 
+import os
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -217,9 +218,9 @@ class ERDTrainer:
         self._first = True
         self._pending = False                # an un-applied gradient sits in flat.grad
         self._teacher_ahead = None           # (inputs, TeacherOut) of the following step (train_step(next_batch=...))
+        self.prefold = Fn.BnPrefold(model) if os.environ.get("ERD_BN_PREFOLD", "1") != "0" else None
         self.sync = None
         if self.distributed:
-            from . import functional as Fn
             self.sync = BucketedGradSync(self.flat, streams=[torch.cuda.current_stream(dev), Fn.aux_stream(dev),
                                                              Fn.trail_stream(dev)])
         self.is_erd = isinstance(model, GFLIncrementERD)
@@ -256,6 +257,8 @@ class ERDTrainer:
         self._first = False
         self._pending = False
         self.flat.refresh_shadow()
+        if self.prefold is not None:
+            self.prefold.run()               # every trainable BN of the student folded for the coming step, one launch
 
     def flush(self) -> None:
         self._apply_pending()

@@ -202,6 +202,20 @@ int erd_resize_normalize(const void* src_hwc_u8, int sh, int sw, const int* xofs
 /* scale = gamma*rsqrt(var+eps), shift = beta-mean*scale over n channels (resnet.py:268-300, eval BN) */
 int erd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                 float eps, float* scale, float* shift, int64_t n, erd_stream_t stream);
+/* the same for many BNs in ONE launch (the trainable BNs of the student are re-folded once per step, right after the
+ * optimizer update: 42 five-microsecond launches on the forward pass's critical path otherwise).  `items_dev` is a DEVICE
+ * array of nitems entries, max_n the largest n among them. */
+typedef struct {
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* var;
+    float* scale;
+    float* shift;
+    int n;
+    float eps;
+} erd_bn_fold_item;
+int erd_bn_fold_batch(const erd_bn_fold_item* items_dev, int nitems, int max_n, erd_stream_t stream);
 /* use_relu: dz = dy * (y > 0) (dz may alias dy); else dz is not written (dz == dy semantically);
  * colsum[c] += sum_p dz[p,c].  Rows are [npix][C] with an image stride (level views). */
 int erd_relu_bwd_colsum(const void* y, const void* dy, void* dz, int64_t npix, int C,

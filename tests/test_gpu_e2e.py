@@ -376,6 +376,36 @@ def test_teacher_look_ahead_follows_the_plain_trainer():
             assert b[k] == pytest.approx(a[k], rel=5e-6 if i == 0 else 2e-4, abs=1e-6), (i, k, a[k], b[k])
 
 
+def test_batched_bn_fold_equals_the_per_layer_fold_and_tracks_updates():
+    """ERDTrainer folds every trainable frozen-statistics BN of the student in one launch after each optimizer update
+    (functional.BnPrefold, erd_bn_fold_batch): the views it hands to the forward pass are bit-equal to a per-layer erd_bn_fold of
+    the CURRENT parameters, step after step; parameters changed behind the trainer's back fall back to the per-layer launch."""
+    from erd_amd.engine import ERDTrainer
+    from erd_amd import functional as Fn, kernels as K
+    tsd, ssd = f7_state_dicts()
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=0)
+    x, metas = O.preprocess(imgs)
+    batch = (x.cuda(), make_samples(boxes, labels, metas))
+    model = build_erd(tsd, ssd)
+    tr = ERDTrainer(model, lr=0.02, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0)
+    assert tr.prefold is not None and len(tr.prefold.bns) > 30
+    for step in range(3):
+        tr.train_step(*batch)
+        tr.flush()                                  # the update + the batched fold of the updated parameters
+        assert tr.prefold.valid[0]
+        for m in tr.prefold.bns:
+            sc, sh = Fn._bn_fold_cached(m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+            rs, rh = K.bn_fold(m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.eps)
+            assert sc.data_ptr() == m.weight._erd_prefold[2].data_ptr()            # served from the batched result
+            assert torch.equal(sc, rs) and torch.equal(sh, rh)
+    m = tr.prefold.bns[0]
+    with torch.no_grad():
+        m.weight.mul_(1.5)                          # (bumps the version counter: the entry no longer matches)
+    sc, _ = Fn._bn_fold_cached(m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+    assert sc.data_ptr() != m.weight._erd_prefold[2].data_ptr()
+    assert torch.equal(sc, K.bn_fold(m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.eps)[0])
+
+
 def test_bf16_full_size_step_against_the_fp32_path():
     """BASELINE.json configs[2] at BASELINE size (800x1333, one image): the bf16 mode -- bf16 matrix cores, feature maps and
     their gradients STORED as bf16, fp32 statistics / head outputs / losses / parameter gradients -- against this package's
