@@ -58,6 +58,11 @@ class BnFoldItem(C.Structure):
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("n", i32), ("eps", f32)]
 
 
+class WeightPrepItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("rowscale", C.c_void_p), ("dst", C.c_void_p),
+                ("Cout", i32), ("ntaps", i32), ("Cin", i32), ("flip", i32), ("kind", i32), ("block0", i32)]
+
+
 class Levels(C.Structure):
     _fields_ = [("nseg", i32), ("off", i64 * ERD_MAX_SEG), ("cnt", i64 * ERD_MAX_SEG)]
 
@@ -80,6 +85,8 @@ _SIGNATURES = {
     "erd_maxpool3x3s2": [P, P, i32, i32, i32, i32, i32, P],
     "erd_bn_fold": [P, P, P, P, f32, P, P, i64, P],
     "erd_bn_fold_batch": [P, i32, i32, P],
+    "erd_weight_prep_blocks": [i32, i32, i32, i32],
+    "erd_weight_prep_batch": [P, i32, i32, P],
     "erd_relu_bwd_colsum": [P, P, P, i64, i32, i64, i64, P, i32, i32, P],
     "erd_bn_dgamma": [P, P, i32, P, P, f32, P, P, i32, i32, P],
     "erd_gn_relu_fwd": [P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), f32, i32, P],

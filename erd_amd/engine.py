@@ -219,6 +219,8 @@ class ERDTrainer:
         self._pending = False                # an un-applied gradient sits in flat.grad
         self._teacher_ahead = None           # (inputs, TeacherOut) of the following step (train_step(next_batch=...))
         self.prefold = Fn.BnPrefold(model) if os.environ.get("ERD_BN_PREFOLD", "1") != "0" else None
+        self.prep = K.ParamPrep(self.device) if os.environ.get("ERD_PARAM_PREP", "1") != "0" and self.prefold is not None else None
+        K.PREP = self.prep                   # (one trainer per process drives the wrappers' prepared-buffer lookups)
         self.sync = None
         if self.distributed:
             self.sync = BucketedGradSync(self.flat, streams=[torch.cuda.current_stream(dev), Fn.aux_stream(dev),
@@ -259,6 +261,11 @@ class ERDTrainer:
         self.flat.refresh_shadow()
         if self.prefold is not None:
             self.prefold.run()               # every trainable BN of the student folded for the coming step, one launch
+        if self.prep is not None:            # transposed weights / Winograd weight images of the coming step, two launches
+            if self.prefold is not None and self.prefold.valid[0]:
+                self.prep.run()
+            else:
+                self.prep.invalidate()
 
     def flush(self) -> None:
         self._apply_pending()

@@ -225,6 +225,7 @@ class BnPrefold:
             sc, sh = self.buf[off:off + n], self.buf[total + off:total + off + n]
             it.gamma, it.beta, it.mean, it.var = m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr()
             it.scale, it.shift, it.n, it.eps = sc.data_ptr(), sh.data_ptr(), n, float(m.eps)
+            sc._erd_stable = True           # (kernels.ParamPrep: a row scale at a fixed address, refreshed every step)
             self.views.append((sc, sh))
             off += n
         import ctypes as C

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os as _os
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -400,8 +400,18 @@ def wino_weights(w_ohwi: Tensor, flip: bool = False) -> Tensor:
     input-gradient form on transposed weights)"""
     Cout, kh, kw, Cin = w_ohwi.shape
     assert kh == 3 and kw == 3 and w_ohwi.is_contiguous() and w_ohwi.dtype == torch.float32
+    owner = None
+    if PREP is not None:         # forward form: the source is the parameter; gradient form: a prepared transposed weight
+        owner = _prep_owner(w_ohwi) if not flip else getattr(w_ohwi, "_erd_prep_owner", None)
+    key = ("UT" if flip else "U", id(owner))
+    if owner is not None:
+        r = PREP.lookup(key)
+        if r is not None and r.matches(owner, w_ohwi, None):
+            return r.out
     U = torch.empty(int(_lib.load().erd_wino_weights_elems(Cout, Cin)), dtype=torch.float32, device=w_ohwi.device)
     call("erd_wino_weights", _p(w_ohwi), _p(U), Cout, Cin, 1 if flip else 0, _stream())
+    if owner is not None and not torch.cuda.is_current_stream_capturing():
+        PREP.register(key, 2, w_ohwi, None, torch.empty_like(U), Cout, 9, Cin, 1 if flip else 0, owner, 1 if flip else 0)
     return U
 
 
@@ -492,15 +502,109 @@ def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: 
                 tag=f"px{sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs)} {Cin}->{Cout} k3s1" if TIMING_DETAIL else "")
 
 
+# ---------------------------------------------------------------------------------------------
+# per-step parameter preparation: everything the step derives from the convolution weights alone (transposed / BN-scaled
+# weights of the input-gradient convolutions, Winograd weight images of both forms) is rebuilt by the trainer right after
+# the optimizer update in two launches (erd_weight_prep_batch) instead of ~105 small launches scattered over the forward
+# and backward passes.  The wrappers below serve a prepared buffer when one is valid for this step and otherwise launch
+# as before -- and, under a trainer, leave a recipe so that the NEXT update prepares it.
+# ---------------------------------------------------------------------------------------------
+class _PrepRecipe:
+    __slots__ = ("kind", "src", "rowscale", "out", "Cout", "ntaps", "Cin", "flip", "owner", "version", "level", "stamp",
+                 "src_ptr", "rs_ptr")
+
+    def matches(self, owner, src: Tensor, rowscale: Optional[Tensor]) -> bool:
+        return (self.owner is owner and owner._version == self.version and src.data_ptr() == self.src_ptr and
+                (0 if rowscale is None else rowscale.data_ptr()) == self.rs_ptr)
+
+
+class ParamPrep:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.recipes: Dict[tuple, _PrepRecipe] = {}
+        self.stamp = 0
+        self._tables = None
+
+    def lookup(self, key) -> Optional[_PrepRecipe]:
+        r = self.recipes.get(key)
+        return r if r is not None and r.stamp == self.stamp and self.stamp > 0 else None
+
+    def register(self, key, kind: int, src: Tensor, rowscale: Optional[Tensor], out: Tensor, Cout: int, ntaps: int, Cin: int,
+                 flip: int, owner, level: int) -> None:
+        r = _PrepRecipe()
+        r.kind, r.src, r.rowscale, r.out, r.Cout, r.ntaps, r.Cin, r.flip = kind, src, rowscale, out, Cout, ntaps, Cin, flip
+        r.owner, r.version, r.level, r.stamp = owner, owner._version, level, -1
+        r.src_ptr, r.rs_ptr = src.data_ptr(), 0 if rowscale is None else rowscale.data_ptr()
+        out._erd_prep_owner = owner
+        if key[0] == "T":                       # a Winograd image built from the previous transposed buffer is orphaned
+            self.recipes.pop(("UT", key[1]), None)
+        self.recipes[key] = r
+        self._tables = None
+
+    def invalidate(self) -> None:
+        self.stamp += 1
+
+    def run(self) -> None:
+        """rebuild every registered buffer from the current parameters (call right after the optimizer update, on the
+        stream the step runs on, after the batched BN fold whose results the row scales are)"""
+        self.stamp += 1
+        if not self.recipes:
+            return
+        for key, r in list(self.recipes.items()):      # re-homed storage / edited parameters: the recipe is stale
+            if r.src.data_ptr() != r.src_ptr or (r.rowscale is not None and r.rowscale.data_ptr() != r.rs_ptr) or \
+                    r.owner._version != r.version:
+                del self.recipes[key]
+                if key[0] == "T":
+                    self.recipes.pop(("UT", key[1]), None)
+                self._tables = None
+        if self._tables is None:
+            from ._lib import WeightPrepItem
+            lib = _lib.load()
+            self._tables = []
+            for level in (0, 1):
+                rs = [r for r in self.recipes.values() if r.level == level]
+                if not rs:
+                    continue
+                items = (WeightPrepItem * len(rs))()
+                blk = 0
+                for it, r in zip(items, rs):
+                    it.w, it.rowscale, it.dst = r.src_ptr, r.rs_ptr, r.out.data_ptr()
+                    it.Cout, it.ntaps, it.Cin, it.flip, it.kind, it.block0 = r.Cout, r.ntaps, r.Cin, r.flip, r.kind, blk
+                    blk += int(lib.erd_weight_prep_blocks(r.kind, r.Cout, r.ntaps, r.Cin))
+                table = torch.frombuffer(bytearray(bytes(memoryview(items))), dtype=torch.uint8).to(self.device)
+                self._tables.append((table, len(rs), blk, rs))
+        for table, n, blocks, rs in self._tables:
+            call("erd_weight_prep_batch", _p(table), n, blocks, _stream())
+            for r in rs:
+                r.stamp = self.stamp
+
+
+PREP: Optional[ParamPrep] = None        # installed by ERDTrainer (one model per process)
+
+
+def _prep_owner(w: Tensor):
+    o = getattr(w, "_erd_owner", None)
+    return o if o is not None and getattr(o, "_erd_sink", False) else None
+
+
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
     """[Cout,k,k,Cin] -> [Cin,k,k,Cout] (* rowscale[co]): weights of the input-gradient convolution."""
     Cout, k, _, Cin = w.shape
-    if COMPUTE == "bf16":      # rounded on the way out: conv_dgrad hands it to the bf16 matrix cores as is
+    bf = COMPUTE == "bf16"
+    owner = _prep_owner(w) if PREP is not None else None
+    if owner is not None:
+        r = PREP.lookup(("T", id(owner), bf))
+        if r is not None and r.matches(owner, w, rowscale):
+            return r.out
+    if bf:      # rounded on the way out: conv_dgrad hands it to the bf16 matrix cores as is
         wt = torch.empty((Cin, k, k, Cout), dtype=torch.bfloat16, device=w.device)
         call("erd_weight_transpose_bf16", _p(w), _p(rowscale), _p(wt), Cout, k * k, Cin, 0, _stream())
-        return wt
-    wt = torch.empty((Cin, k, k, Cout), dtype=torch.float32, device=w.device)
-    call("erd_weight_transpose", _p(w), _p(rowscale), _p(wt), Cout, k * k, Cin, 0, _stream())
+    else:
+        wt = torch.empty((Cin, k, k, Cout), dtype=torch.float32, device=w.device)
+        call("erd_weight_transpose", _p(w), _p(rowscale), _p(wt), Cout, k * k, Cin, 0, _stream())
+    if owner is not None and (rowscale is None or getattr(rowscale, "_erd_stable", False)) and not torch.cuda.is_current_stream_capturing():
+        # (a row scale that is not a view of the trainer's batched BN fold changes its address every step: not preparable)
+        PREP.register(("T", id(owner), bf), 1 if bf else 0, w, rowscale, torch.empty_like(wt), Cout, k * k, Cin, 0, owner, 0)
     return wt
 
 

@@ -175,6 +175,23 @@ int erd_weight_transpose(const float* w, const float* rowscale, float* dst, int 
 int erd_weight_transpose_bf16(const float* w, const float* rowscale, void* dst, int Cout, int ntaps,
                               int Cin, int flip, erd_stream_t stream);
 
+/* Many weight transforms in ONE launch: erd_weight_transpose (kind 0), erd_weight_transpose_bf16 (kind 1) or
+ * erd_wino_weights (kind 2: w is [Cout][3][3][Cin], ntaps = 9, rowscale unused) per item, same arithmetic.  `items_dev` is a
+ * DEVICE array sorted by block0; item i owns blocks [block0, block0 + erd_weight_prep_blocks(kind, Cout, ntaps, Cin)) of the
+ * launch, total_blocks is their sum.  Items of one launch must not depend on each other (a Winograd image of a transposed
+ * weight goes into a second launch).  The trainer prepares everything the step derives from the parameters alone this
+ * way, right after the optimizer update. */
+typedef struct {
+    const float* w;
+    const float* rowscale;
+    void* dst;
+    int Cout, ntaps, Cin, flip;
+    int kind;
+    int block0;
+} erd_weight_prep_item;
+int erd_weight_prep_blocks(int kind, int Cout, int ntaps, int Cin);
+int erd_weight_prep_batch(const erd_weight_prep_item* items_dev, int nitems, int total_blocks, erd_stream_t stream);
+
 /* ---- stem (resnet.py:636-639): conv7x7/2 (3->64) + frozen BN + ReLU, then maxpool 3x3/2 ---- */
 int erd_stem_conv7x7_bn_relu(const float* x_nchw, const float* w_ohwi, const float* scale,
                              const float* shift, float* out_nhwc, int N, int H, int W,

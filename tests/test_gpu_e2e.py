@@ -406,6 +406,55 @@ def test_batched_bn_fold_equals_the_per_layer_fold_and_tracks_updates():
     assert torch.equal(sc, K.bn_fold(m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.eps)[0])
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
+    """kernels.ParamPrep: after every optimizer update the trainer rebuilds the transposed (BN-scaled) weights of the
+    input-gradient convolutions and the Winograd weight images in two launches (erd_weight_prep_batch).  From the step at
+    which a recipe is known on, the wrappers serve those buffers -- and they must be bit-equal to what erd_weight_transpose
+    / erd_wino_weights produce from the CURRENT parameters."""
+    from erd_amd.engine import ERDTrainer
+    from erd_amd import functional as Fn, kernels as K
+    tsd, ssd = f7_state_dicts()
+    imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=0)
+    x, metas = O.preprocess(imgs)
+    batch = (x.cuda(), make_samples(boxes, labels, metas))
+    K.set_compute(mode)
+    try:
+        model = build_erd(tsd, ssd)
+        tr = ERDTrainer(model, lr=0.02, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0)
+        assert K.PREP is tr.prep and tr.prep is not None
+        for _ in range(4):
+            tr.train_step(*batch)
+        tr.flush()
+        torch.cuda.synchronize()
+        kinds = {}
+        for key, r in tr.prep.recipes.items():
+            assert r.stamp == tr.prep.stamp, key                      # rebuilt by the last update
+            kinds[key[0]] = kinds.get(key[0], 0) + 1
+            if r.kind == 2:
+                ref = torch.empty_like(r.out)
+                K.call("erd_wino_weights", K._p(r.src), K._p(ref), r.Cout, r.Cin, r.flip, K._stream())
+            else:
+                ref = torch.empty_like(r.out)
+                K.call("erd_weight_transpose_bf16" if r.kind == 1 else "erd_weight_transpose", K._p(r.src), K._p(r.rowscale), K._p(ref),
+                       r.Cout, r.ntaps, r.Cin, r.flip, K._stream())
+            assert torch.equal(ref, r.out), key
+        assert kinds.get("T", 0) >= 40, kinds                         # every trainable convolution's transposed weights
+        if mode == "f32":
+            assert kinds.get("U", 0) >= 15 and kinds.get("UT", 0) >= 15, kinds
+        # ... and they are what the wrappers hand out
+        blk = model.backbone.layer3[0]
+        wk = Fn.ohwi(blk.conv2.weight)
+        r = tr.prep.recipes[("T", id(blk.conv2.weight), mode == "bf16")]
+        assert K.weight_transpose(wk, r.rowscale).data_ptr() == r.out.data_ptr()
+        with torch.no_grad():
+            blk.conv2.weight.mul_(1.0)              # version bump: the prepared buffer no longer vouches for the parameter
+        assert K.weight_transpose(wk, r.rowscale).data_ptr() != r.out.data_ptr()
+    finally:
+        K.set_compute("f32")
+        K.PREP = None
+
+
 def test_bf16_full_size_step_against_the_fp32_path():
     """BASELINE.json configs[2] at BASELINE size (800x1333, one image): the bf16 mode -- bf16 matrix cores, feature maps and
     their gradients STORED as bf16, fp32 statistics / head outputs / losses / parameter gradients -- against this package's
