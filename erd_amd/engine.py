@@ -104,6 +104,8 @@ class BucketedGradSync:
         self._works: List = []
         self._remaining: List[int] = []
         self.late_buckets = 0            # buckets whose all-reduce had to be issued by wait() (diagnostic)
+        self._warned_late = False
+        self._next = 0
         for i, p in enumerate(flat.params):
             hook = self._make_hook(i)
             p.register_post_accumulate_grad_hook(hook)
@@ -112,6 +114,18 @@ class BucketedGradSync:
     def arm(self) -> None:
         self._remaining = [len(m) for (_, _, m) in self.flat.buckets]
         self._works = []
+        self._next = 0                   # collectives are issued strictly in bucket order: the same order on every rank
+
+    def _issue(self, b: int) -> None:
+        s, e, _ = self.flat.buckets[b]
+        # a bucket's gradients may come from kernels on different streams (the two head towers run their backward on
+        # two, the backbone's weight gradients trail on a third): the collective is ordered behind ALL of them
+        if self.streams:
+            cs = torch.cuda.current_stream(self.flat.grad.device)
+            for st in self.streams:
+                if st != cs:
+                    cs.wait_stream(st)
+        self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def _make_hook(self, i: int):
         def hook(_p):
@@ -119,32 +133,29 @@ class BucketedGradSync:
                 return
             b = self.flat.bucket_of[i]
             self._remaining[b] -= 1
-            if self._remaining[b] == 0:
-                s, e, _ = self.flat.buckets[b]
-                # a bucket's gradients may come from kernels on different streams (the two head towers run their
-                # backward on two streams): the collective is ordered behind ALL of them, not only the reporting one
-                if self.streams:
-                    cs = torch.cuda.current_stream(self.flat.grad.device)
-                    for st in self.streams:
-                        if st != cs:
-                            cs.wait_stream(st)
-                self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            # issue every complete bucket at the head of the queue.  A bucket that completes before an earlier one (a
+            # parameter without a gradient on THIS rank only) waits for it, so that all ranks enqueue the collectives of
+            # one communicator in the same order whatever their local completion order is
+            while self._next < len(self._remaining) and self._remaining[self._next] == 0:
+                self._issue(self._next)
+                self._next += 1
         return hook
 
     def wait(self) -> None:
         # a bucket whose countdown never reached zero (a parameter without a gradient this step, or a broken
         # "one notification per parameter" contract) would leave rank-local gradients in the flat buffer and let the
-        # ranks diverge silently: its collective is issued here, behind every gradient-producing stream
-        for b, left in enumerate(self._remaining):
-            if left > 0:
-                s, e, _ = self.flat.buckets[b]
-                if self.streams:
-                    cs = torch.cuda.current_stream(self.flat.grad.device)
-                    for st in self.streams:
-                        if st != cs:
-                            cs.wait_stream(st)
-                self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
-                self.late_buckets += 1
+        # ranks diverge silently: the rest of the queue is issued here, in bucket order, behind every producing stream
+        late = len(self._remaining) - self._next if self._remaining else 0
+        while self._remaining and self._next < len(self._remaining):
+            self._issue(self._next)
+            self._next += 1
+        if late:
+            self.late_buckets += late
+            if not self._warned_late:
+                self._warned_late = True
+                import warnings
+                warnings.warn(f"BucketedGradSync: {late} of {len(self._remaining)} gradient buckets were not complete when backward "
+                              "ended (a parameter without a gradient this step?); their all-reduce was issued late, in bucket order")
         for w in self._works:
             w.wait()
         self._works = []
@@ -170,6 +181,7 @@ class TeacherGraphs:
             if len(self.graphs) >= self.max_graphs:
                 self.graphs.pop(next(iter(self.graphs)))
             stream = torch.cuda.current_stream(inputs.device)
+            K.pin_workspaces()               # graphs hold workspace addresses: outgrown buffers are retired, not freed
             static_in = inputs.clone()
             with torch.no_grad():
                 self.model.teacher_pass(static_in, share_trunk=False)      # eager warm-up: workspaces, anchor / folded-BN caches
@@ -220,7 +232,10 @@ class ERDTrainer:
         self._teacher_ahead = None           # (inputs, TeacherOut) of the following step (train_step(next_batch=...))
         self.prefold = Fn.BnPrefold(model) if os.environ.get("ERD_BN_PREFOLD", "1") != "0" else None
         self.prep = K.ParamPrep(self.device) if os.environ.get("ERD_PARAM_PREP", "1") != "0" and self.prefold is not None else None
-        K.PREP = self.prep                   # (one trainer per process drives the wrappers' prepared-buffer lookups)
+        for p in self.flat.params:           # the wrappers find the prepared buffers through the parameter they belong to
+            p._erd_prep = self.prep          # (kernels._prep_of): several trainers in one process do not see each other's
+        if self.prep is not None:
+            self.prep.on_stale = self._drop_step_graphs
         self.sync = None
         if self.distributed:
             self.sync = BucketedGradSync(self.flat, streams=[torch.cuda.current_stream(dev), Fn.aux_stream(dev),
@@ -238,6 +253,11 @@ class ERDTrainer:
         if teacher_graph and not self.overlap_teacher:
             raise ValueError("teacher_graph needs the ERD detector with overlap_teacher=True")
         self.teacher_graphs = TeacherGraphs(model) if teacher_graph else None
+
+    def _drop_step_graphs(self) -> None:
+        """captured steps read the prepared weight buffers by address: once those stop vouching for the parameters
+        (re-homed storage, a parameter edited behind the trainer's back) the graphs are recorded anew on next use"""
+        self._step_graphs.clear()
 
     # -- schedule (schedule_1x.py:7-17: LinearLR warm-up; MultiStep handled by the caller per epoch) ------------
     def lr_at(self, it: int, epoch_factor: float = 1.0) -> float:
@@ -347,6 +367,7 @@ class ERDTrainer:
                                  goff=torch.zeros((N + 1,), dtype=torch.int32, device=dev),
                                  metas=[dict(pad_shape=tuple(m["pad_shape"])) for m in metas], names=None)
             self._fill_static(st, inputs, gts, counts)
+            K.pin_workspaces()               # graphs hold workspace addresses: outgrown buffers are retired, not freed
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(cur)
             Fn.CAPTURE_ORIGIN = s.cuda_stream        # joins only into the origin stream: see functional.CAPTURE_ORIGIN
@@ -435,7 +456,12 @@ class ERDTrainer:
             losses = model(inputs, data_samples, mode="loss")
         total, log_vars = parse_losses(losses)
         if next_batch is not None and self.overlap_teacher and self.teacher_graphs is None:
-            # the teacher of the following step: behind everything the side stream holds for this one, next to this backward
+            # the teacher of the following step: behind everything the side stream holds for this one, next to this backward.
+            # `cur` holds whatever PRODUCED next_batch (Runner.train prepares batch t+1 on the current stream before it calls
+            # train_step(t): preprocess / resize kernels, H2D copies) plus this step's forward and losses, but not yet its
+            # backward -- the side stream must be ordered behind that producer (without this join the teacher could read
+            # half-written pixels as soon as the host runs ahead), and still runs next to backward(t).
+            self.side.wait_stream(cur)
             with torch.cuda.stream(self.side), torch.no_grad():
                 self._teacher_ahead = (next_batch[0], model.teacher_pass(next_batch[0], next_batch[1]))
         if self.sync is not None:

@@ -86,6 +86,25 @@ def _timed_call(kname: str, flop: float, cname: str, *args, nbytes: float = 0.0,
 # workspace cache: one growing buffer per (name, device, stream) -- stream-ordered reuse is safe
 # ---------------------------------------------------------------------------------------------
 _WS = {}
+# A captured hipGraph (engine.TeacherGraphs, ERDTrainer(step_graph=True)) bakes the ADDRESSES of the workspaces its
+# kernels used into its nodes.  A later, larger request (another input shape, eager or captured) replaces the buffer; if
+# the old allocation were freed, replaying the earlier graph would write into memory the caching allocator has handed to
+# somebody else.  From the first capture on (`pin_workspaces()`), outgrown buffers are therefore retired, not freed.
+_WS_PINNED = False
+_WS_RETIRED: List[Tensor] = []
+
+
+def pin_workspaces() -> None:
+    """called by whoever captures a graph, before the capture: outgrown workspaces stay allocated from now on"""
+    global _WS_PINNED
+    _WS_PINNED = True
+
+
+def _ws_replace(key, buf: Tensor) -> None:
+    old = _WS.get(key)
+    if old is not None and _WS_PINNED:
+        _WS_RETIRED.append(old)
+    _WS[key] = buf
 
 
 def workspace(name: str, nbytes: int, device) -> Tensor:
@@ -93,7 +112,7 @@ def workspace(name: str, nbytes: int, device) -> Tensor:
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
-        _WS[key] = buf
+        _ws_replace(key, buf)
     return buf
 
 
@@ -304,7 +323,7 @@ def _attach_sk_ws(d: ConvDesc, device) -> None:
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)    # tickets must start at zero
-        _WS[key] = ws
+        _ws_replace(key, ws)
     d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), nbytes
 
 
@@ -400,9 +419,11 @@ def wino_weights(w_ohwi: Tensor, flip: bool = False) -> Tensor:
     input-gradient form on transposed weights)"""
     Cout, kh, kw, Cin = w_ohwi.shape
     assert kh == 3 and kw == 3 and w_ohwi.is_contiguous() and w_ohwi.dtype == torch.float32
-    owner = None
-    if PREP is not None:         # forward form: the source is the parameter; gradient form: a prepared transposed weight
-        owner = _prep_owner(w_ohwi) if not flip else getattr(w_ohwi, "_erd_prep_owner", None)
+    # forward form: the source is the parameter; gradient form: a prepared transposed weight
+    owner = _prep_owner(w_ohwi) if not flip else getattr(w_ohwi, "_erd_prep_owner", None)
+    PREP = _prep_of(owner)
+    if PREP is None:
+        owner = None
     key = ("UT" if flip else "U", id(owner))
     if owner is not None:
         r = PREP.lookup(key)
@@ -524,6 +545,12 @@ class ParamPrep:
         self.recipes: Dict[tuple, _PrepRecipe] = {}
         self.stamp = 0
         self._tables = None
+        self.on_stale = None             # callable: prepared buffers stopped vouching for the parameters (captured step graphs
+                                         # read them by address: the trainer drops those graphs)
+
+    def _stale(self) -> None:
+        if self.on_stale is not None:
+            self.on_stale()
 
     def lookup(self, key) -> Optional[_PrepRecipe]:
         r = self.recipes.get(key)
@@ -543,6 +570,7 @@ class ParamPrep:
 
     def invalidate(self) -> None:
         self.stamp += 1
+        self._stale()
 
     def run(self) -> None:
         """rebuild every registered buffer from the current parameters (call right after the optimizer update, on the
@@ -557,6 +585,7 @@ class ParamPrep:
                 if key[0] == "T":
                     self.recipes.pop(("UT", key[1]), None)
                 self._tables = None
+                self._stale()
         if self._tables is None:
             from ._lib import WeightPrepItem
             lib = _lib.load()
@@ -579,19 +608,25 @@ class ParamPrep:
                 r.stamp = self.stamp
 
 
-PREP: Optional[ParamPrep] = None        # installed by ERDTrainer (one model per process)
-
-
 def _prep_owner(w: Tensor):
     o = getattr(w, "_erd_owner", None)
     return o if o is not None and getattr(o, "_erd_sink", False) else None
+
+
+def _prep_of(owner) -> Optional[ParamPrep]:
+    """the ParamPrep of the trainer that owns this parameter (ERDTrainer tags its flat parameters with `_erd_prep`):
+    two trainers in one process (a test suite; a train + fine-tune pair) each serve their own prepared buffers"""
+    return None if owner is None else getattr(owner, "_erd_prep", None)
 
 
 def weight_transpose(w: Tensor, rowscale: Optional[Tensor] = None) -> Tensor:
     """[Cout,k,k,Cin] -> [Cin,k,k,Cout] (* rowscale[co]): weights of the input-gradient convolution."""
     Cout, k, _, Cin = w.shape
     bf = COMPUTE == "bf16"
-    owner = _prep_owner(w) if PREP is not None else None
+    owner = _prep_owner(w)
+    PREP = _prep_of(owner)
+    if PREP is None:
+        owner = None
     if owner is not None:
         r = PREP.lookup(("T", id(owner), bf))
         if r is not None and r.matches(owner, w, rowscale):

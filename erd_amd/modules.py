@@ -123,21 +123,39 @@ def _gpu_only(x: Tensor, who: str) -> None:
 # ---------------------------------------------------------------------------------------------------
 # ResNet
 # ---------------------------------------------------------------------------------------------------
+# 'torchvision://<name>' in the reference resolves through mmengine's `get_torchvision_models()`, which for every
+# torchvision >= 0.13 reads the frozen torchvision-0.12 URL table (mmengine/hub/torchvision_0.12.json): ONE fixed file
+# per name.  These are the basenames of those URLs for the ResNets this package builds.
+_TORCHVISION_FILES = {"resnet18": "resnet18-f37072fd.pth", "resnet34": "resnet34-b627a593.pth",
+                      "resnet50": "resnet50-0676ba61.pth", "resnet101": "resnet101-63fe2227.pth",
+                      "resnet152": "resnet152-394f9c45.pth"}
+
+
 def _resolve_pretrained(checkpoint: str) -> Optional[str]:
-    """local path of an init_cfg checkpoint, or None.  'torchvision://resnet50' -> resnet50*.pth under
-    $ERD_PRETRAINED_DIR or <torch hub dir>/checkpoints (the names torchvision's own downloader uses)."""
+    """local path of an init_cfg checkpoint, or None.  'torchvision://resnet50' -> the exact file the reference's
+    scheme downloads (resnet50-0676ba61.pth) under $ERD_PRETRAINED_DIR or <torch hub dir>/checkpoints.  Only when that
+    file is absent does a `<name>*.pth` glob apply, and then with a warning that names the file that was picked (a
+    directory may also hold IMAGENET1K_V2 weights or a user's resnet50_custom.pth)."""
     if os.path.isfile(checkpoint):
         return checkpoint
     if "://" not in checkpoint:
         return None
     name = checkpoint.split("://", 1)[1]
     import glob
-    dirs = [os.environ.get("ERD_PRETRAINED_DIR"), os.path.join(torch.hub.get_dir(), "checkpoints")]
+    dirs = [d for d in (os.environ.get("ERD_PRETRAINED_DIR"), os.path.join(torch.hub.get_dir(), "checkpoints"))
+            if d and os.path.isdir(d)]
+    exact = _TORCHVISION_FILES.get(name) if checkpoint.startswith("torchvision://") else None
+    if exact:
+        for d in dirs:
+            if os.path.isfile(os.path.join(d, exact)):
+                return os.path.join(d, exact)
     for d in dirs:
-        if d and os.path.isdir(d):
-            hits = sorted(glob.glob(os.path.join(d, name + "*.pth")))
-            if hits:
-                return hits[0]
+        hits = sorted(glob.glob(os.path.join(d, name + "*.pth")))
+        if hits:
+            import warnings
+            warnings.warn(f"{checkpoint!r}: {exact or 'the canonical file'} not found under {dirs}; using {hits[0]} "
+                          f"(first of {len(hits)} files matching {name}*.pth)", RuntimeWarning)
+            return hits[0]
     return None
 
 
@@ -260,7 +278,7 @@ class ResNet(nn.Module):
             import warnings
             warnings.warn(msg + " -- continuing with RANDOM (kaiming) backbone weights", RuntimeWarning)
             return
-        sd = torch.load(path, map_location="cpu", weights_only=False)
+        sd = torch.load(path, map_location="cpu", weights_only=True)      # a plain state dict: no pickled code is run
         sd = sd.get("state_dict", sd)
         prefix = cfg.get("prefix")
         if prefix:

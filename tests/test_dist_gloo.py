@@ -47,6 +47,28 @@ def _worker(rank, world, port, q):
         avg = reduce_mean(local)
         ok = ok and world_size() == world and torch.allclose(avg, torch.tensor([3.5, 15.0]))
         ok = ok and torch.equal(local, torch.tensor([3.0 + rank, 10.0 * (rank + 1)]))       # the input is not modified
+        # a parameter without a gradient on ONE rank only (rank 1 leaves the last layer -- the FIRST bucket in backward
+        # order -- out of its loss): that rank completes the bucket late.  Collectives must still be enqueued in the same
+        # order on both ranks (mismatched order = wrong buffers paired, or a hang), the result is the plain average, and
+        # the late rank says so
+        import warnings
+        flat.zero_grad(); sync.arm()
+        with warnings.catch_warnings(record=True) as wrn:
+            warnings.simplefilter("always")
+            h = net[3](net[2](net[1](net[0](x))))
+            (net[4](h).square().mean() if rank == 0 else h.square().mean()).backward()
+            sync.wait()
+        mine = flat.grad.clone() / world
+        flat.zero_grad()
+        h = net[3](net[2](net[1](net[0](x))))
+        (net[4](h).square().mean() if rank == 0 else h.square().mean()).backward()
+        loc = [torch.zeros_like(flat.grad) for _ in range(world)]
+        dist.all_gather(loc, flat.grad.clone())
+        ok = ok and torch.allclose(mine, sum(loc) / world, rtol=1e-6, atol=1e-8)
+        if rank == 1:
+            ok = ok and sync.late_buckets >= 1 and any("issued late" in str(m.message) for m in wrn)
+        else:
+            ok = ok and sync.late_buckets == 0
         q.put((rank, bool(ok), len(flat.buckets)))
     finally:
         dist.destroy_process_group()

@@ -376,6 +376,42 @@ def test_teacher_look_ahead_follows_the_plain_trainer():
             assert b[k] == pytest.approx(a[k], rel=5e-6 if i == 0 else 2e-4, abs=1e-6), (i, k, a[k], b[k])
 
 
+def test_teacher_look_ahead_waits_for_the_producer_of_the_next_batch():
+    """Runner.train prepares batch t+1 on the CURRENT stream (preprocess / resize kernels, non-blocking H2D copies, no
+    host sync) before it calls train_step(t, next_batch=t+1).  The look-ahead teacher runs on the side stream: it must be
+    ordered behind that producer.  Here the next batch's pixels are written by a copy that sits behind a long-running
+    kernel on the current stream; without the join the side stream (idle after its first step) would read the
+    placeholder values.  The queued teacher output must equal an in-place teacher pass on the FINAL pixels."""
+    from erd_amd.engine import ERDTrainer
+    tsd, ssd = f7_state_dicts()
+    batches = []
+    for seed in (0, 1, 2):
+        imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=seed)
+        x, metas = O.preprocess(imgs)
+        batches.append((x.cuda(), make_samples(boxes, labels, metas)))
+    model = build_erd(tsd, ssd)
+    tr = ERDTrainer(model, lr=0.02, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0)
+    tr.train_step(*batches[0], next_batch=batches[1])          # the side stream has run once: look-ahead is active from here
+    torch.cuda.synchronize()
+    for rep in range(3):
+        final = batches[2][0] + float(rep)
+        slot = torch.full_like(final, 1e3)                     # placeholder pixels the teacher must never see
+        nxt = (slot, batches[2][1])
+        torch.cuda._sleep(400_000_000)                         # ~0.2 s of spinning on the current stream ...
+        slot.copy_(final)                                      # ... and only then the producer of the next batch
+        tr.train_step(*batches[1], next_batch=nxt)
+        inp, t = tr._teacher_ahead
+        assert inp is slot
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = model.teacher_pass(final, batches[2][1])
+        assert torch.equal(t.t_cls, ref.t_cls) and torch.equal(t.t_bbox, ref.t_bbox), rep
+        assert torch.equal(t.ers["counts"], ref.ers["counts"]) and torch.equal(t.keep, ref.keep)
+        tr._teacher_ahead = None                               # (the announced tensor is not fed back in this test)
+    tr.flush()
+    torch.cuda.synchronize()
+
+
 def test_batched_bn_fold_equals_the_per_layer_fold_and_tracks_updates():
     """ERDTrainer folds every trainable frozen-statistics BN of the student in one launch after each optimizer update
     (functional.BnPrefold, erd_bn_fold_batch): the views it hands to the forward pass are bit-equal to a per-layer erd_bn_fold of
@@ -422,7 +458,7 @@ def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
     try:
         model = build_erd(tsd, ssd)
         tr = ERDTrainer(model, lr=0.02, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0)
-        assert K.PREP is tr.prep and tr.prep is not None
+        assert tr.prep is not None and all(p._erd_prep is tr.prep for p in tr.flat.params)
         for _ in range(4):
             tr.train_step(*batch)
         tr.flush()
@@ -452,7 +488,6 @@ def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
         assert K.weight_transpose(wk, r.rowscale).data_ptr() != r.out.data_ptr()
     finally:
         K.set_compute("f32")
-        K.PREP = None
 
 
 def test_bf16_full_size_step_against_the_fp32_path():
@@ -589,3 +624,48 @@ def test_whole_step_hipgraph_replay_follows_the_eager_trainer():
     num = sum(float((graph_w[k] - eager_w[k]).double().pow(2).sum()) for k in eager_w)
     den = sum(float(eager_w[k].double().pow(2).sum()) for k in eager_w)
     assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5
+
+
+def test_step_graphs_of_two_shapes_survive_workspace_growth():
+    """A captured graph holds the ADDRESSES of the workspaces its kernels used (split-K slabs on the trailing stream,
+    GroupNorm statistics, ERS / NMS scratch).  Capturing a LARGER shape afterwards grows those workspaces; the outgrown
+    buffers must stay allocated (kernels.pin_workspaces), otherwise the replay of the small graph writes into memory the
+    caching allocator has handed to other tensors.  small -> large -> small replays: the small shape's logged losses are
+    the eager trainer's, and a canary allocated after the growth is untouched."""
+    from erd_amd.engine import ERDTrainer
+    from erd_amd import kernels as K
+    tsd, ssd = f7_state_dicts()
+
+    def batch(h, w, seed):
+        imgs, boxes, labels = O.synthetic_batch(2, h, w, 40, seed=seed)
+        x, metas = O.preprocess(imgs)
+        return x.cuda(), make_samples(boxes, labels, metas)
+
+    small, large = batch(96, 128, 0), batch(250, 330, 1)
+    order = [small, large, small, large, small]
+
+    def run(step_graph):
+        model = build_erd(tsd, ssd)
+        tr = ERDTrainer(model, lr=0.0, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0, step_graph=step_graph)
+        logs = []
+        canaries = []
+        for b in order:
+            lv = tr.train_step(*b)
+            logs.append({k: float(v) for k, v in lv.items()})
+            torch.cuda.synchronize()
+            if step_graph:       # grab whatever the allocator has free right now (a freed workspace would be first in line)
+                canaries.append(torch.zeros(1 << 20, device="cuda"))
+        tr.flush()
+        torch.cuda.synchronize()
+        return logs, tr, canaries
+
+    eager, _, _ = run(False)
+    retired_before = len(K._WS_RETIRED)
+    graph, tr, canaries = run(True)
+    assert len(tr._step_graphs) == 2
+    assert len(K._WS_RETIRED) > retired_before, "the larger shape must have outgrown at least one workspace"
+    for c in canaries:
+        assert float(c.abs().max()) == 0.0, "a replayed graph wrote into memory that was handed out again"
+    for i, (a, b) in enumerate(zip(eager, graph)):      # lr = 0: every visit of a shape sees the same weights
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=2e-5, abs=1e-6), (i, k, a[k], b[k])

@@ -181,6 +181,9 @@ def test_resnet_init_cfg_pretrained_is_honoured(tmp_path, monkeypatch):
     hub = tmp_path / "ckpts"
     hub.mkdir()
     torch.save(sd, hub / "resnet50-0676ba61.pth")
+    # decoys that sort BEFORE the canonical file: 'torchvision://resnet50' is one fixed file in the reference
+    # (mmengine's torchvision-0.12 URL table), not "whatever resnet50*.pth comes first"
+    torch.save({k: torch.zeros_like(v) for k, v in sd.items()}, hub / "resnet50-0000decoy.pth")
     cfg = dict(type="ResNet", depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
                norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True, style="pytorch",
                init_cfg=dict(type="Pretrained", checkpoint="torchvision://resnet50"))
@@ -203,6 +206,16 @@ def test_resnet_init_cfg_pretrained_is_honoured(tmp_path, monkeypatch):
         warnings.simplefilter("always")
         MODELS.build(cfg).init_weights()
     assert any("RANDOM" in str(x.message) for x in w)
+    # without the canonical file a name glob still resolves -- with a warning naming what was picked
+    monkeypatch.delenv("ERD_ALLOW_RANDOM_BACKBONE")
+    only = tmp_path / "only"
+    only.mkdir()
+    torch.save(sd, only / "resnet50_custom.pth")
+    monkeypatch.setenv("ERD_PRETRAINED_DIR", str(only))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        MODELS.build(cfg).init_weights()
+    assert any("resnet50_custom.pth" in str(x.message) for x in w)
     # a checkpoint of the wrong depth is rejected
     monkeypatch.setenv("ERD_PRETRAINED_DIR", str(hub))
     with pytest.raises(RuntimeError):
