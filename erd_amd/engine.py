@@ -163,19 +163,25 @@ class BucketedGradSync:
 
 
 class TeacherGraphs:
-    """hipGraph capture of the frozen teacher's half of the step (forward + ERS + NMS of the selected boxes): the
-    teacher never changes, so its ~150 launches per batch are recorded once per input shape and replayed as one graph
-    launch (BASELINE.json configs[4]: mixed-resolution batches -> one graph per padded shape, built on first use).
-    Outputs live in the graph's static buffers and are overwritten by the next replay of the same shape; the trainer
-    orders that behind the previous step's backward (side.wait_stream(main))."""
+    """hipGraph capture of the frozen teacher's half of the step (shared frozen trunk, forward, ERS, NMS of the selected
+    boxes): the teacher never changes, so its ~150 launches per batch are recorded once per input shape and replayed as one
+    graph launch (BASELINE.json configs[4]: mixed-resolution batches -> one graph per padded shape, built on first use).
+    Outputs live in the graph's static buffers and are overwritten by the next replay of the SAME graph.  Each shape
+    therefore has TWO graphs (`slot` = parity of the step): step t's backward pass still reads slot t % 2 (teacher logits,
+    ERS lists, the trunk map the student's first trainable block saved) while the look-ahead replay for step t+1 fills the
+    other one; slot t % 2 is replayed again for step t+2, which the trainer orders behind step t+1's losses and thus
+    behind everything of step t.
+    The shared frozen trunk (GFLIncrementERD.shares_trunk) is part of the capture: the student reads it from the static
+    buffer, ordered by an event recorded after the replay (an event cannot be recorded for another stream inside a
+    capture)."""
 
-    def __init__(self, model: GFLIncrementERD, max_graphs: int = 16):
+    def __init__(self, model: GFLIncrementERD, max_graphs: int = 32):
         self.model, self.max_graphs = model, max_graphs
         self.graphs: Dict[tuple, tuple] = {}
 
-    def run(self, inputs: Tensor):
+    def run(self, inputs: Tensor, slot: int = 0):
         """call with the stream the teacher should run on as the current stream"""
-        key = (tuple(inputs.shape), inputs.device.index)
+        key = (tuple(inputs.shape), inputs.device.index, K.COMPUTE, slot & 1)
         ent = self.graphs.get(key)
         if ent is None:
             if len(self.graphs) >= self.max_graphs:
@@ -184,18 +190,19 @@ class TeacherGraphs:
             K.pin_workspaces()               # graphs hold workspace addresses: outgrown buffers are retired, not freed
             static_in = inputs.clone()
             with torch.no_grad():
-                self.model.teacher_pass(static_in, share_trunk=False)      # eager warm-up: workspaces, anchor / folded-BN caches
-                # (share_trunk=False: the captured teacher computes its own frozen trunk -- a hand-over event to the student's
-                #  stream cannot be recorded inside a graph)
+                self.model.teacher_pass(static_in, share_trunk="static")      # eager warm-up: workspaces, anchor / folded-BN caches
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream), torch.no_grad():
-                out = self.model.teacher_pass(static_in, share_trunk=False)
+                out = self.model.teacher_pass(static_in, share_trunk="static")
             ent = self.graphs[key] = (graph, static_in, out)
         graph, static_in, out = ent
         static_in.copy_(inputs, non_blocking=True)
         graph.replay()
         out.targets = None
+        if out.trunk is not None:            # the hand-over event of the shared trunk: after the replay, on the replaying stream
+            out.trunk_event = torch.cuda.Event()
+            out.trunk_event.record()
         return out
 
 
@@ -403,6 +410,15 @@ class ERDTrainer:
             st.gl[:off[-1]].copy_(torch.cat([g.labels.reshape(-1).long() for g in gts], 0).to(dev, non_blocking=True))
         st.goff.copy_(torch.from_numpy(off), non_blocking=True)
 
+    def _teacher(self, inputs: Tensor, data_samples, it: int):
+        """the frozen teacher's half of step `it` on the current (side) stream: eager launches, or one graph replay"""
+        if self.teacher_graphs is None:
+            return self.model.teacher_pass(inputs, data_samples)
+        out = self.teacher_graphs.run(inputs, slot=it)
+        gts, _, metas = unpack_gt_instances(data_samples)         # targets depend on the GT: eager
+        out.targets = self.model.bbox_head._targets(out.sizes, gts, metas, self.device)
+        return out
+
     def train_step(self, inputs: Tensor, data_samples, next_batch=None) -> Dict[str, Tensor]:
         """`next_batch` = (inputs, data_samples) of the FOLLOWING step when the loader has it (a prefetching loader does):
         the frozen teacher's half of that step is then queued on the side stream behind this step's losses, so it runs
@@ -429,12 +445,7 @@ class ERDTrainer:
             else:
                 self.side.wait_stream(cur)
                 with torch.cuda.stream(self.side), torch.no_grad():
-                    if self.teacher_graphs is not None:
-                        teacher_out = self.teacher_graphs.run(inputs)
-                        gts, _, metas = unpack_gt_instances(data_samples)         # targets depend on the GT: eager
-                        teacher_out.targets = model.bbox_head._targets(teacher_out.sizes, gts, metas, self.device)
-                    else:
-                        teacher_out = model.teacher_pass(inputs, data_samples)
+                    teacher_out = self._teacher(inputs, data_samples, self.iter)
             self._apply_pending()
             self.flat.zero_grad()
             K.zero_arena_begin(self.device)
@@ -455,7 +466,7 @@ class ERDTrainer:
             K.zero_arena_begin(self.device)
             losses = model(inputs, data_samples, mode="loss")
         total, log_vars = parse_losses(losses)
-        if next_batch is not None and self.overlap_teacher and self.teacher_graphs is None:
+        if next_batch is not None and self.overlap_teacher:
             # the teacher of the following step: behind everything the side stream holds for this one, next to this backward.
             # `cur` holds whatever PRODUCED next_batch (Runner.train prepares batch t+1 on the current stream before it calls
             # train_step(t): preprocess / resize kernels, H2D copies) plus this step's forward and losses, but not yet its
@@ -463,7 +474,7 @@ class ERDTrainer:
             # half-written pixels as soon as the host runs ahead), and still runs next to backward(t).
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side), torch.no_grad():
-                self._teacher_ahead = (next_batch[0], model.teacher_pass(next_batch[0], next_batch[1]))
+                self._teacher_ahead = (next_batch[0], self._teacher(next_batch[0], next_batch[1], self.iter + 1))
         if self.sync is not None:
             self.sync.arm()
         total.backward()

@@ -816,11 +816,12 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     ent = cache.get(key)
     if ent is None:
         ent = cache[key] = _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff)
-    d, S, flop, nbytes, tag, Cout, Cin = ent
+    d, S, flop, nbytes, tag, Cout, Cin, row3 = ent
     d.x, d.dz = xb, zb
     part = ws_float("wgrad_part", S * Cout * k * k * Cin, xs[0].device)
     d.part = part.data_ptr()
-    _timed_call("conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
+    # (timing classes follow the kernel SYMBOL: the three-tap kernel of the 3x3 / stride-1 layers vs the generic one)
+    _timed_call("conv_wgrad_row3" if row3 else "conv_wgrad", flop, "erd_conv_wgrad", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
                 tag=tag if TIMING_DETAIL else "")
     return part, S
 
@@ -863,7 +864,7 @@ def _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff):
     d.nsplit = S
     flop = 2.0 * npix * Cout * Cin * k * k
     nbytes = 4.0 * (sum(t.numel() for t in xs) + sum(t.numel() for t in dzs) + S * Cout * k * k * Cin)
-    return d, S, flop, nbytes, f"px{npix} {Cin}->{Cout} k{k}s{stride} S{S}", Cout, Cin
+    return d, S, flop, nbytes, f"px{npix} {Cin}->{Cout} k{k}s{stride} S{S}", Cout, Cin, bool(row3)
 
 
 def wgrad_reduce(part: Tensor, S: int, w: Tensor, rowscale: Optional[Tensor], dW: Tensor, accumulate: bool,

@@ -1123,7 +1123,9 @@ class GFLIncrementERD(GFL):
             # updates them): computed ONCE, on the kernels the student's trunk uses, and fed to both networks
             with K.distillation_forward(K.WINO_FROZEN_TRUNK):
                 trunk = self.backbone.trunk(batch_inputs)
-            if share_trunk:      # (share_trunk=False: same arithmetic, but the map is not handed on -- hipGraph capture)
+            # share_trunk=False: same arithmetic, but the map is not handed on.  "static": handed on without an event --
+            # a hipGraph capture (engine.TeacherGraphs records the hand-over event after each replay)
+            if share_trunk is True:
                 trunk_event = torch.cuda.Event()
                 trunk_event.record()
         with K.distillation_forward(K.WINO_TEACHER):

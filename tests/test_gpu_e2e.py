@@ -261,6 +261,41 @@ def test_teacher_hipgraph_replay_equals_eager_on_mixed_resolutions():
     assert np.allclose(logs[True], logs[False], rtol=1e-5), logs
 
 
+def test_teacher_hipgraph_with_look_ahead_and_shared_trunk():
+    """The graph teacher under the benched schedule: the replay for step t+1 is queued next to the backward pass of step t,
+    which still reads step t's teacher outputs and the shared trunk map out of the graph's static buffers -- two graphs per
+    shape (buffer parity) keep them apart.  Same-shape and alternating-shape sequences log the eager trainer's losses, and
+    the student reads the trunk the graph computed (no second trunk launch set)."""
+    from erd_amd.engine import ERDTrainer
+    tsd, ssd = f7_state_dicts()
+
+    def batch(h, w, seed):
+        imgs, boxes, labels = O.synthetic_batch(2, h, w, 40, seed=seed)
+        x, metas = O.preprocess(imgs)
+        return x.cuda(), make_samples(boxes, labels, metas)
+
+    for name, seq in (("same shape", [batch(123, 153, s) for s in range(4)]),
+                      ("alternating", [batch(123, 153, 0), batch(90, 220, 1), batch(123, 153, 2), batch(90, 220, 3), batch(123, 153, 4)])):
+        logs = {}
+        for use_graph in (False, True):
+            m = build_erd(tsd, ssd)
+            tr = ERDTrainer(m, lr=0.01, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=0, teacher_graph=use_graph)
+            out = []
+            for i, b in enumerate(seq):
+                nxt = seq[i + 1] if i + 1 < len(seq) else None
+                out.append(float(tr.train_step(*b, next_batch=nxt)["loss"].detach()))
+                if use_graph and nxt is not None:
+                    assert tr._teacher_ahead is not None and tr._teacher_ahead[1].trunk is not None      # queued ahead, trunk shared
+            tr.flush()
+            torch.cuda.synchronize()
+            logs[use_graph] = out
+            if use_graph:
+                shapes = {k[0] for k in tr.teacher_graphs.graphs}
+                assert len(tr.teacher_graphs.graphs) == 2 * len(shapes), tr.teacher_graphs.graphs.keys()
+        assert np.allclose(logs[True], logs[False], rtol=2e-4), (name, logs)
+        assert logs[True][0] == pytest.approx(logs[False][0], rel=5e-6), (name, logs)      # step 0: identical weights
+
+
 def test_bf16_matrix_core_mode_vs_oracle_bf16_multiplicands():
     """BASELINE.json configs[2]: every 1x1/3x3 convolution on the bf16 matrix cores (multiplicands rounded to bf16,
     exact products, fp32 accumulation / normalisation / losses / storage), against the oracle in its bf16-multiplicand
