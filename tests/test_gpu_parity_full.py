@@ -89,31 +89,34 @@ def test_benched_batch_of_four_losses_and_ers_vs_oracle(nets):
         assert torch.equal(t.ers["idx_bbox"][i, :int(cnt[i, 1])].cpu(), aux["ers_bbox"][i]), i
 
 
+SEEDS_FP64 = (7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)
+
+
 def test_full_size_gradients_anchored_to_fp64(nets):
-    """Four full-size steps (seeds 7-10), each evaluated three times: the oracle in fp64 (the truth), the oracle in fp32 (the
-    reference's own arithmetic) and the HIP path.  Measured (profiles/r02 notes), relative L2 distance to fp64 as
-    median over the 175 gradient tensors / all elements / worst tensor:
+    """Twelve full-size steps (seeds 7-18), each evaluated three times: the oracle in fp64 (the truth), the oracle in fp32 (the
+    reference's own arithmetic) and the HIP path.  Relative L2 distance to fp64 as median over the 175 gradient tensors /
+    all elements (= the whole gradient) / worst tensor, measured in round 2:
         seed   cpu fp32                      hip
           7    4.7e-4  4.1e-4  2.5e-3        6.8e-4  4.2e-4  2.3e-3
           8    3.4e-3  1.8e-3  4.8e-3        5.7e-4  5.9e-4  2.3e-3
           9    4.9e-4  5.1e-4  3.1e-3        1.1e-3  7.8e-4  3.2e-3
          10    8.7e-4  5.4e-4  1.7e-3        9.0e-4  5.9e-4  1.8e-3
-    (The worst-tensor column read 3.5e-3 / 6.3e-3 / 1.1e-2 on seeds 8-10 until the Winograd cover stopped storing some
-    tiles twice: the fused column sums of an input-gradient launch -- a BN bias gradient -- counted those pixels double.
-    This test's bound D was loose enough to pass with the bug; test_winograd_cover_stores_every_pixel_exactly_once is the
-    direct check, and D is now the measured 1.25x.)
+      11-18    whole gradient 7.0 3.2 3.8 5.9 0.6 3.4 5.9 3.9 e-4 | 8.9 3.9 5.0 6.6 1.0 4.2 3.7 5.3 e-4
     A ReLU whose pre-activation is ~1e-7 takes one side in one fp32 summation order and the other side in another; ONE such
     flip moves every gradient tensor upstream by ~1e-3 and a small-norm one (a BN bias gradient: a sum over a map with heavy
-    cancellation) by up to 1e-2.  Which implementation owns the flip changes with the seed: the fp32 CPU reference on seed 8,
-    this one on seed 9.  A per-seed bound "hip <= 1.25 x cpu" is therefore false for EITHER implementation on some seed; what
-    holds, and is asserted:
-      A. every seed: losses within 1e-3 of the fp32 reference and of fp64; the WHOLE gradient within 1e-3 of fp64;
-      B. every seed: median per-tensor distance <= 1.5e-3, and <= max(1e-3, 1.25 x the reference's) on at least 3 of 4 seeds;
-      C. over the seeds: this implementation's worst median / worst whole-gradient distance is not above the reference's worst;
-      D. worst single tensor: <= 5e-3 on every seed and within 1.25x of the reference's worst tensor of the same seed."""
+    cancellation) by up to 1e-2.  Which implementation owns the flip changes with the seed (the fp32 CPU reference on seed 8,
+    this one on seed 9), so per-seed comparisons between the two say nothing; the statements are over ALL twelve seeds:
+      A. every seed: losses within 1e-3 of the fp32 reference and of fp64; the WHOLE gradient within 1e-3 of fp64
+         (north_star's bar, against the exact gradients);
+      B. means over the seeds: this implementation's whole-gradient distance, per-tensor median and worst tensor are each at
+         most 1.25 x the reference's own (it is as close to the truth as the reference's arithmetic is);
+      C. worst single tensor <= 5e-3 on every seed (a systematic error in one layer -- the Winograd double store of round 2
+         read 1.1e-2 here -- shows up in this column first)."""
     from erd_amd import parse_losses
     tsd, ssd, _ = nets
     names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))        # (oneDNN oversubscribes on a 128-core host: bench.py's thread sweep)
 
     def dist(ga, gb):
         errs, num, den = [], 0.0, 0.0
@@ -125,35 +128,128 @@ def test_full_size_gradients_anchored_to_fp64(nets):
         return float(np.median(errs)), (num / den) ** 0.5, max(errs)
 
     cpu_rows, hip_rows = [], []
-    for seed in (7, 8, 9, 10):
-        imgs, boxes, labels = O.synthetic_batch(1, 800, 1333, 40, seed=seed)
-        x, metas = O.preprocess(imgs)
+    try:
+        for seed in SEEDS_FP64:
+            imgs, boxes, labels = O.synthetic_batch(1, 800, 1333, 40, seed=seed)
+            x, metas = O.preprocess(imgs)
 
-        def oracle(dtype):
-            t = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in tsd.items()}
-            sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in ssd.items()}
-            sd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
-            losses = O.erd_step_loss(t, sd, x.to(dtype), boxes, labels, metas, 40, 80)
-            O.parse_losses(losses).backward()
-            return {k: sd[k].grad.double() for k in names}, {k: [float(v) for v in vs] for k, vs in losses.items()}
+            def oracle(dtype):
+                t = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in tsd.items()}
+                sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in ssd.items()}
+                sd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+                losses = O.erd_step_loss(t, sd, x.to(dtype), boxes, labels, metas, 40, 80)
+                O.parse_losses(losses).backward()
+                return {k: sd[k].grad.double() for k in names}, {k: [float(v) for v in vs] for k, vs in losses.items()}
 
-        g64, l64 = oracle(torch.float64)
-        g32, l32 = oracle(torch.float32)
-        model = build_erd(tsd, ssd)
-        losses = model(x.cuda(), make_samples(boxes, labels, metas), mode="loss")
-        parse_losses(losses)[0].backward()
-        p = dict(model.named_parameters())
-        gh = {k: p[k].grad.detach().cpu().double() for k in names}
-        for k, vs in l32.items():
-            got = [float(v.detach()) for v in losses[k]]
-            assert np.allclose(got, vs, rtol=1e-3, atol=1e-7) and np.allclose(got, l64[k], rtol=1e-3, atol=1e-7), (seed, k, got, vs)
-        cpu, hip = dist(g32, g64), dist(gh, g64)
-        cpu_rows.append(cpu); hip_rows.append(hip)
-        print("seed %d, %d gradient tensors, rel L2 to fp64 (median / all elements / worst tensor): cpu fp32 %.2e %.2e %.2e | hip %.2e %.2e %.2e"
-              % ((seed, len(names)) + cpu + hip))
-        del model
+            g64, l64 = oracle(torch.float64)
+            g32, l32 = oracle(torch.float32)
+            model = build_erd(tsd, ssd)
+            losses = model(x.cuda(), make_samples(boxes, labels, metas), mode="loss")
+            parse_losses(losses)[0].backward()
+            p = dict(model.named_parameters())
+            gh = {k: p[k].grad.detach().cpu().double() for k in names}
+            for k, vs in l32.items():
+                got = [float(v.detach()) for v in losses[k]]
+                assert np.allclose(got, vs, rtol=1e-3, atol=1e-7) and np.allclose(got, l64[k], rtol=1e-3, atol=1e-7), (seed, k, got, vs)
+            cpu, hip = dist(g32, g64), dist(gh, g64)
+            cpu_rows.append(cpu); hip_rows.append(hip)
+            print("seed %d, %d gradient tensors, rel L2 to fp64 (median / all elements / worst tensor): cpu fp32 %.2e %.2e %.2e | hip %.2e %.2e %.2e"
+                  % ((seed, len(names)) + cpu + hip))
+            del model
+    finally:
+        torch.set_num_threads(threads)
     cpu, hip = np.array(cpu_rows), np.array(hip_rows)
+    print("means over %d seeds (median / whole gradient / worst tensor): cpu fp32 %.2e %.2e %.2e | hip %.2e %.2e %.2e"
+          % ((len(SEEDS_FP64),) + tuple(cpu.mean(0)) + tuple(hip.mean(0))))
     assert (hip[:, 1] <= 1e-3).all(), hip[:, 1]                                                     # A
-    assert (hip[:, 0] <= 1.5e-3).all() and int((hip[:, 0] <= np.maximum(1e-3, 1.25 * cpu[:, 0])).sum()) >= 3, (hip[:, 0], cpu[:, 0])   # B
-    assert hip[:, 0].max() <= cpu[:, 0].max() and hip[:, 1].max() <= cpu[:, 1].max(), (hip, cpu)   # C
-    assert (hip[:, 2] <= 5e-3).all() and (hip[:, 2] <= 1.25 * cpu[:, 2]).all(), (hip[:, 2], cpu[:, 2])   # D
+    assert (hip.mean(0) <= 1.25 * cpu.mean(0)).all(), (hip.mean(0), cpu.mean(0))                    # B
+    assert (hip[:, 2] <= 5e-3).all(), hip[:, 2]                                                     # C
+
+
+def test_benched_trainer_configuration_follows_the_oracle_trajectory_at_full_size(nets, monkeypatch):
+    """The configuration bench.py times -- ERDTrainer with every default on (teacher look-ahead on the side stream, trailing
+    weight-gradient stream, per-step parameter preparation, batched BN fold, shared frozen trunk, cls || reg towers) at
+    BASELINE's batch (4 images of 800x1344) -- against the oracle as a WHOLE: three optimisation steps on two alternating
+    batches (gfl_increment_erd.py:202-220 + the optimizer wrapper's SGD).
+      * per-step losses, every entry, within 1e-3 of the oracle's trajectory (the oracle applies its own SGD between steps);
+      * parameter displacement after the third update against the oracle's (relative L2 over all trainable tensors);
+      * the first step is bit-identical from run to run (deterministic forward reductions);
+      * the same trajectory with the shared trunk off / without the look-ahead / with both off, to float-atomic-order noise:
+        the overlap machinery changes WHEN kernels run, never what they compute.
+    (The trainer-level tests in test_gpu_e2e.py run at 123x153, where the five streams barely overlap; the Winograd double
+    store of round 2 only showed at full size.)"""
+    from erd_amd.engine import ERDTrainer
+    tsd, ssd, _ = nets
+    names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
+    batches = []
+    for s in (31, 32):
+        imgs, boxes, labels = O.synthetic_batch(4, 800, 1333, 40, seed=s)
+        x, metas = O.preprocess(imgs)
+        batches.append((x, boxes, labels, metas))
+    LR, MOM, WD, STEPS = 0.02, 0.9, 1e-4, 3
+
+    def hip_run(ahead: bool, share: bool):
+        if share:
+            monkeypatch.delenv("ERD_SHARE_TRUNK", raising=False)
+        else:
+            monkeypatch.setenv("ERD_SHARE_TRUNK", "0")
+        model = build_erd(tsd, ssd)
+        assert model.shares_trunk() == share
+        tr = ERDTrainer(model, lr=LR, momentum=MOM, weight_decay=WD, batch_size_per_gpu=4, auto_scale_lr=False,
+                        warmup_iters=3, warmup_start_factor=0.5)
+        assert tr.prep is not None and tr.prefold is not None and tr.overlap_teacher      # the defaults ARE on
+        gpu = [(x.cuda(), make_samples(b, l, m)) for x, b, l, m in batches]
+        logs = []
+        for it in range(STEPS):
+            nxt = gpu[(it + 1) % 2] if ahead else None
+            lv = tr.train_step(*gpu[it % 2], next_batch=nxt)
+            if ahead:
+                assert tr._teacher_ahead is not None
+            logs.append({k: float(v) for k, v in lv.items()})
+        tr.flush()
+        torch.cuda.synchronize()
+        if ahead:
+            assert len(tr.prep.recipes) > 50                                                # prepared buffers were in use
+        p = dict(model.named_parameters())
+        return logs, {k: p[k].detach().cpu() for k in names}, [tr.lr_at(i) for i in range(STEPS)]
+
+    logs, params, lrs = hip_run(True, True)
+    # ---- the oracle's trajectory
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+    try:
+        sd = {k: v.clone() for k, v in ssd.items()}
+        bufs, ref = {}, []
+        for it in range(STEPS):
+            x, boxes, labels, metas = batches[it % 2]
+            leaf = {k: (sd[k].clone().requires_grad_(True) if k in names else sd[k]) for k in sd}
+            losses = O.erd_step_loss(tsd, leaf, x, boxes, labels, metas, 40, 80)
+            total = O.parse_losses(losses)
+            total.backward()
+            row = {k: float(sum(v.detach().mean() for v in vs)) for k, vs in losses.items()}
+            row["loss"] = float(total)
+            ref.append(row)
+            O.sgd_momentum_step({k: sd[k] for k in names}, {k: leaf[k].grad for k in names}, bufs, lrs[it], MOM, WD)
+            del leaf, losses, total
+    finally:
+        torch.set_num_threads(threads)
+    for it, (g, r) in enumerate(zip(logs, ref)):
+        for k, v in r.items():
+            assert g[k] == pytest.approx(v, rel=1e-3, abs=1e-7), (it, k, g[k], v)
+    num = sum(float((params[k].double() - ssd[k].double() - (sd[k].double() - ssd[k].double())).pow(2).sum()) for k in names)
+    den = sum(float((sd[k].double() - ssd[k].double()).pow(2).sum()) for k in names)
+    disp = (num / den) ** 0.5
+    print("benched configuration, 3 steps at 4 x 800x1344: losses %s vs oracle %s; displacement rel L2 error %.2e"
+          % ([round(l["loss"], 6) for l in logs], [round(r["loss"], 6) for r in ref], disp))
+    assert disp < 1e-2, disp
+    # ---- run to run, and the overlap machinery switched off piece by piece
+    again, _, _ = hip_run(True, True)
+    assert again[0] == logs[0]                                                             # bit-identical first step
+    for ahead, share in ((False, True), (True, False), (False, False)):
+        other, oparams, _ = hip_run(ahead, share)
+        for it, (a, b) in enumerate(zip(logs, other)):
+            for k in a:      # (without the shared trunk the teacher's trunk runs on the Winograd kernels: 1e-6-level logit changes)
+                assert b[k] == pytest.approx(a[k], rel=(5e-6 if share else 1e-4) if it == 0 else 5e-4, abs=1e-6), (ahead, share, it, k, a[k], b[k])
+        n2 = sum(float((oparams[k].double() - params[k].double()).pow(2).sum()) for k in names)
+        d2 = sum(float((params[k].double() - ssd[k].double()).pow(2).sum()) for k in names)
+        assert (n2 / d2) ** 0.5 < 5e-3, (ahead, share, (n2 / d2) ** 0.5)
