@@ -259,7 +259,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--teacher-graph", action="store_true",
                     help="replay the frozen teacher's pass from a hipGraph (BASELINE configs[4]); same arithmetic")
-    ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--compute", choices=["f32", "f32x3", "bf16"], default="f32",
                     help="f32: fp32 matrix cores, fp32 maps (BASELINE configs[1], the headline).  bf16: BASELINE configs[2] -- the 1x1 / 3x3 "
                          "convolutions on the bf16 matrix cores with fp32 accumulation, feature maps and their gradients STORED as "
                          "bf16; head outputs, statistics, losses, parameters and parameter gradients stay fp32")
@@ -421,7 +421,7 @@ def main():
         # `roofline.step_frac` keeps counting the ALGORITHMIC work of the reference's step (both copies)
         out["shared_frozen_trunk"] = {"enabled": shared, "skipped_gflop_per_image": TRUNK_GFLOP_PER_IMAGE if shared else 0.0}
         if ktime:
-            peak_tf = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else BF16_MFMA_PEAK_TFLOPS   # every GEMM class follows --compute
+            peak_tf = BF16_MFMA_PEAK_TFLOPS if args.compute == "bf16" else FP32_MFMA_PEAK_TFLOPS   # every GEMM class follows --compute
             # ---- the dominant KERNEL SYMBOL (rocprof's unit: the Winograd kernel's forward and input-gradient launches are
             # one symbol) and its roofline on the flops it EXECUTES
             groups = {}

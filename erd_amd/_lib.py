@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32), ("colsum", C.c_void_p),
                 ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("w_bf16", C.c_void_p), ("colsum_copies", i32),
-                ("in_bf16", i32), ("out_bf16", i32)]
+                ("in_bf16", i32), ("out_bf16", i32), ("w_x3", C.c_void_p)]
 
 
 class WgradSeg(C.Structure):
@@ -73,6 +73,8 @@ _SIGNATURES = {
     "erd_conv_igemm": [C.POINTER(ConvDesc), P],
     "erd_conv_igemm_ws_bytes": [i32],
     "erd_to_bf16": [P, P, i64, P],
+    "erd_split3": [P, P, i64, P],
+    "erd_weight_transpose_x3": [P, P, P, i32, i32, i32, i32, P],
     "erd_wino_weights_elems": [i32, i32],
     "erd_wino_weights": [P, P, i32, i32, i32, P],
     "erd_wino_conv3x3": [P, i32, P, i32, i32, P, P, i32, P, i32, P, P],
@@ -155,7 +157,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t if name.endswith(("_ws_bytes", "_elems")) else C.c_int
-    if lib.erd_abi_version() != 2:
+    if lib.erd_abi_version() != 3:
         raise ErdHipError("liberd_hip.so ABI version mismatch")
     _lib = lib
     return lib

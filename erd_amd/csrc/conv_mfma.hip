@@ -80,6 +80,7 @@ struct SkWs {
     int* cnt;        // [tiles] arrival tickets (zeroed before the launch)
     float* slabs;    // [2*G][BM*BN]
     int xcd_order;   // 1: XCD-aware work order (default); 0: dispatch order (A/B aid, ERD_XCD=0)
+    int whole_tiles; // 1: persistent grid over WHOLE tiles (workgroup b owns tiles [b T / G, (b+1) T / G): no partial tiles, no fix-up)
 };
 
 int xcd_order_enabled() {
@@ -94,8 +95,17 @@ int xcd_order_enabled() {
 // AB / OB (bf16 mode only): the input maps / the output, residual and mask maps are STORED as bf16 (erd_conv_desc::
 // in_bf16 / out_bf16): a 16-B load then carries a whole 8-value LDS chunk and needs no conversion, and the epilogue
 // moves 8-B groups of four channels.  Accumulation, scale/shift, the stream-K slabs and the column sums stay fp32.
+// X3 = true ("f32x3", erd_conv_desc::w_x3): fp32 maps, fp32 accumulation, fp32 results -- but the PRODUCTS run on the bf16 matrix
+// cores, which on gfx950 are 16x faster than the fp32 ones (v_mfma_f32_32x32x2_f32 runs at the vector rate).  Every fp32
+// value is the exact sum of three bf16 limbs (8 + 8 + 8 significand bits: hi = truncate(x), mid = truncate(x - hi),
+// lo = x - hi - mid); a product a*b is then the sum of nine exact limb products, of which the six with weight >= 2^-16 are
+// accumulated (a_hi b_hi, a_hi b_mid, a_mid b_hi, a_hi b_lo, a_mid b_mid, a_lo b_hi: what is dropped is below 2^-23 of
+// |a*b|, the size of fp32's own rounding of that product).  Weights arrive pre-split (three bf16 planes); activations stay
+// fp32 in HBM and in LDS and are split in registers when a wave reads its fragments.  The waves form a 4 x 1 grid (each
+// owns 32 pixel rows x all BN couts) so that every activation value is split by exactly one wave: 44 VALU operations per 24
+// MFMAs.  One K-slice = 32 channels = two k16 steps.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false,
-          bool OB = false>
+          bool OB = false, bool X3 = false>
 __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
                                                                      const SkWs ws) {
     constexpr int FM = BM / (WAVES_M * 32);
@@ -109,16 +119,28 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     constexpr bool SGB = ERD_SGB;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     static_assert(BF || (!AB && !OB), "bf16 storage only with the bf16 matrix cores");
+    static_assert(!X3 || (!BF && BKT == 32 && WAVES_N == 1 && FM == 1), "f32x3: fp32 maps, 32-channel slices, 4 x 1 waves");
     constexpr unsigned ABYTES = AB ? 2u : 4u;   // bytes per stored input value
+    constexpr int CHB = X3 ? 4 : CH;            // 16-B chunks per K-slice row of ONE weight plane (f32x3: 8 bf16 per chunk)
+    constexpr int NPL = X3 ? 3 : 1;             // weight planes in LDS
+    constexpr int RPPB = NTHREADS / CHB;        // weight rows staged per pass
+    constexpr int BJX = BN / RPPB;              // 16-B loads per thread and plane for B (f32x3)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*CH]
-    float4* Bs = As + 2 * BM * CH;                                 // [2][BN*CH]
-    constexpr int OPER_BYTES = 2 * (BM + BN) * CH * 16;
+    float4* Bs = As + 2 * BM * CH;                                 // [2][BN*CH]   (f32x3: [2][3 planes][BN*4])
+    constexpr int OPER_BYTES = 2 * (BM * CH + NPL * BN * CHB) * 16;
     constexpr int STAGE_BYTES = 64 * (BN + 4) * 4 + NTHREADS * 16;  // epilogue staging (+ column-sum scratch) re-uses the operand region
     constexpr int REGION = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
-    RowInfo* rows = reinterpret_cast<RowInfo*>(smem + REGION);     // [BM]
-    int* bcast = reinterpret_cast<int*>(rows + BM);                // [4]
+    // f32x3: the operand region is 80 KB at 128 x 128 -- exactly half of the CU's LDS, two workgroups per CU only if nothing
+    // else is allocated.  The row table therefore lives INSIDE the region: at its start while a tile is set up (before the
+    // first operand slice is stored) and behind the epilogue's staging area once the K loop is over (recomputed: 128 threads,
+    // two divisions each); the broadcast word of the stream-K fix-up sits next to it.
+    constexpr int ROWS_EPI_OFF = X3 ? ((STAGE_BYTES + 255) / 256 * 256) : REGION;
+    static_assert(!X3 || ROWS_EPI_OFF + BM * (int)sizeof(RowInfo) + 16 <= OPER_BYTES, "f32x3: row table does not fit behind the staging area");
+    RowInfo* rows = reinterpret_cast<RowInfo*>(smem + (X3 ? 0 : REGION));     // [BM]
+    RowInfo* rows_epi = reinterpret_cast<RowInfo*>(smem + ROWS_EPI_OFF);
+    int* bcast = reinterpret_cast<int*>(reinterpret_cast<RowInfo*>(smem + ROWS_EPI_OFF) + BM);                // [4]
 
     const int tid = threadIdx.x;
     const int ntn = (p.Cout + BN - 1) / BN;
@@ -137,7 +159,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long u_begin = (U * wg) / G, u_end = (U * (wg + 1)) / G;
+    const long long u_begin = ws.whole_tiles ? ((long long)total_tiles * wg / G) * nkt : (U * wg) / G;
+    const long long u_end = ws.whole_tiles ? ((long long)total_tiles * (wg + 1) / G) * nkt : (U * (wg + 1)) / G;
 
     const int chunk = tid % CH;
     const int r0 = tid / CH;
@@ -181,29 +204,32 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         }
 
         __syncthreads();   // previous tile's epilogue / fragment reads are done with LDS
-        if (tid < BM) {
-            const int GHW = sg.GH * sg.GW;
-            const int M = sg.N * GHW;
-            const int m = mt * BM + tid;
-            RowInfo ri;
-            if (m < M) {
-                const int n = m / GHW;
-                const int rem = m - n * GHW;
-                const int a = rem / sg.GW;
-                const int b = rem - a * sg.GW;
-                ri.in_off = (int)(n * sg.in_nstride);
-                ri.ih0 = a * p.in_stride;
-                ri.iw0 = b * p.in_stride;
-                ri.out_off = (int)(n * sg.out_nstride) +
-                             ((a * p.out_stride + oy_s) * sg.OW + (b * p.out_stride + ox_s)) * p.Cout;
-            } else {
-                ri.in_off = 0;
-                ri.ih0 = -(1 << 28);
-                ri.iw0 = -(1 << 28);
-                ri.out_off = -1;
+        auto fill_rows = [&](RowInfo* dst) {
+            if (tid < BM) {
+                const int GHW = sg.GH * sg.GW;
+                const int M = sg.N * GHW;
+                const int m = mt * BM + tid;
+                RowInfo ri;
+                if (m < M) {
+                    const int n = m / GHW;
+                    const int rem = m - n * GHW;
+                    const int a = rem / sg.GW;
+                    const int b = rem - a * sg.GW;
+                    ri.in_off = (int)(n * sg.in_nstride);
+                    ri.ih0 = a * p.in_stride;
+                    ri.iw0 = b * p.in_stride;
+                    ri.out_off = (int)(n * sg.out_nstride) +
+                                 ((a * p.out_stride + oy_s) * sg.OW + (b * p.out_stride + ox_s)) * p.Cout;
+                } else {
+                    ri.in_off = 0;
+                    ri.ih0 = -(1 << 28);
+                    ri.iw0 = -(1 << 28);
+                    ri.out_off = -1;
+                }
+                dst[tid] = ri;
             }
-            rows[tid] = ri;
-        }
+        };
+        fill_rows(rows);
         __syncthreads();
 
         // per-row byte offset of tap (0,0) and a validity bit per tap: the K loop then needs one add + one select
@@ -221,25 +247,39 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             a_mask[j] = m;
         }
         const int n0 = nt * BN;
-        unsigned b_base[BJ];
+        unsigned b_base[X3 ? 1 : BJ];
+        unsigned bx_base[X3 ? BJX : 1];            // f32x3: byte offset of (cout row, 8-value chunk) inside ONE bf16 weight plane
+        const int chunkb = tid % CHB, rb0 = tid / CHB;
+        if constexpr (X3) {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int co = n0 + r0 + RPP * j;
-            b_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunk * KPC) * (BF ? 2u : 4u) : OOB;
+            for (int j = 0; j < BJX; ++j) {
+                const int co = n0 + rb0 + RPPB * j;
+                bx_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunkb * 8) * 2u : OOB;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int co = n0 + r0 + RPP * j;
+                b_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunk * KPC) * (BF ? 2u : 4u) : OOB;
+            }
         }
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(in), 0, (int)((long long)sg.N * sg.in_nstride * ABYTES), 0x00020000);
+        const unsigned plane_b = (unsigned)((long long)p.Cout * p.wrow * 2);      // f32x3: bytes of one weight plane
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-            BF ? const_cast<void*>(p.w_bf16) : (void*)const_cast<float*>(w), 0,
-            (int)((long long)p.Cout * p.wrow * (BF ? 2 : 4)), 0x00020000);
+            X3 ? const_cast<void*>(p.w_x3) : (BF ? const_cast<void*>(p.w_bf16) : (void*)const_cast<float*>(w)), 0,
+            (int)((long long)p.Cout * p.wrow * (X3 ? 6 : (BF ? 2 : 4))), 0x00020000);
+        if constexpr (X3) __syncthreads();         // the row table (start of the operand region) has been read by everybody
 
         // bf16 matrix cores: a K-slice is ~250 ns of MFMA work, far less than the latency of the global loads that
         // feed the next one -> TWO slices are kept in flight in registers (set = slice parity): slice kt+2 is requested
         // while slice kt is multiplied and slice kt+1 waits in its registers for the LDS buffer that slice kt-1 has left.
         constexpr bool PD2 = BF && MINW <= 2;      // (the four-per-CU tuning variant has no registers to spare)
         constexpr int NSET = PD2 ? 2 : 1;
-        float4 ra[NSET][AJ], rb[NSET][BJ];
+        constexpr int NBL = X3 ? 3 * BJX : BJ;      // 16-B weight loads per thread and K-slice
+        float4 ra[NSET][AJ], rb[NSET][NBL];
         float4 ra1[NSET][(BF && !AB) ? AJ : 1];     // bf16 mode on fp32 maps: the second half (k+4..k+7) of each 8-value chunk
+        bool cokb = false;                          // f32x3: this thread's 8-value weight chunk lies inside Cin
         int tap = ks / cpt, cc = ks - tap * cpt;
         // wave-uniform description of the K-slice being fetched
         int adelta = 0, bdelta = 0, ctap = 0;
@@ -248,8 +288,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             const int cb = cc * BK;
             ctap = tap;
             adelta = ((p.dy[tap_lo + tap] * IW + p.dx[tap_lo + tap]) * Cin + cb) * (int)ABYTES;    // bytes, relative to tap (0,0)
-            bdelta = (p.wk[tap_lo + tap] + cb) * (BF ? 2 : 4);
+            bdelta = (p.wk[tap_lo + tap] + cb) * ((BF || X3) ? 2 : 4);
             cok = cb + chunk * KPC < Cin;   // Cin % 4 == 0: a 4-value group is all-in or all-out
+            cokb = X3 && cb + chunkb * 8 < Cin;      // (Cin % 8 == 0 in this mode)
             cok1 = BF && !AB && cb + chunk * KPC + 4 < Cin;
             if (++cc == cpt) { cc = 0; ++tap; }
         };
@@ -259,7 +300,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             if (BF && !AB) ra1[set][j] = buf_load16(rs_in, (ok && cok1) ? a_base[j] + (unsigned)adelta + 16u : OOB);
         };
         auto load_b = [&](int j, const int set) {
-            rb[set][j] = buf_load16(rs_w, cok ? b_base[j] + (unsigned)bdelta : OOB);
+            if constexpr (X3) {                     // j = plane * BJX + row pass
+                const int pl = j / BJX, jj = j - pl * BJX;
+                // (a row past Cout carries OOB = 0x7fffffff: adding the slice / plane offsets keeps it beyond the buffer's extent)
+                rb[set][j] = buf_load16(rs_w, cokb ? bx_base[jj] + (unsigned)bdelta + (unsigned)pl * plane_b : OOB);
+            } else {
+                rb[set][j] = buf_load16(rs_w, cok ? b_base[X3 ? 0 : j] + (unsigned)bdelta : OOB);
+            }
         };
         auto store_lds = [&](int buf, const int set) {
 #pragma unroll
@@ -273,10 +320,18 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 else
                     As[buf * BM * CH + row * CH + swzc(row, chunk)] = ra[set][j];
             }
+            if constexpr (X3) {
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const int row = r0 + RPP * j;
-                Bs[buf * BN * CH + row * CH + swzc(row, chunk)] = rb[set][j];
+                for (int j = 0; j < 3 * BJX; ++j) {
+                    const int pl = j / BJX, row = rb0 + RPPB * (j - pl * BJX);
+                    Bs[(buf * 3 + pl) * BN * CHB + row * CHB + (chunkb ^ ((row >> 2) & 3))] = rb[set][j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int row = r0 + RPP * j;
+                    Bs[buf * BN * CH + row * CH + swzc(row, chunk)] = rb[set][X3 ? 0 : j];
+                }
             }
         };
 
@@ -292,21 +347,108 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
         for (int j = 0; j < AJ; ++j) load_a(j, 0);
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) load_b(j, 0);
+        for (int j = 0; j < NBL; ++j) load_b(j, 0);
         if (PD2 && ks + 1 < ke) {
             slice_begin();
 #pragma unroll
             for (int j = 0; j < AJ; ++j) load_a(j, NSET - 1);
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) load_b(j, NSET - 1);
+            for (int j = 0; j < NBL; ++j) load_b(j, NSET - 1);
         }
         store_lds(0, 0);
         __syncthreads();
 
         IG_ACC(2, t_pro);
         IG_T0(t_loop);
-        constexpr int KSTEPS = CH / 2;      // one k-step = the two chunks (h = 0 / 1) a wave's lanes read
-        constexpr int APS = (AJ + KSTEPS - 1) / KSTEPS, BPS = (BJ + KSTEPS - 1) / KSTEPS;   // loads per k-step
+        constexpr int KSTEPS = X3 ? 2 : CH / 2;      // one k-step = the two chunks (h = 0 / 1) a wave's lanes read (f32x3: 16 channels)
+        constexpr int APS = (AJ + KSTEPS - 1) / KSTEPS, BPS = (NBL + KSTEPS - 1) / KSTEPS;   // loads per k-step
+        // f32x3: one K-slice = two k16 steps.  A lane owns pixel row li of its wave's 32 rows and the 8 channels 16 s + 8 h ..
+        // + 7 of step s: two 16-B reads of fp32 values, split into three bf16x8 limbs (truncation: and / sub, exact), and
+        // three 16-B reads per cout block of the pre-split weights; then six MFMAs per block, smallest terms first.
+        auto k_slice_x3 = [&](const int kt, const int par) {
+            const int buf = par;
+            const bool more = kt + 1 < ke;
+            if (more) slice_begin();
+            const float4* Ab = As + buf * BM * CH;
+            const float4* Bb = Bs + buf * 3 * BN * CHB;
+            const int arow = wm * 32 + li;
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            constexpr unsigned TOP = 0xffff0000u, SEL = 0x07060302u;      // v_perm: upper halves of (second, first) operand
+            auto pack_top = [&](const float (&v)[8]) {                      // bf16x8 of the upper 16 bits of eight fp32 values
+                u4v P;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) P[e] = __builtin_amdgcn_perm(__float_as_uint(v[2 * e + 1]), __float_as_uint(v[2 * e]), SEL);
+                return __builtin_bit_cast(bf16x8, P);
+            };
+            auto read_a = [&](int kk, float (&x)[8]) {
+                const int ca = 4 * kk + 2 * h;                 // fp32 chunks ca, ca + 1 of the pixel row: channels 16 kk + 8 h .. + 7
+                const float4 x0 = Ab[arow * CH + swzc(arow, ca)], x1 = Ab[arow * CH + swzc(arow, ca + 1)];
+                x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+            };
+            float4 wb[FN][3];
+            auto read_b = [&](int kk, const int pl) {
+                const int cbk = 2 * kk + h;                    // bf16 chunk of the weight rows
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = j * 32 + li;
+                    wb[j][pl] = Bb[pl * BN * CHB + row * CHB + (cbk ^ ((row >> 2) & 3))];
+                }
+            };
+#ifdef ERD_X3_NOMFMA      // timing probe: everything but the matrix instructions (results are garbage)
+#define ERD_X3(AV, PL)                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[0][j][PL] += wb[j][PL].x * __builtin_bit_cast(float4, AV).x;
+#else
+#define ERD_X3(AV, PL)                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                          \
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV, __builtin_bit_cast(bf16x8, wb[j][PL]), acc[0][j], 0, 0, 0);
+#endif
+            float x[8], xn[8];
+            read_a(0, x);
+            read_b(0, 2);
+            read_b(0, 1);
+            read_b(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // Order of the six limb products: the three that need only the UPPER limb of the activation first (four
+                // v_perm and the fragments are ready), the remainders r1 = x - hi, r2 = r1 - mid are computed under their
+                // MFMAs.  A weight plane's fragments are re-read for the next k16 step as soon as its last product is issued.
+                if (kk == 0) read_a(1, xn);
+#ifndef ERD_X3_NOLOAD     // (timing probe: the K loop re-uses the first slice's registers)
+                if (more) {      // the next slice's global loads, half of them per k16 step, issued under this step's MFMAs
+#pragma unroll
+                    for (int q = 0; q < APS; ++q)
+                        if (kk * APS + q < AJ) load_a(kk * APS + q, 0);
+#pragma unroll
+                    for (int q = 0; q < BPS; ++q)
+                        if (kk * BPS + q < NBL) load_b(kk * BPS + q, 0);
+                }
+#endif
+                const bf16x8 ah = pack_top(x);
+                ERD_X3(ah, 2)
+                if (kk == 0) read_b(1, 2);
+                ERD_X3(ah, 1)
+                ERD_X3(ah, 0)
+                float r1[8], r2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & TOP);
+                const bf16x8 am = pack_top(r1);
+                ERD_X3(am, 1)
+                if (kk == 0) read_b(1, 1);
+                ERD_X3(am, 0)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & TOP);
+                const bf16x8 al = pack_top(r2);
+                ERD_X3(al, 0)
+                if (kk == 0) {
+                    read_b(1, 0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = xn[e];
+                }
+            }
+#undef ERD_X3
+            if (more) store_lds(buf ^ 1, 0);
+            __syncthreads();
+        };
         // one K-slice; par = (kt - ks) & 1 selects the LDS buffer (and, with two slices in flight, the register set)
         auto k_slice = [&](const int kt, const int par) {
             const int buf = par;
@@ -369,7 +511,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             if (more) store_lds(buf ^ 1, PD2 ? (par ^ 1) : 0);
             __syncthreads();
         };
-        if constexpr (PD2) {
+        if constexpr (X3) {
+            for (int kt = ks; kt < ke; ++kt) k_slice_x3(kt, (kt - ks) & 1);
+        } else if constexpr (PD2) {
             for (int kt = ks; kt < ke; kt += 2) {       // unrolled by two: register sets are named at compile time
                 k_slice(kt, 0);
                 if (kt + 1 < ke) k_slice(kt + 1, 1);
@@ -446,6 +590,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 
         IG_ACC(4, t_fix);
         IG_T0(t_epi);
+        if constexpr (X3) fill_rows(rows_epi);      // (behind the staging area; published by the barrier that opens the first pass)
         // ---- epilogue: accumulators -> LDS (64 rows at a time) -> coalesced float4 rows --------------------
         // A lane owns one output column, so direct stores would be 64 dword stores per lane (store-issue bound).
         // Staging the tile through the (now idle) operand LDS turns them into 16-B stores of whole 512-B rows and
@@ -472,7 +617,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             if (PREFETCH && pf_src && (p.Cout & 3) == 0 && n0 + (tid % C4N) * 4 < p.Cout) {
 #pragma unroll
                 for (int q = 0; q < NPF; ++q) {
-                    const int oo = rows[half * FM * 32 + tid / C4N + q * RPS].out_off;
+                    const int oo = rows_epi[half * FM * 32 + tid / C4N + q * RPS].out_off;
                     if (oo >= 0) pf[PREFETCH ? q : 0] = erd::ld4(pf_src + oo + n0 + (tid % C4N) * 4);
                 }
             }
@@ -495,7 +640,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                 // Cout not a multiple of 4 (e.g. a 70-class teacher head): rows are not 16-B aligned -> scalar stores
                 float csum[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int rr = tid / C4N; rr < FM * 32; rr += RPS) {
-                    const int oo = rows[half * FM * 32 + rr].out_off;
+                    const int oo = rows_epi[half * FM * 32 + rr].out_off;
                     if (oo < 0) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -519,7 +664,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
                 for (int q = 0; q < NPF; ++q) {
                     const int rr = tid / C4N + q * RPS;
-                    const int oo = rows[half * FM * 32 + rr].out_off;
+                    const int oo = rows_epi[half * FM * 32 + rr].out_off;
                     if (oo < 0) continue;
                     float4 v = *reinterpret_cast<const float4*>(stage + rr * SLD + c4 * 4);
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
@@ -1170,6 +1315,58 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
+// three bf16 limbs of a fp32 value by truncation: x == hi + mid + lo exactly (8 + 8 + 8 significand bits)
+__device__ __forceinline__ void limbs3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    const unsigned xb = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(xb & 0xffff0000u);
+    const unsigned r1b = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(r1b & 0xffff0000u);
+    hi = (unsigned short)(xb >> 16);
+    mid = (unsigned short)(r1b >> 16);
+    lo = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// dst[plane][i] = limb `plane` of src[i]
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n) return;
+    unsigned short h, m, l;
+    limbs3(src[i], h, m, l);
+    dst[i] = h;
+    dst[n + i] = m;
+    dst[2 * n + i] = l;
+}
+
+// dst[plane][ci][t'][co] = limb `plane` of rowscale[co] * w[co][t][ci]
+__global__ __launch_bounds__(256) void weight_transpose_x3_kernel(const float* __restrict__ w, const float* __restrict__ rowscale,
+                                                                   unsigned short* __restrict__ dst, int Cout, int ntaps, int Cin,
+                                                                   int flip) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int td = flip ? ntaps - 1 - t : t;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((int64_t)co * ntaps + t) * Cin + ci] * (rowscale ? rowscale[co] : 1.f);
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    const int64_t plane = (int64_t)Cin * ntaps * Cout;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (co < Cout && ci < Cin) {
+            unsigned short h, m, l;
+            limbs3(tile[tx][r], h, m, l);
+            const int64_t o = ((int64_t)ci * ntaps + td) * Cout + co;
+            dst[o] = h;
+            dst[plane + o] = m;
+            dst[2 * plane + o] = l;
+        }
+    }
+}
+
 int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -1182,7 +1379,8 @@ int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false, bool OB = false>
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false, bool OB = false,
+          bool X3 = false>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     constexpr int BK = (BKT / 4) * (BF ? 8 : 4);
     int tiles = 0;
@@ -1194,9 +1392,11 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     tiles *= ntn;
     if (tiles == 0) return 0;
     const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
-    const size_t oper = (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4), stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
-    const size_t lds = (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB>;
+    const size_t oper = X3 ? (size_t)2 * (BM * 8 + 3 * BN * 4) * sizeof(float4) : (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4);
+    const size_t stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
+    // (f32x3: the row table and the fix-up's broadcast word live inside the operand region -- see the kernel)
+    const size_t lds = X3 ? oper : (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB, X3>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1206,7 +1406,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     // ragged last round; otherwise one workgroup per tile.
     const int slots = MINW * num_cus();
     int G = tiles;
-    SkWs ws{nullptr, nullptr, xcd_order_enabled()};
+    SkWs ws{nullptr, nullptr, xcd_order_enabled(), 0};
     // workspace layout (fixed, independent of this launch's tile count): [slabs: 2*slots*128*128 floats][tickets]
     const size_t slab_bytes = (size_t)2 * 4 * num_cus() * 128 * 128 * sizeof(float);
     const size_t need = slab_bytes + (size_t)tiles * sizeof(int);
@@ -1232,6 +1432,12 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
         // tickets are zero on entry: the workspace is zero-initialised by its owner and every reducer re-zeroes
         // the ticket it consumed
     }
+    // persistent whole tiles (experiment, ERD_PT=1): launches that stay tile-parallel and have more tiles than resident slots
+    static const int pt = getenv("ERD_PT") ? atoi(getenv("ERD_PT")) : 0;
+    if (pt && !ws.slabs && !seg_taps && tiles > slots) {
+        G = slots;
+        ws.whole_tiles = 1;
+    }
     hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), lds, st, *d, tiles, ws);
     return erd::check_launch("conv_igemm");
 }
@@ -1244,7 +1450,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     ERD_REQUIRE(d->ntaps >= 1 && d->ntaps <= ERD_MAX_TAPS, "conv: ntaps=%d", d->ntaps);
     ERD_REQUIRE(d->Cin > 0 && d->Cin % 4 == 0, "conv: Cin=%d must be a multiple of 4", d->Cin);
     ERD_REQUIRE(d->Cout > 0 && d->wrow % 4 == 0, "conv: Cout=%d wrow=%d", d->Cout, d->wrow);
-    ERD_REQUIRE(d->w_bf16 || d->w, "conv: no weights");
+    ERD_REQUIRE(d->w_bf16 || d->w || d->w_x3, "conv: no weights");
+    ERD_REQUIRE(!(d->w_x3 && d->w_bf16), "conv: w_x3 and w_bf16 are exclusive");
     ERD_REQUIRE(d->w_bf16 || !(d->in_bf16 || d->out_bf16), "conv: bf16 maps need the bf16 matrix-core mode (w_bf16)");
     ERD_REQUIRE(!d->in_bf16 || d->Cin % 8 == 0, "conv: bf16 input maps need Cin %% 8 == 0 (Cin=%d)", d->Cin);
     ERD_REQUIRE(d->colsum_copies >= 0 && (d->colsum_copies & (d->colsum_copies - 1)) == 0, "conv: colsum_copies=%d must be a power of two",
@@ -1279,6 +1486,13 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
         ERD_BF_LAUNCH(false, false);
 #undef ERD_BF_LAUNCH
     }
+    if (d->w_x3 && d->Cin % 8 == 0 && d->wrow % 8 == 0) {
+        // "f32x3": fp32 maps and results, products on the bf16 matrix cores through exact three-limb splits (see the kernel)
+        if (seg_taps_any) return launch_igemm<128, 128, 4, 1, 32, 2, false, true, false, false, true>(d, st);
+        if (d->Cout <= 64) return launch_igemm<128, 64, 4, 1, 32, 2, false, false, false, false, true>(d, st);
+        return launch_igemm<128, 128, 4, 1, 32, 2, false, false, false, false, true>(d, st);
+    }
+    ERD_REQUIRE(d->w, "conv: this launch needs the fp32 weights (w_x3 serves Cin %% 8 == 0 only)");
     if (seg_taps_any)   // per-segment tap sets (merged parity classes of a stride-2 input gradient): a dedicated instantiation
         return launch_igemm<128, 128, 2, 2, 32, 2, false, true>(d, st);
     if (variant == 9) return launch_igemm<128, 128, 2, 2, 32, 1>(d, st);
@@ -1294,6 +1508,15 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     // 1056 tiles of 128x128 run as one full dispatch round plus a 37 % full one whose workgroups do not run faster for
     // being alone; 128x64 tiles halve that tail (121.7 -> 107.4 us per launch, +0.9 % on the step; K = 64 / 128 measured
     // equal or worse).  ERD_IGEMM_SHORTK=0: off (A/B aid).
+    static const int force = getenv("ERD_IG_FORCE") ? atoi(getenv("ERD_IG_FORCE")) : 0;      // experiment: one variant for every short-K launch
+    if (force && d->ntaps * d->Cin <= 256) {
+        if (force == 1) return launch_igemm<128, 128, 2, 2, 32, 2>(d, st);
+        if (force == 2) return launch_igemm<128, 128, 2, 2, 16, 3>(d, st);
+        if (force == 3) return launch_igemm<128, 128, 2, 2, 16, 4>(d, st);
+        if (force == 4) return launch_igemm<128, 64, 2, 2, 32, 2>(d, st);
+        if (force == 5) return launch_igemm<128, 64, 2, 2, 16, 4>(d, st);
+        if (force == 6) return launch_igemm<128, 64, 2, 2, 32, 3>(d, st);
+    }
     static const int shortk = getenv("ERD_IGEMM_SHORTK") ? atoi(getenv("ERD_IGEMM_SHORTK")) : 1;
     if (shortk && d->ntaps * d->Cin == 256 && d->Cout >= 512) return launch_igemm<128, 64, 2, 2, 32, 2>(d, st);
     if (d->ntaps * d->Cin <= 256) {
@@ -1434,6 +1657,21 @@ extern "C" int erd_weight_transpose(const float* w, const float* rowscale, float
     hipLaunchKernelGGL(weight_transpose_kernel<float>, dim3((Cin + 31) / 32, (Cout + 31) / 32, ntaps), dim3(256), 0,
                        (hipStream_t)stream, w, rowscale, dst, Cout, ntaps, Cin, flip);
     return erd::check_launch("weight_transpose");
+}
+
+extern "C" int erd_split3(const float* src, void* dst, int64_t n, erd_stream_t stream) {
+    ERD_REQUIRE(src && dst && n > 0, "split3: bad args");
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<unsigned short*>(dst), n);
+    return erd::check_launch("split3");
+}
+
+extern "C" int erd_weight_transpose_x3(const float* w, const float* rowscale, void* dst, int Cout, int ntaps, int Cin, int flip,
+                                       erd_stream_t stream) {
+    ERD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && ntaps > 0, "weight_transpose_x3: bad args");
+    hipLaunchKernelGGL(weight_transpose_x3_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, ntaps), dim3(256), 0, (hipStream_t)stream, w,
+                       rowscale, reinterpret_cast<unsigned short*>(dst), Cout, ntaps, Cin, flip);
+    return erd::check_launch("weight_transpose_x3");
 }
 
 extern "C" int erd_weight_transpose_bf16(const float* w, const float* rowscale, void* dst, int Cout, int ntaps,

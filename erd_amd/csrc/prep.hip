@@ -69,6 +69,22 @@ __device__ __forceinline__ void wino_block(const erd_weight_prep_item& it, int l
     }
 }
 
+// kind 3: the three bf16 limb planes of w (n = Cout * ntaps * Cin values, any layout): dst[plane][i], arithmetic of erd_split3
+__device__ __forceinline__ void split3_block(const erd_weight_prep_item& it, int local) {
+    const int64_t n = (int64_t)it.Cout * it.ntaps * it.Cin;
+    const int64_t i = local * 256ll + threadIdx.x;
+    if (i >= n) return;
+    const float x = it.w[i];
+    const unsigned xb = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(xb & 0xffff0000u);
+    const unsigned r1b = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(r1b & 0xffff0000u);
+    unsigned short* d = reinterpret_cast<unsigned short*>(it.dst);
+    d[i] = (unsigned short)(xb >> 16);
+    d[n + i] = (unsigned short)(r1b >> 16);
+    d[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
 __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_item* __restrict__ items, int nitems) {
     __shared__ float tile[32][33];
     __shared__ int s_item;
@@ -84,6 +100,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_
     const erd_weight_prep_item it = items[s_item];
     const int local = (int)blockIdx.x - it.block0;
     if (it.kind == 2) wino_block(it, local);
+    else if (it.kind == 3) split3_block(it, local);
     else transpose_block(it, local, tile);
 }
 
@@ -91,6 +108,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_
 
 extern "C" int erd_weight_prep_blocks(int kind, int Cout, int ntaps, int Cin) {
     if (kind == 2) return (int)(((int64_t)((Cout + 15) / 16 * 16) * Cin + 255) / 256);
+    if (kind == 3) return (int)(((int64_t)Cout * ntaps * Cin + 255) / 256);
     return ((Cin + 31) / 32) * ((Cout + 31) / 32) * ntaps;
 }
 

@@ -592,6 +592,19 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
             // iteration g stores raw(g+2) over raw(g), requests raw(g+3), transforms raw(g+1) -> V(g+1); barrier B_{g+1}
             auto iter = [&](auto par_tag, auto npar_tag) {
                 ERD_T0(ts);
+#ifdef ERD_WINO_GNPROBE     // timing probe only (tools/build_probe.sh): what a GroupNorm-apply + ReLU on the raw slice would cost the
+                            // data waves -- one scale and NCH shift float4 loads per slice (the shift row of a padding entry would be a
+                            // zero row) and fma + max per element.  The values are placeholders: results are NOT a convolution of anything.
+                {
+                    const float4 gsc = buf_load16_s(rs_in, (unsigned)(dt & 3) * 16u, la_soff & 1023u);
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const float4 gsh = buf_load16_s(rs_in, (unsigned)(dt & 3) * 16u + 64u * i, la_soff & 1023u);
+                        rv[i].x = fmaxf(rv[i].x * gsc.x + gsh.x, 0.f); rv[i].y = fmaxf(rv[i].y * gsc.y + gsh.y, 0.f);
+                        rv[i].z = fmaxf(rv[i].z * gsc.z + gsh.z, 0.f); rv[i].w = fmaxf(rv[i].w * gsc.w + gsh.w, 0.f);
+                    }
+                }
+#endif
                 store_raw(rv, par_tag);
                 flush_pending();
                 issue_next(rv);

@@ -186,17 +186,21 @@ def make_levels(sizes: Sequence[Tuple[int, int]]) -> Levels:
 
 
 # ---------------------------------------------------------------------------------------------
-# compute mode of the 1x1 / 3x3 convolutions: "f32" (fp32 matrix cores, the headline configuration) or "bf16"
+# compute mode of the 1x1 / 3x3 convolutions: "f32" (fp32 matrix cores, the headline configuration), "bf16"
 # (BASELINE.json configs[2]: both multiplicands rounded to bf16 on their way to the bf16 matrix cores, fp32
-# accumulation, epilogues and storage).  Process-wide switch: set_compute("bf16") / ERD_COMPUTE=bf16.
+# accumulation, epilogues and storage) or "f32x3": fp32 maps / accumulation / results as in "f32", but the direct
+# implicit-GEMM launches form every product on the bf16 matrix cores from exact three-limb splits of both fp32
+# multiplicands (erd_conv_desc::w_x3; gfx950's fp32 MFMA runs at 1/16 of the bf16 rate).  The Winograd launches and the
+# weight-gradient kernels are the "f32" ones.  Process-wide switch: set_compute(...) / ERD_COMPUTE=...
 # ---------------------------------------------------------------------------------------------
-COMPUTE = _os.environ.get("ERD_COMPUTE", "f32")
+DEFAULT_COMPUTE = _os.environ.get("ERD_COMPUTE", "f32x3")      # the fp32 configuration of BASELINE configs[1]; "f32": native fp32 MFMA
+COMPUTE = DEFAULT_COMPUTE
 
 
 def set_compute(mode: str) -> None:
     global COMPUTE
-    if mode not in ("f32", "bf16"):
-        raise ValueError(f"compute mode {mode!r}: 'f32' or 'bf16'")
+    if mode not in ("f32", "bf16", "f32x3"):
+        raise ValueError(f"compute mode {mode!r}: 'f32', 'f32x3' or 'bf16'")
     COMPUTE = mode
 
 
@@ -249,6 +253,42 @@ def _weights_bf16(w: Tensor) -> Tensor:
         hit = (ver, to_bf16(w.detach()))
         base._erd_bf16 = hit
     return hit[1]
+
+
+def split3(t: Tensor) -> Tensor:
+    """[3, *t.shape] bf16: the three limb planes of a contiguous fp32 tensor (hi + mid + lo == t exactly)"""
+    assert t.is_contiguous() and t.dtype == torch.float32
+    out = torch.empty((3,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+    call("erd_split3", _p(t), _p(out), t.numel(), _stream())
+    return out
+
+
+def _weights_x3(w: Tensor, grad_form: bool = False) -> Tensor:
+    """limb planes of a contiguous weight view for erd_conv_desc::w_x3.  Forward form: `w` is the OHWI view of a parameter --
+    frozen ones are split once (cached on the parameter, validated by pointer + version), trainable ones are served from the
+    trainer's per-step preparation (ParamPrep, kind 3) or split per use.  Gradient form: `w` is a transposed (BN-scaled)
+    weight from weight_transpose(); when that buffer is a prepared one its planes are prepared too (second launch)."""
+    owner = getattr(w, "_erd_prep_owner", None) if grad_form else _prep_owner(w)
+    prep = _prep_of(owner)
+    key = ("XT" if grad_form else "X", id(owner))
+    if prep is not None:
+        r = prep.lookup(key)
+        if r is not None and r.matches(owner, w, None):
+            return r.out
+    if not grad_form:
+        base = getattr(w, "_erd_owner", None)
+        if base is not None and not base.requires_grad and not w.requires_grad:
+            ver = (w.data_ptr(), base._version, tuple(w.shape))
+            hit = getattr(base, "_erd_x3", None)
+            if hit is None or hit[0] != ver:
+                hit = (ver, split3(w.detach()))
+                base._erd_x3 = hit
+            return hit[1]
+    out = split3(w.detach())
+    if prep is not None and not torch.cuda.is_current_stream_capturing():
+        prep.register(key, 3, w, None, torch.empty_like(out), w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 0, owner,
+                      1 if grad_form else 0)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -406,6 +446,11 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     if COMPUTE == "bf16":
         wb = _weights_bf16(w)          # (kept alive by this frame until the launch is queued; stream-ordered free)
         d.w_bf16 = wb.data_ptr()
+    elif COMPUTE == "f32x3" and Cin % 8 == 0:
+        wx = _weights_x3(w)
+        d.w_x3 = wx.data_ptr()
+    else:
+        d.w_x3 = 0
     _attach_sk_ws(d, w.device)
     _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
                 tag=tag if TIMING_DETAIL else "")
@@ -499,7 +544,7 @@ class distillation_forward:
 
 def wino_ok(Cin: int, k: int, stride: int, pad: int) -> bool:
     # (16-channel K slices; the kernel's look-ahead pipeline wants at least four of them per item)
-    return WINOGRAD and COMPUTE == "f32" and k == 3 and stride == 1 and pad == 1 and Cin % 16 == 0 and Cin >= 64
+    return WINOGRAD and COMPUTE in ("f32", "f32x3") and k == 3 and stride == 1 and pad == 1 and Cin % 16 == 0 and Cin >= 64
 
 
 def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: int, scale: Optional[Tensor] = None,
@@ -563,8 +608,9 @@ class ParamPrep:
         r.owner, r.version, r.level, r.stamp = owner, owner._version, level, -1
         r.src_ptr, r.rs_ptr = src.data_ptr(), 0 if rowscale is None else rowscale.data_ptr()
         out._erd_prep_owner = owner
-        if key[0] == "T":                       # a Winograd image built from the previous transposed buffer is orphaned
+        if key[0] == "T":                       # what was built from the previous transposed buffer is orphaned
             self.recipes.pop(("UT", key[1]), None)
+            self.recipes.pop(("XT", key[1]), None)
         self.recipes[key] = r
         self._tables = None
 
@@ -584,6 +630,7 @@ class ParamPrep:
                 del self.recipes[key]
                 if key[0] == "T":
                     self.recipes.pop(("UT", key[1]), None)
+                    self.recipes.pop(("XT", key[1]), None)
                 self._tables = None
                 self._stale()
         if self._tables is None:
@@ -659,12 +706,15 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
                      colsum=colsum, kname="conv_wino_dgrad")
         return
     wtb = None
+    wtx = None
     if COMPUTE == "bf16":
         wtb = wt if wt.dtype == torch.bfloat16 else to_bf16(wt)
     elif wt.dtype != torch.float32:
         raise ValueError("conv_dgrad: bf16 weights in f32 compute mode")
+    elif COMPUTE == "f32x3" and Cout % 8 == 0:
+        wtx = _weights_x3(wt, grad_form=True)
     if stride == 2 and k == 3 and len(dzs) == 1 and MERGE_PARITY:
-        _dgrad_s2_merged(dzs[0], wt, wtb, dxs[0], pad, Cin, Cout, accumulate, res, relu_mask, colsum)
+        _dgrad_s2_merged(dzs[0], wt, wtb, dxs[0], pad, Cin, Cout, accumulate, res, relu_mask, colsum, wtx=wtx)
         return
     cache = _desc_cache()
     key = ("dgrad", k, stride, pad, accumulate, wt.shape, _geom(dzs), _geom(dxs), None if res is None else _geom(res),
@@ -686,6 +736,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         d.colsum = 0 if colsum is None else colsum.data_ptr()
         if wtb is not None:
             d.w_bf16 = wtb.data_ptr()
+        d.w_x3 = 0 if wtx is None else wtx.data_ptr()
         _attach_sk_ws(d, wt.device)
         _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
                     tag=tag if TIMING_DETAIL else "")
@@ -741,7 +792,7 @@ MERGE_PARITY = _os.environ.get("ERD_MERGE_PARITY", "1") != "0"
 
 
 def _dgrad_s2_merged(dz: Tensor, wt: Tensor, wtb, dx: Tensor, pad: int, Cin: int, Cout: int, accumulate: bool, res,
-                     relu_mask, colsum) -> None:
+                     relu_mask, colsum, wtx=None) -> None:
     """The four output-parity classes of a 3x3 / stride-2 input gradient (4 + 2 + 2 + 1 taps) as four segments of ONE
     launch with per-segment tap sets: ~1000 tiles of mixed length in one grid instead of four ragged launches of ~260."""
     k, stride = 3, 2
@@ -777,6 +828,7 @@ def _dgrad_s2_merged(dz: Tensor, wt: Tensor, wtb, dx: Tensor, pad: int, Cin: int
     d.colsum_copies = 0 if colsum is None else colsum.numel() // Cin
     if wtb is not None:
         d.w_bf16 = wtb.data_ptr()
+    d.w_x3 = 0 if wtx is None else wtx.data_ptr()
     d.in_bf16, d.out_bf16 = _stored_bf16([dz]), _stored_bf16([dx], res, relu_mask)
     d.sk_ws, d.sk_ws_bytes = 0, 0
     nbytes = 4.0 * (dz.numel() + dx.numel() + wt.numel()) if _TIMING is not None else 0.0

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERD_ABI_VERSION 2
+#define ERD_ABI_VERSION 3
 #define ERD_MAX_SEG 5   /* FPN levels batched in one launch */
 #define ERD_MAX_TAPS 9
 
@@ -99,6 +99,13 @@ typedef struct {
      * 0 / 0 = fp32 maps.  Cin % 8 == 0 with in_bf16.  The reference's AMP switch (tools/train.py:85-97) stores conv
      * outputs in the low-precision type the same way. */
     int in_bf16, out_bf16;
+    /* optional ("f32x3" mode): the same weights as three bf16 LIMB planes, [3][Cout][wrow] (erd_split3 / erd_weight_transpose_x3):
+     * plane 0 = the upper 16 bits of each fp32 weight, plane 1 = the upper 16 bits of the remainder, plane 2 = what is left
+     * -- w == p0 + p1 + p2 EXACTLY.  When set (and Cin % 8 == 0, wrow % 8 == 0; otherwise the launch needs `w`) maps, accumulation
+     * and results stay fp32 but every product a*w is formed on the bf16 matrix cores as the sum of the six limb products of
+     * weight >= 2^-16 (the activation is split the same way in registers): the dropped terms are below 2^-23 |a*w|, fp32's own
+     * rounding of that product.  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate; six bf16 MFMAs cost 3/8 of one fp32 MFMA. */
+    const void* w_x3;
 } erd_conv_desc;
 
 /* replaces: F.conv2d dispatches at resnet.py:268-283, res_layer.py:57-63, fpn.py:196,215-220,
@@ -108,6 +115,9 @@ int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream);
 size_t erd_conv_igemm_ws_bytes(int max_tiles);
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements */
 int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
+/* the three bf16 limbs of every value by truncation: dst[0][i] + dst[1][i] + dst[2][i] == src[i] exactly; dst = [3][n] bf16
+ * (erd_conv_desc::w_x3 of a forward convolution) */
+int erd_split3(const float* src, void* dst, int64_t n, erd_stream_t stream);
 
 /* ---- Winograd F(2x2,3x3) for the stride-1 3x3 convolutions (fp32 matrix cores, 2.25x fewer multiplications) ----
  * erd_wino_weights: U = G g G^T of w [Cout][3][3][Cin] in the tiled layout the kernel streams
@@ -174,9 +184,13 @@ int erd_weight_transpose(const float* w, const float* rowscale, float* dst, int 
 /* the same, rounded to bf16 (round to nearest even) for erd_conv_desc::w_bf16 */
 int erd_weight_transpose_bf16(const float* w, const float* rowscale, void* dst, int Cout, int ntaps,
                               int Cin, int flip, erd_stream_t stream);
+/* the same as three bf16 limb planes [3][Cin][ntaps][Cout] for erd_conv_desc::w_x3 of an input-gradient convolution */
+int erd_weight_transpose_x3(const float* w, const float* rowscale, void* dst, int Cout, int ntaps,
+                            int Cin, int flip, erd_stream_t stream);
 
-/* Many weight transforms in ONE launch: erd_weight_transpose (kind 0), erd_weight_transpose_bf16 (kind 1) or
- * erd_wino_weights (kind 2: w is [Cout][3][3][Cin], ntaps = 9, rowscale unused) per item, same arithmetic.  `items_dev` is a
+/* Many weight transforms in ONE launch: erd_weight_transpose (kind 0), erd_weight_transpose_bf16 (kind 1),
+ * erd_wino_weights (kind 2: w is [Cout][3][3][Cin], ntaps = 9, rowscale unused) or erd_split3 (kind 3: the Cout * ntaps * Cin
+ * values at w, rowscale / flip unused) per item, same arithmetic.  `items_dev` is a
  * DEVICE array sorted by block0; item i owns blocks [block0, block0 + erd_weight_prep_blocks(kind, Cout, ntaps, Cin)) of the
  * launch, total_blocks is their sum.  Items of one launch must not depend on each other (a Winograd image of a transposed
  * weight goes into a second launch).  The trainer prepares everything the step derives from the parameters alone this

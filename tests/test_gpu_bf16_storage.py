@@ -27,7 +27,7 @@ def K():
 def bf16_mode(K):
     K.set_compute("bf16")
     yield
-    K.set_compute("f32")
+    K.set_compute(K.DEFAULT_COMPUTE)
 
 
 def _r(t):
@@ -212,6 +212,6 @@ def test_maps_of_one_role_must_share_a_storage_type(K, bf16_mode):
     w = torch.zeros((64, 1, 1, 64), device="cuda")
     with pytest.raises(AssertionError):
         K.conv_forward([x], w, [out], 1, 1, 0, res=[res])
-    K.set_compute("f32")
+    K.set_compute(K.DEFAULT_COMPUTE)
     with pytest.raises(AssertionError):          # bf16 maps only in the bf16 mode
         K.conv_forward([x], w, [out], 1, 1, 0)

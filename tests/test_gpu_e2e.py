@@ -359,7 +359,7 @@ def test_bf16_matrix_core_mode_vs_oracle_bf16_multiplicands():
         print("bf16 mode vs oracle(bf16 multiplicands): logits max abs %.2e, losses max rel %.2e, ERS Jaccard min %.3f, "
               "grad rel L2 median %.2e max %.2e" % (dmax, lerr, min(jac), float(np.median(errs)), max(errs)))
     finally:
-        K.set_compute("f32")
+        K.set_compute(K.DEFAULT_COMPUTE)
 
 
 def test_teacher_look_ahead_follows_the_plain_trainer():
@@ -477,7 +477,7 @@ def test_batched_bn_fold_equals_the_per_layer_fold_and_tracks_updates():
     assert torch.equal(sc, K.bn_fold(m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.eps)[0])
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "bf16"])
 def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
     """kernels.ParamPrep: after every optimizer update the trainer rebuilds the transposed (BN-scaled) weights of the
     input-gradient convolutions and the Winograd weight images in two launches (erd_weight_prep_batch).  From the step at
@@ -505,14 +505,20 @@ def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
             if r.kind == 2:
                 ref = torch.empty_like(r.out)
                 K.call("erd_wino_weights", K._p(r.src), K._p(ref), r.Cout, r.Cin, r.flip, K._stream())
+            elif r.kind == 3:                     # the three bf16 limb planes of a weight ("f32x3")
+                ref = torch.empty_like(r.out)
+                K.call("erd_split3", K._p(r.src), K._p(ref), r.src.numel(), K._stream())
+                assert torch.equal((r.out[0].float() + r.out[1].float()) + r.out[2].float(), r.src), key      # limbs sum to the weight
             else:
                 ref = torch.empty_like(r.out)
                 K.call("erd_weight_transpose_bf16" if r.kind == 1 else "erd_weight_transpose", K._p(r.src), K._p(r.rowscale), K._p(ref),
                        r.Cout, r.ntaps, r.Cin, r.flip, K._stream())
             assert torch.equal(ref, r.out), key
         assert kinds.get("T", 0) >= 40, kinds                         # every trainable convolution's transposed weights
-        if mode == "f32":
+        if mode in ("f32", "f32x3"):
             assert kinds.get("U", 0) >= 15 and kinds.get("UT", 0) >= 15, kinds
+        if mode == "f32x3":
+            assert kinds.get("X", 0) >= 30 and kinds.get("XT", 0) >= 25, kinds    # the direct launches' limb planes, both forms
         # ... and they are what the wrappers hand out
         blk = model.backbone.layer3[0]
         wk = Fn.ohwi(blk.conv2.weight)
@@ -522,7 +528,7 @@ def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
             blk.conv2.weight.mul_(1.0)              # version bump: the prepared buffer no longer vouches for the parameter
         assert K.weight_transpose(wk, r.rowscale).data_ptr() != r.out.data_ptr()
     finally:
-        K.set_compute("f32")
+        K.set_compute(K.DEFAULT_COMPUTE)
 
 
 def test_bf16_full_size_step_against_the_fp32_path():
@@ -554,7 +560,7 @@ def test_bf16_full_size_step_against_the_fp32_path():
             g = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
             return {k: float(v) for k, v in lv.items()}, g, sets, (None if feats is None else feats[0].dtype)
         finally:
-            K.set_compute("f32")
+            K.set_compute(K.DEFAULT_COMPUTE)
 
     l32, g32, s32, _ = run("f32")
     l16, g16, s16, fdt = run("bf16")

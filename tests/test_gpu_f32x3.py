@@ -1,0 +1,105 @@
+"""GPU: the "f32x3" compute mode (erd_conv_desc::w_x3) -- fp32 maps, fp32 accumulation, fp32 results, with every product
+formed on the bf16 matrix cores from exact three-limb splits of both fp32 multiplicands (six of the nine limb products; what
+is dropped is below 2^-23 of the product).  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate, so this is how an fp32-accurate
+GEMM is done fast on this chip.  Checked here: the limb split is exact; every direct implicit-GEMM form (forward with its
+epilogues, input gradient incl. the merged stride-2 classes, multi-level launches, stream-K splits) is AS CLOSE TO AN FP64
+evaluation as the native fp32-MFMA kernel is; the prepared limb planes of a trainer equal the per-use ones bit for bit."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import golden_inputs as G
+from test_gpu_kernels import CONV_CASES, nhwc, to_nchw
+
+
+@pytest.fixture()
+def K():
+    from erd_amd import kernels as K
+    yield K
+    K.set_compute(K.DEFAULT_COMPUTE)
+
+
+def rel64(a, b):
+    """relative L2 distance of a (fp32, cpu) from the fp64 reference b"""
+    return float((a.double() - b).norm() / (b.norm() + 1e-300))
+
+
+def test_split3_is_exact(K):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1 << 16, generator=g) * torch.exp(8 * torch.randn(1 << 16, generator=g))      # 20 orders of magnitude
+    x[:4] = torch.tensor([0.0, -0.0, 1.0, -3.0e-30])
+    planes = K.split3(x.cuda()).cpu()
+    assert planes.dtype == torch.bfloat16 and planes.shape == (3, 1 << 16)
+    hi, mid, lo = planes[0].float(), planes[1].float(), planes[2].float()
+    assert torch.equal((hi + mid) + lo, x)                     # the three limbs ARE the value (8 + 8 + 8 significand bits)
+    assert torch.equal(hi.view(torch.int32) & 0xffff, torch.zeros_like(hi, dtype=torch.int32))
+    assert bool(((mid == 0) | (mid.abs() <= hi.abs() * 2.0 ** -7)).all()) and bool(((lo == 0) | (lo.abs() <= hi.abs() * 2.0 ** -15)).all())
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p", CONV_CASES)
+def test_f32x3_convolutions_are_as_close_to_fp64_as_the_native_fp32_kernels(K, N, Cin, Cout, H, W, k, s, p):
+    x = G.randn(1, N, Cin, H, W)
+    w = G.randn(2, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    scale, shift = 0.5 + G.rand(3, Cout), G.randn(4, Cout, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), None, s, p)
+    OH, OW = ref.shape[2:]
+    res = G.randn(5, N, Cout, OH, OW)
+    ref2 = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    dy = G.randn(13, N, Cout, OH, OW)
+    rowscale = 0.5 + G.rand(14, Cout)
+    xd = x.double().requires_grad_(True)
+    gref = torch.autograd.grad(F.conv2d(xd, w.double(), None, s, p), xd, dy.double() * rowscale.double().view(1, -1, 1, 1))[0]
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xg, dyg = nhwc(x), nhwc(dy)
+    err = {}
+    for mode in ("f32", "f32x3"):
+        K.set_compute(mode)
+        keep, K.WINOGRAD = K.WINOGRAD, False          # (the direct kernels are what the mode changes)
+        try:
+            out = torch.empty((N, OH, OW, Cout), device="cuda")
+            K.conv_forward([xg], wg, [out], k, s, p)
+            out2 = torch.empty_like(out)
+            K.conv_forward([xg], wg, [out2], k, s, p, scale=scale.cuda(), shift=shift.cuda(), res=[nhwc(res)], relu=True)
+            wt = K.weight_transpose(wg, rowscale.cuda())
+            dx = torch.zeros((N, H, W, Cin), device="cuda")
+            K.conv_dgrad([dyg], wt, [dx], k, s, p)
+        finally:
+            K.WINOGRAD = keep
+        err[mode] = (rel64(to_nchw(out), ref), rel64(to_nchw(out2), ref2), rel64(to_nchw(dx), gref))
+    print("rel L2 to fp64 (plain / epilogue / input gradient): native fp32 MFMA %.2e %.2e %.2e | f32x3 %.2e %.2e %.2e" % (err["f32"] + err["f32x3"]))
+    for a, b in zip(err["f32x3"], err["f32"]):
+        assert a <= max(1.5 * b, 2e-7), err
+
+
+def test_f32x3_multilevel_and_streamk_launches(K):
+    """five levels sharing one weight in one launch, and a long-K launch that the stream-K decomposition splits"""
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    N, Cc = 2, 256
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(21, N, A, Cc)
+    w = G.randn(22, Cc, Cc, 3, 3, scale=(2.0 / (Cc * 9)) ** 0.5)
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    K.set_compute("f32x3")
+    keep, K.WINOGRAD = K.WINOGRAD, False
+    try:
+        out = torch.empty((N, A, Cc), device="cuda")
+        K.conv_forward(K.level_views(x.cuda(), sizes), wg, K.level_views(out, sizes), 3, 1, 1)
+        off = 0
+        for (h, wd) in sizes:
+            xl = x[:, off:off + h * wd].reshape(N, h, wd, Cc).permute(0, 3, 1, 2)
+            ref = F.conv2d(xl.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(N, h * wd, Cc)
+            assert rel64(out[:, off:off + h * wd].cpu(), ref) < 3e-7
+            off += h * wd
+        # 1x1 on 2048 channels, 4 x 25 x 42 pixels: 33 x 4 tiles of 64 K-slices on 512 resident workgroups -> split K
+        x2 = G.randn(23, 4, 2048, 25, 42)
+        w2 = G.randn(24, 512, 2048, 1, 1, scale=(2.0 / 2048) ** 0.5)
+        ref = F.conv2d(x2.double(), w2.double())
+        o2 = torch.empty((4, 25, 42, 512), device="cuda")
+        for _ in range(2):      # twice: the tickets of the first launch must be back at zero
+            K.conv_forward([nhwc(x2)], w2.permute(0, 2, 3, 1).contiguous().cuda(), [o2], 1, 1, 0)
+            assert rel64(to_nchw(o2), ref) < 6e-7       # (K = 2048: the native kernel reads 3.4e-7 here)
+    finally:
+        K.WINOGRAD = keep

@@ -88,7 +88,7 @@ def test_bf16_mode_full_size_tracks_fp32():
             logs[mode], model, _ = _run(True, steps=3, bs=2)
             assert all(torch.isfinite(p).all() for p in model.parameters())
         finally:
-            K.set_compute("f32")
+            K.set_compute(K.DEFAULT_COMPUTE)
     for a, b in zip(logs["bf16"], logs["f32"]):
         assert a["loss"] == pytest.approx(b["loss"], rel=2e-2), (a, b)
         assert a["loss"] != b["loss"]

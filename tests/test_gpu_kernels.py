@@ -267,7 +267,7 @@ def test_conv_forward_cout_not_multiple_of_4(K, Cout):
 def bf16_mode(K):
     K.set_compute("bf16")
     yield
-    K.set_compute("f32")
+    K.set_compute(K.DEFAULT_COMPUTE)
 
 
 def _r(t):

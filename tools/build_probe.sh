@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/build_probe.sh NAME FILE.hip [extra hipcc flags...]: a liberd_hip variant with FILE.hip rebuilt under extra flags
+# (erd_amd/lib/abl/liberd_hip_NAME.so; select it with ERD_HIP_LIB for same-box A/B timing runs)
+set -e
+cd "$(dirname "$0")/../erd_amd/csrc"
+mkdir -p ../lib/abl
+n=$1; f=$2; shift 2
+base=$(basename $f .hip)
+extra=""
+case $base in losses|leaf_ops|predict) extra="-ffp-contract=off";; esac
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f -o /tmp/${base}_probe_$n.o
+objs=""
+for o in conv_mfma elementwise losses predict winograd leaf_ops prep; do
+  if [ $o = $base ]; then objs="$objs /tmp/${base}_probe_$n.o"; else objs="$objs $o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../lib/abl/liberd_hip_$n.so
+echo built erd_amd/lib/abl/liberd_hip_$n.so

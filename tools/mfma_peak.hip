@@ -1,0 +1,100 @@
+// Sustained matrix-core rate and the clock the chip holds while doing it (evidence for DESIGN.md's roofline peaks).
+//   hipcc --offload-arch=gfx950 -O3 -w tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+// Every CU runs WG workgroups of 4 waves; each wave issues back-to-back MFMAs on 4 independent accumulators (no memory
+// traffic).  Reported per variant: TFLOP/s from hipEvent time, and the shader clock = s_memtime ticks / s_memrealtime
+// (100 MHz constant-rate) ticks measured inside the kernel by one wave per workgroup (median over workgroups).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KIND, int NACC>
+__global__ __launch_bounds__(256) void mfma_loop(float* sink, unsigned long long* ticks, int iters) {
+    f32x16 acc[KIND == 1 ? 1 : NACC];
+    f32x4 acc4[KIND == 1 ? NACC : 1];
+    for (int q = 0; q < (KIND == 1 ? 1 : NACC); ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int q = 0; q < (KIND == 1 ? NACC : 1); ++q) acc4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 0; ++q) {
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        acc4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float a = 1e-3f * (threadIdx.x & 7), b = 0.5f;
+    bf16x8 ab, bb;
+    for (int r = 0; r < 8; ++r) { ab[r] = (__bf16)a; bb[r] = (__bf16)b; }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+            if constexpr (KIND == 0) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+            if constexpr (KIND == 1) acc4[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[q], 0, 0, 0);
+            if constexpr (KIND == 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[q], 0, 0, 0);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int q = 0; q < (KIND == 1 ? 1 : NACC); ++q) s += acc[q][0] + acc[q][7];
+    for (int q = 0; q < (KIND == 1 ? NACC : 1); ++q) s += acc4[q][0] + acc4[q][3];
+    if (s == 123.456f) sink[0] = s;
+    if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = c1 - c0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+template <int KIND, int NACC>
+void run(const char* name, double flop_per_mfma, int wg_per_cu, int iters) {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int grid = prop.multiProcessorCount * wg_per_cu;
+    float* sink;
+    unsigned long long* ticks;
+    hipMalloc(&sink, 4);
+    hipMalloc(&ticks, sizeof(unsigned long long) * 2 * grid);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((mfma_loop<KIND, NACC>), dim3(grid), dim3(256), 0, 0, sink, ticks, iters / 10);   // warm-up
+    hipDeviceSynchronize();
+    std::vector<double> tfs, clks;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((mfma_loop<KIND, NACC>), dim3(grid), dim3(256), 0, 0, sink, ticks, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(2 * grid);
+        hipMemcpy(h.data(), ticks, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost);
+        std::vector<double> c;
+        for (int b = 0; b < grid; ++b) c.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100e6 / 1e9);
+        std::sort(c.begin(), c.end());
+        tfs.push_back((double)grid * 4 /*waves*/ * (double)NACC * iters * flop_per_mfma / (ms * 1e-3) / 1e12);
+        clks.push_back(c[c.size() / 2]);
+    }
+    std::sort(tfs.begin(), tfs.end());
+    std::sort(clks.begin(), clks.end());
+    printf("%-26s %2d independent accumulators, %d WG/CU x 4 waves, %d MFMAs/wave: %8.1f TFLOP/s (median of 5; min %.1f max %.1f), shader clock %.3f GHz "
+           "(s_memtime / s_memrealtime, median workgroup; min %.3f max %.3f over runs)\n",
+           name, NACC, wg_per_cu, NACC * iters, tfs[2], tfs[0], tfs[4], clks[2], clks[0], clks[4]);
+    hipFree(sink);
+    hipFree(ticks);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    printf("%s, %d CUs, clockRate %.0f MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1e3);
+    for (int wg = 1; wg <= 2; ++wg) {
+        run<0, 4>("v_mfma_f32_32x32x2_f32", 32.0 * 32 * 2 * 2, wg, 40000);
+        run<0, 2>("v_mfma_f32_32x32x2_f32", 32.0 * 32 * 2 * 2, wg, 80000);
+        run<1, 2>("v_mfma_f32_16x16x4_f32", 16.0 * 16 * 4 * 2, wg, 160000);
+        run<1, 4>("v_mfma_f32_16x16x4_f32", 16.0 * 16 * 4 * 2, wg, 80000);
+        run<1, 8>("v_mfma_f32_16x16x4_f32", 16.0 * 16 * 4 * 2, wg, 40000);
+        run<1, 16>("v_mfma_f32_16x16x4_f32", 16.0 * 16 * 4 * 2, wg, 20000);
+        run<2, 4>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16 * 2, wg, 80000);
+        run<2, 8>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16 * 2, wg, 40000);
+    }
+    return 0;
+}
