@@ -259,10 +259,14 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--teacher-graph", action="store_true",
                     help="replay the frozen teacher's pass from a hipGraph (BASELINE configs[4]); same arithmetic")
-    ap.add_argument("--compute", choices=["f32", "f32x3", "bf16"], default="f32",
-                    help="f32: fp32 matrix cores, fp32 maps (BASELINE configs[1], the headline).  bf16: BASELINE configs[2] -- the 1x1 / 3x3 "
-                         "convolutions on the bf16 matrix cores with fp32 accumulation, feature maps and their gradients STORED as "
-                         "bf16; head outputs, statistics, losses, parameters and parameter gradients stay fp32")
+    ap.add_argument("--compute", choices=["f32x3", "f32", "bf16"], default="f32x3",
+                    help="f32x3 (default; BASELINE configs[1], the headline): fp32 maps, fp32 accumulation, fp32 results; the direct "
+                         "implicit-GEMM launches form each fp32 product on the bf16 matrix cores from exact three-limb splits of both "
+                         "multiplicands (what is dropped is below 2^-23 of the product; gfx950's fp32 MFMA runs at 1/16 of the bf16 rate), "
+                         "Winograd and weight-gradient launches run on the fp32 matrix cores.  f32: every launch on the fp32 matrix cores "
+                         "(the A/B sibling).  bf16: BASELINE configs[2] -- the 1x1 / 3x3 convolutions on the bf16 matrix cores with fp32 "
+                         "accumulation, feature maps and their gradients STORED as bf16; head outputs, statistics, losses, parameters "
+                         "and parameter gradients stay fp32")
     ap.add_argument("--step-graph", action="store_true",
                     help="replay the whole step (everything between two SGD updates) from one hipGraph; same arithmetic")
     ap.add_argument("--no-teacher-ahead", action="store_true",
@@ -388,20 +392,26 @@ def main():
 
     if rank == 0:
         images = args.batch * world * args.steps
+        prec = "bf16" if args.compute == "bf16" else "f32"
         which = {("r50_40_40", "f32", False): "BASELINE configs[1]", ("r50_40_40", "bf16", False): "BASELINE configs[2], per-GPU leg",
                  ("r101_70_10", "f32", False): "BASELINE configs[3], per-GPU leg, fp32", ("r101_70_10", "bf16", False): "BASELINE configs[3], per-GPU leg, bf16",
                  ("r50_40_40", "f32", True): "BASELINE configs[4], per-GPU leg, fp32", ("r50_40_40", "bf16", True): "BASELINE configs[4], per-GPU leg, bf16"}.get(
-                     (args.arch, args.compute, args.mixed_res), "a combination BASELINE.json does not name")
+                     (args.arch, prec, args.mixed_res), "a combination BASELINE.json does not name")
+        arithmetic = {"f32x3": "fp32 maps / accumulation / results; direct implicit-GEMM products on the bf16 matrix cores from exact three-limb "
+                               "splits of both fp32 multiplicands (6 of 9 limb products, dropped part < 2^-23 of a product); Winograd F(2x2,3x3) "
+                               "and weight gradients on the fp32 matrix cores",
+                      "f32": "fp32 throughout, every GEMM-shaped launch on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+                      "bf16": "bf16 matrix cores, bf16-stored maps, fp32 accumulate / statistics / losses"}[args.compute]
         res = "mixed resolution " + "/".join(f"{h}x{w}" for h, w in MIXED_SHAPES) + " (round-robin, each padded to /32)" if args.mixed_res \
             else "1333x800 padded to 800x1344"
         out = {
             "metric": f"images/sec GFL-{'R50 40+40' if args.arch == 'r50_40_40' else 'R101 70+10'} incre step @1333x800",
             "value": round(images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": warm, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": prec, "arithmetic": arithmetic, "compute_mode": args.compute, "data": "synthetic",
             "config": {"workload": f"{arch['label']} ({which}), {res}, " +
-                                   ("fp32" if args.compute == "f32" else ("bf16 matrix cores, bf16-stored maps, fp32 accumulate / statistics / losses"
-                                                                         if K.BF16_STORAGE else "bf16 multiplicands / fp32 accumulate+storage")) +
+                                   ("fp32" if prec == "f32" else ("bf16 matrix cores, bf16-stored maps, fp32 accumulate / statistics / losses"
+                                                                 if K.BF16_STORAGE else "bf16 multiplicands / fp32 accumulate+storage")) +
                                    ", procedural weights", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 6), "streams": "serial" if args.serial else ("teacher(t+1)||backward(t), cls||reg towers, trailing weight gradients" if ahead
@@ -431,7 +441,12 @@ def main():
                     groups[sym] = dict(ms=sum(r["ms"] for r in rs), flop=sum(r["flop"] for r in rs), launches=sum(r["launches"] for r in rs),
                                        min_bytes=sum(r["min_bytes"] for r in rs))
             sym, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
-            execf = WINO_EXECUTED if sym == "wino_conv_kernel" else 1.0
+            # executed flops per algorithmic flop, and the matrix pipe they run on: Winograd 16/36 on the fp32 pipe; the three-limb
+            # form of the direct launches 6 bf16 MFMA flops per fp32 flop on the bf16 pipe
+            x3 = args.compute == "f32x3"
+            execf = WINO_EXECUTED if sym == "wino_conv_kernel" else (6.0 if (x3 and sym == "conv_igemm_kernel") else 1.0)
+            if x3 and sym == "conv_igemm_kernel":
+                peak_tf = BF16_MFMA_PEAK_TFLOPS
             alg_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
             # PMC counters cannot be read from inside this process: `traffic` / `mfma_busy_pmc` are STATIC values from the
             # committed profile of the same command (fp32 only; the profile names its commit) -- pointers, not measurements
@@ -440,7 +455,8 @@ def main():
                                "achieved": round(alg_tf * execf, 2), "peak": peak_tf, "unit": "TFLOP/s",
                                "frac": round(alg_tf * execf / peak_tf, 4),
                                "basis": "flops the kernel executes on the matrix cores" + (
-                                   " (Winograd F(2x2,3x3): 16/36 of the direct-convolution count)" if execf < 1 else " (= the direct-convolution count)"),
+                                   " (Winograd F(2x2,3x3): 16/36 of the direct-convolution count)" if execf < 1 else (
+                                       " (six bf16 limb products per fp32 product, against the bf16 MFMA peak)" if execf > 1 else " (= the direct-convolution count)")),
                                "algorithmic_tflops": round(alg_tf, 2), "executed_flop_fraction": round(execf, 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, PMC)",
                                "traffic_source": traffic_src, "traffic_static": True,
@@ -455,17 +471,24 @@ def main():
             #  step_frac           the ALGORITHMIC work of the reference's step (both copies of the frozen trunk)
             #  step_frac_executed  minus the student's copy of the shared frozen trunk, which this build does not execute
             #  mfma_executed_frac  the flops the matrix cores actually run: additionally Winograd launches at 16/36
+            #                      = the share of the step the matrix pipes MUST be busy: sum over the launch classes of executed flops /
+            #                      the peak of the pipe they run on (three-limb launches: 6 x their flops on the bf16 pipe), over the step time
+            step_peak = BF16_MFMA_PEAK_TFLOPS if args.compute == "bf16" else FP32_MFMA_PEAK_TFLOPS
             g_img = STEP_GFLOP_PER_IMAGE[args.arch] * rel_area
             step_s = dt / args.steps
             skipped = (TRUNK_GFLOP_PER_IMAGE if shared else 0.0) * rel_area
-            wino_alg = sum(ktime[c]["flop"] for c in SYMBOLS["wino_conv_kernel"] if c in ktime) / rsteps / 1e9     # GFLOP per step (rank 0's batch)
+            per_step = lambda classes: sum(ktime[c]["flop"] for c in classes if c in ktime) / rsteps / 1e9     # GFLOP per step (rank 0's batch)
+            wino_alg, igemm_alg = per_step(SYMBOLS["wino_conv_kernel"]), per_step(SYMBOLS["conv_igemm_kernel"]) if x3 else 0.0
             exec_gflop_step = args.batch * (g_img - skipped) - wino_alg * (1.0 - WINO_EXECUTED)
+            pipe_s = ((exec_gflop_step - igemm_alg) / step_peak + igemm_alg * 6.0 / BF16_MFMA_PEAK_TFLOPS) * 1e-3
             out["roofline"]["step_gflop_per_image"] = round(g_img, 1)
             out["roofline"]["step_tflops"] = round(args.batch * g_img / step_s / 1e3, 2)
-            out["roofline"]["step_frac"] = round(out["roofline"]["step_tflops"] / peak_tf, 4)
-            out["roofline"]["step_frac_executed"] = round(args.batch * (g_img - skipped) / step_s / 1e3 / peak_tf, 4)
-            out["roofline"]["mfma_executed_frac"] = round(exec_gflop_step / step_s / 1e3 / peak_tf, 4)
+            out["roofline"]["step_frac"] = round(out["roofline"]["step_tflops"] / step_peak, 4)
+            out["roofline"]["step_frac_executed"] = round(args.batch * (g_img - skipped) / step_s / 1e3 / step_peak, 4)
+            out["roofline"]["mfma_executed_frac"] = round(pipe_s / step_s, 4)
             out["roofline"]["mfma_executed_gflop_per_step"] = round(exec_gflop_step, 1)
+            if x3:
+                out["roofline"]["three_limb_gflop_per_step"] = round(igemm_alg, 1)
             out["kernels"] = {k: {"ms_per_step": round(r["ms"] / rsteps, 3),
                                   "tflops": round(r["flop"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flop"] else None,
                                   "launches_per_step": r["launches"] // rsteps} for k, r in ktime.items()}

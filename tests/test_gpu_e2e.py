@@ -180,19 +180,34 @@ def test_trainer_three_steps_follow_oracle_sgd_trajectory():
         imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=s)
         x, metas = O.preprocess(imgs)
         batches.append((x, boxes, labels, metas))
-    # oracle trajectory
-    sd = {k: v.clone() for k, v in ssd.items()}
-    names = [k for k, v in sd.items() if O.trainable(k) and v.dtype == torch.float32]
-    bufs, ref_loss = {}, []
-    for it in range(3):
-        x, boxes, labels, metas = batches[it % 2]
-        leaf = {k: (sd[k].clone().requires_grad_(True) if k in names else sd[k]) for k in sd}
-        total = O.parse_losses(O.erd_step_loss(tsd, leaf, x, boxes, labels, metas, 40, 80))
-        total.backward()
-        ref_loss.append(float(total))
-        lr = tr.lr_at(it)
-        assert lr == pytest.approx(0.02 * (0.5 + 0.5 * it / 2))
-        O.sgd_momentum_step({k: sd[k] for k in names}, {k: leaf[k].grad for k in names}, bufs, lr, 0.9, 1e-4)
+    # oracle trajectory -- and the oracle's trajectory from weights perturbed by 1e-6 (relative): at 123x153 a handful of
+    # ReLU / ATSS decisions sit on their thresholds, and how far two fp32 evaluations of the SAME mathematics drift apart
+    # in three updates is a property of the problem, not of an implementation
+    names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
+
+    def oracle_run(noise):
+        sd = {k: v.clone() for k, v in ssd.items()}
+        if noise:
+            gen = torch.Generator().manual_seed(11)
+            for k in names:
+                sd[k] = sd[k] * (1 + noise * torch.randn(sd[k].shape, generator=gen))
+        start = {k: sd[k].clone() for k in names}
+        bufs, losses = {}, []
+        for it in range(3):
+            x, boxes, labels, metas = batches[it % 2]
+            leaf = {k: (sd[k].clone().requires_grad_(True) if k in names else sd[k]) for k in sd}
+            total = O.parse_losses(O.erd_step_loss(tsd, leaf, x, boxes, labels, metas, 40, 80))
+            total.backward()
+            losses.append(float(total))
+            lr = tr.lr_at(it)
+            assert lr == pytest.approx(0.02 * (0.5 + 0.5 * it / 2))
+            O.sgd_momentum_step({k: sd[k] for k in names}, {k: leaf[k].grad for k in names}, bufs, lr, 0.9, 1e-4)
+        return sd, losses, {k: (sd[k] - start[k]).double() for k in names}
+
+    sd, ref_loss, d_ref = oracle_run(0.0)
+    _, _, d_eps = oracle_run(1e-6)
+    den = sum(float(d_ref[k].pow(2).sum()) for k in names)
+    self_err = (sum(float((d_eps[k] - d_ref[k]).pow(2).sum()) for k in names) / den) ** 0.5
     got = []
     for it in range(3):
         x, boxes, labels, metas = batches[it % 2]
@@ -201,16 +216,16 @@ def test_trainer_three_steps_follow_oracle_sgd_trajectory():
     torch.cuda.synchronize()
     assert np.allclose(got, ref_loss, rtol=2e-3), (got, ref_loss)
     params = dict(model.named_parameters())
-    num = den = 0.0
-    for k in names:
-        d_ref = (sd[k] - ssd[k]).double()
-        d_got = (params[k].detach().cpu() - ssd[k]).double()
-        num += float((d_got - d_ref).pow(2).sum()); den += float(d_ref.pow(2).sum())
-    # Observed 1.6e-2 (with the student's frozen trunk on the direct kernels; 5e-2 when its three layer1 convolutions ran on
-    # the Winograd kernels -- that is how the trunk's sensitivity first showed up, see test_gpu_fullsize.py).  The per-step
-    # losses above are the tight check (2e-3); this one catches a wrong lr / momentum / weight decay.
-    assert den > 0 and (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
-    print("3-step displacement rel L2 err: %.2e; losses %s vs %s" % ((num / den) ** 0.5, got, ref_loss))
+    num = sum(float(((params[k].detach().cpu() - ssd[k]).double() - d_ref[k]).pow(2).sum()) for k in names)
+    err = (num / den) ** 0.5
+    # Observed: 1.6e-2 with the direct launches on the native fp32 MFMA, 5.2e-2 in the three-limb form (which is the CLOSER
+    # of the two to fp64 kernel by kernel, test_gpu_f32x3.py) and 5e-2 when the student's frozen trunk ran on the Winograd
+    # kernels -- against `self_err`, the displacement error of the oracle's own trajectory from weights perturbed by 1e-6.
+    # The per-step losses above are the tight check (2e-3); this one catches a wrong lr / momentum / weight decay (a factor
+    # of two in any of them reads > 0.3 here).
+    print("3-step displacement rel L2 err: %.2e (the oracle's own, from weights x (1 + 1e-6 noise): %.2e); losses %s vs %s"
+          % (err, self_err, got, ref_loss))
+    assert den > 0 and err < max(3e-2, 3.0 * self_err) and err < 0.15, (err, self_err)
     # frozen parts did not move; the teacher is untouched
     for k, v in ssd.items():
         if k not in names and v.dtype == torch.float32:
