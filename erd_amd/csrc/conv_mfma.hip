@@ -290,7 +290,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
             adelta = ((p.dy[tap_lo + tap] * IW + p.dx[tap_lo + tap]) * Cin + cb) * (int)ABYTES;    // bytes, relative to tap (0,0)
             bdelta = (p.wk[tap_lo + tap] + cb) * ((BF || X3) ? 2 : 4);
             cok = cb + chunk * KPC < Cin;   // Cin % 4 == 0: a 4-value group is all-in or all-out
-            cokb = X3 && cb + chunkb * 8 < Cin;      // (Cin % 8 == 0 in this mode)
+            cokb = X3 && cb + chunkb * 8 < Cin;      // (a chunk that starts inside Cin may end past it: see erd_conv_igemm)
             cok1 = BF && !AB && cb + chunk * KPC + 4 < Cin;
             if (++cc == cpt) { cc = 0; ++tap; }
         };
@@ -425,29 +425,44 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #endif
                 const bf16x8 ah = pack_top(x);
                 ERD_X3(ah, 2)
+#ifndef ERD_X3_NOBREAD    // (timing probe: the second k16 step re-uses the first one's weight fragments)
                 if (kk == 0) read_b(1, 2);
+#endif
                 ERD_X3(ah, 1)
                 ERD_X3(ah, 0)
                 float r1[8], r2[8];
+#ifdef ERD_X3_NOVALU      // timing probe: the upper limb stands in for the other two (results are wrong)
+                const bf16x8 am = ah, al = ah;
+                (void)r1; (void)r2;
+#else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & TOP);
                 const bf16x8 am = pack_top(r1);
+#endif
                 ERD_X3(am, 1)
+#ifndef ERD_X3_NOBREAD
                 if (kk == 0) read_b(1, 1);
+#endif
                 ERD_X3(am, 0)
+#ifndef ERD_X3_NOVALU
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & TOP);
                 const bf16x8 al = pack_top(r2);
+#endif
                 ERD_X3(al, 0)
                 if (kk == 0) {
+#ifndef ERD_X3_NOBREAD
                     read_b(1, 0);
+#endif
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = xn[e];
                 }
             }
 #undef ERD_X3
+#ifndef ERD_X3_NOSYNC     // (timing probe, with ERD_X3_NOLOAD: no LDS refill and no barrier between slices)
             if (more) store_lds(buf ^ 1, 0);
             __syncthreads();
+#endif
         };
         // one K-slice; par = (kt - ks) & 1 selects the LDS buffer (and, with two slices in flight, the register set)
         auto k_slice = [&](const int kt, const int par) {
@@ -1486,13 +1501,15 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
         ERD_BF_LAUNCH(false, false);
 #undef ERD_BF_LAUNCH
     }
-    if (d->w_x3 && d->Cin % 8 == 0 && d->wrow % 8 == 0) {
+    // (Cin % 4 == 0 suffices: an 8-value weight chunk that straddles the end of a tap's channels meets activation zeros there --
+    //  the fp32 activation chunks are 4 wide and zero-filled past Cin -- and 16-byte buffer loads need dword alignment only)
+    if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0) {
         // "f32x3": fp32 maps and results, products on the bf16 matrix cores through exact three-limb splits (see the kernel)
         if (seg_taps_any) return launch_igemm<128, 128, 4, 1, 32, 2, false, true, false, false, true>(d, st);
         if (d->Cout <= 64) return launch_igemm<128, 64, 4, 1, 32, 2, false, false, false, false, true>(d, st);
         return launch_igemm<128, 128, 4, 1, 32, 2, false, false, false, false, true>(d, st);
     }
-    ERD_REQUIRE(d->w, "conv: this launch needs the fp32 weights (w_x3 serves Cin %% 8 == 0 only)");
+    ERD_REQUIRE(d->w, "conv: this launch needs the fp32 weights (w_x3 serves Cin %% 4 == 0 only)");
     if (seg_taps_any)   // per-segment tap sets (merged parity classes of a stride-2 input gradient): a dedicated instantiation
         return launch_igemm<128, 128, 2, 2, 32, 2, false, true>(d, st);
     if (variant == 9) return launch_igemm<128, 128, 2, 2, 32, 1>(d, st);

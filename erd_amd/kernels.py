@@ -446,7 +446,7 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     if COMPUTE == "bf16":
         wb = _weights_bf16(w)          # (kept alive by this frame until the launch is queued; stream-ordered free)
         d.w_bf16 = wb.data_ptr()
-    elif COMPUTE == "f32x3" and Cin % 8 == 0:
+    elif COMPUTE == "f32x3" and Cin % 4 == 0:
         wx = _weights_x3(w)
         d.w_x3 = wx.data_ptr()
     else:
@@ -711,7 +711,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         wtb = wt if wt.dtype == torch.bfloat16 else to_bf16(wt)
     elif wt.dtype != torch.float32:
         raise ValueError("conv_dgrad: bf16 weights in f32 compute mode")
-    elif COMPUTE == "f32x3" and Cout % 8 == 0:
+    elif COMPUTE == "f32x3" and Cout % 4 == 0:
         wtx = _weights_x3(wt, grad_form=True)
     if stride == 2 and k == 3 and len(dzs) == 1 and MERGE_PARITY:
         _dgrad_s2_merged(dzs[0], wt, wtb, dxs[0], pad, Cin, Cout, accumulate, res, relu_mask, colsum, wtx=wtx)
