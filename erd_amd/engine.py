@@ -410,6 +410,10 @@ class ERDTrainer:
             st.gl[:off[-1]].copy_(torch.cat([g.labels.reshape(-1).long() for g in gts], 0).to(dev, non_blocking=True))
         st.goff.copy_(torch.from_numpy(off), non_blocking=True)
 
+    def _forked(self):
+        """raw handles of the streams one step forks to and joins again (trailing weight gradients, the second tower stream)"""
+        return (Fn.trail_stream(self.device).cuda_stream, Fn.aux_stream(self.device).cuda_stream)
+
     def _teacher(self, inputs: Tensor, data_samples, it: int):
         """the frozen teacher's half of step `it` on the current (side) stream: eager launches, or one graph replay"""
         if self.teacher_graphs is None:
@@ -418,6 +422,14 @@ class ERDTrainer:
         gts, _, metas = unpack_gt_instances(data_samples)         # targets depend on the GT: eager
         out.targets = self.model.bbox_head._targets(out.sizes, gts, metas, self.device)
         return out
+
+    PHASES = None       # tools/phase_times.py: a list to which each step appends (name, event) marks on the step's stream
+
+    def _mark(self, name: str) -> None:
+        if ERDTrainer.PHASES is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            ERDTrainer.PHASES.append((name, ev))
 
     def train_step(self, inputs: Tensor, data_samples, next_batch=None) -> Dict[str, Tensor]:
         """`next_batch` = (inputs, data_samples) of the FOLLOWING step when the loader has it (a prefetching loader does):
@@ -446,17 +458,21 @@ class ERDTrainer:
                 self.side.wait_stream(cur)
                 with torch.cuda.stream(self.side), torch.no_grad():
                     teacher_out = self._teacher(inputs, data_samples, self.iter)
+            self._mark("step")
             self._apply_pending()
             self.flat.zero_grad()
-            K.zero_arena_begin(self.device)
+            K.zero_arena_begin(self.device, forked_streams=self._forked())
+            self._mark("update_done")
             if teacher_out.trunk is not None:      # shared frozen trunk: the student starts at its first trainable stage
                 cur.wait_event(teacher_out.trunk_event)
                 teacher_out.trunk[0].record_stream(cur)
             with K.distillation_forward(K.WINO_FROZEN_TRUNK):
                 s_cls, s_bbox, sizes = model._forward_cat(inputs, trunk=teacher_out.trunk)
+            self._mark("student_forward_done")
             cur.wait_stream(self.side)
             for t in teacher_out.tensors():
                 t.record_stream(cur)
+            self._mark("teacher_joined")
             losses = model.bbox_head.loss_cat(teacher_out.t_cls, teacher_out.t_bbox, s_cls, s_bbox, sizes, data_samples,
                                               teacher_out.ers, teacher_out.keep, model.ori_num_classes,
                                               model.dist_loss_weight, targets=teacher_out.targets)
@@ -466,6 +482,7 @@ class ERDTrainer:
             K.zero_arena_begin(self.device)
             losses = model(inputs, data_samples, mode="loss")
         total, log_vars = parse_losses(losses)
+        self._mark("losses_done")
         if next_batch is not None and self.overlap_teacher:
             # the teacher of the following step: behind everything the side stream holds for this one, next to this backward.
             # `cur` holds whatever PRODUCED next_batch (Runner.train prepares batch t+1 on the current stream before it calls
@@ -478,7 +495,9 @@ class ERDTrainer:
         if self.sync is not None:
             self.sync.arm()
         total.backward()
+        self._mark("backward_chain_done")
         Fn.trail_join(self.device)        # the trailing weight gradients of the backbone (functional._Trail)
+        self._mark("trail_joined")
         K.zero_arena_end()
         self._pending = True
         self._pending_lr = self.last_lr = self.lr_at(self.iter, self.epoch_factor)

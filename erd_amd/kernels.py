@@ -120,23 +120,28 @@ def workspace(name: str, nbytes: int, device) -> Tensor:
 # zero arena: the step needs a few hundred small zero-initialised accumulators (column sums, row dots, ...).
 # One memset per step over a bump-allocated arena replaces a fill launch per accumulator.
 # ---------------------------------------------------------------------------------------------
-_ARENA = {"buf": None, "off": 0, "key": None}
+_ARENA = {"buf": None, "off": 0, "key": None, "ok": ()}
 
 
-def zero_arena_begin(device, nbytes: int = 8 << 20) -> None:
-    """called once per step (on the stream the step runs on) by the trainer"""
+def zero_arena_begin(device, nbytes: int = 8 << 20, forked_streams=()) -> None:
+    """called once per step (on the stream the step runs on) by the trainer.  `forked_streams`: raw handles of streams
+    that the step forks to AFTER this call and joins BEFORE zero_arena_end() (the trailing weight-gradient stream, the
+    second tower stream): slices may be handed out there too -- they are ordered behind this memset by the fork and the
+    next step's memset is ordered behind their last use by the join.  (Round 2 handed those streams torch.zeros: 50 fill
+    launches per step for the trailing stream's row-dot / d-gamma scratch.)"""
     if _ARENA["buf"] is None or _ARENA["buf"].device != torch.device(device):
         _ARENA["buf"] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     _ARENA["buf"].zero_()
     _ARENA["off"] = 0
     _ARENA["key"] = _cur_stream()
+    _ARENA["ok"] = (_ARENA["key"],) + tuple(forked_streams)
 
 
 def zeros_f32(n: int, device) -> Tensor:
     """n zeroed floats: a slice of the step's arena when one is active on this stream, else torch.zeros"""
     a = _ARENA
     nb = (n * 4 + 255) // 256 * 256
-    if a["buf"] is None or a["key"] != _cur_stream() or a["off"] + nb > a["buf"].numel() \
+    if a["buf"] is None or a["key"] is None or _cur_stream() not in a["ok"] or a["off"] + nb > a["buf"].numel() \
             or a["buf"].device != torch.device(device):
         return torch.zeros(n, dtype=torch.float32, device=device)
     out = a["buf"][a["off"]:a["off"] + n * 4].view(torch.float32)
@@ -146,6 +151,7 @@ def zeros_f32(n: int, device) -> Tensor:
 
 def zero_arena_end() -> None:
     _ARENA["key"] = None
+    _ARENA["ok"] = ()
 
 
 def ws_float(name: str, n: int, device) -> Tensor:
@@ -1008,11 +1014,12 @@ def bn_dgamma(rowdot: Tensor, dbeta: Tensor, mean: Tensor, var: Tensor, eps: flo
     return dg
 
 
-def colsum(x2d: Tensor) -> Tensor:
-    """x2d: contiguous [rows, C] -> [C]"""
+def colsum(x2d: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """x2d: contiguous [rows, C] -> [C] (stored into `out` when given)"""
     assert x2d.is_contiguous()
     rows, Cc = x2d.shape[:-1].numel(), x2d.shape[-1]
-    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    if out is None:
+        out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
     call("erd_colsum", _p(x2d), rows, Cc, _p(out), 0, _mt(x2d), _stream())
     return out
 
@@ -1032,14 +1039,16 @@ def gn_relu_forward(c: Tensor, gamma: Tensor, beta: Tensor, sizes, G: int = 32, 
     return y, mr
 
 
-def gn_relu_backward(c: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mr: Tensor, sizes, G: int = 32):
+def gn_relu_backward(c: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mr: Tensor, sizes, G: int = 32,
+                     dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None):
+    """dgamma / dbeta: zero-initialised accumulators to add into (the parameters' flat gradient slots), else fresh ones"""
     assert c.is_contiguous() and dy.is_contiguous()
     N, A, Cc = c.shape
     lv = make_levels(sizes)
     stats = workspace("gn_stats", N * lv.nseg * G * 16, c.device)
     dc = torch.empty_like(c)
-    dgamma = zeros_f32(gamma.numel(), c.device)
-    dbeta = zeros_f32(beta.numel(), c.device)
+    dgamma = zeros_f32(gamma.numel(), c.device) if dgamma is None else dgamma
+    dbeta = zeros_f32(beta.numel(), c.device) if dbeta is None else dbeta
     call("erd_gn_relu_bwd", _p(c), _p(dy), _p(gamma), _p(beta), _p(mr), _p(stats), _p(dc), _p(dgamma), _p(dbeta), N, A,
          Cc, G, C.byref(lv), _mt(c, dy), _stream())
     return dc, dgamma, dbeta
