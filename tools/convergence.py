@@ -13,7 +13,7 @@ from erd_amd.engine import ERDTrainer
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)
-ap.add_argument("--compute", default="f32")
+ap.add_argument("--compute", default=K.DEFAULT_COMPUTE)
 ap.add_argument("--nbatches", type=int, default=4)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
