@@ -1503,7 +1503,10 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     }
     // (Cin % 4 == 0 suffices: an 8-value weight chunk that straddles the end of a tap's channels meets activation zeros there --
     //  the fp32 activation chunks are 4 wide and zero-filled past Cin -- and 16-byte buffer loads need dword alignment only)
-    if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0) {
+    // short K loops (K = taps x Cin below ERD_X3_MIN_K) gain nothing from a faster loop: they are set-up / epilogue bound and
+    // want the fp32 kernel's four small workgroups per CU (the three-limb kernel holds 80 KB of LDS: two per CU)
+    static const int x3_min_k = getenv("ERD_X3_MIN_K") ? atoi(getenv("ERD_X3_MIN_K")) : 0;
+    if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0 && (d->ntaps * d->Cin >= x3_min_k || !d->w)) {
         // "f32x3": fp32 maps and results, products on the bf16 matrix cores through exact three-limb splits (see the kernel)
         if (seg_taps_any) return launch_igemm<128, 128, 4, 1, 32, 2, false, true, false, false, true>(d, st);
         if (d->Cout <= 64) return launch_igemm<128, 64, 4, 1, 32, 2, false, false, false, false, true>(d, st);

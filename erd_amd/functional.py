@@ -63,6 +63,7 @@ def _may_fork(cur) -> bool:
 # Only with gradient sinks (ERDTrainer, which owns the join): the results land in the flat gradient buffer, nothing is
 # handed back to autograd from the auxiliary stream.
 WGRAD_TRAIL = _os.environ.get('ERD_WGRAD_TRAIL', '1') != '0'
+RES_LAYER_NODE = _os.environ.get('ERD_RES_LAYER', '1') != '0'    # a whole ResNet stage as one autograd node (ResLayerFn): A/B aid
 HEAD_TRAIL = _os.environ.get('ERD_HEAD_TRAIL', '0') != '0'      # the head towers' weight gradients too (A/B aid: see _wgrad_plain)
 _TRAIL = {}
 _TRAIL_ACTIVE = set()
@@ -365,86 +366,190 @@ class BottleneckFn(Function):
         params = saved[off:]
         P = [params[5 * i:5 * i + 5] for i in range(4 if has_down else 3)]
         need = ctx.needs_input_grad
-        need_x = need[0]
-        dev = x.device
-        grads = [None] * len(params)
-
-        def wgrad(idx, xin, dz, k, s, pad, scale, dbeta):
-            """dW (scaled by the folded BN), d gamma, d beta of conv `idx`"""
-            w, g, b, m, v = P[idx]
-            base = 3 + 5 * idx
-            if not (need[base] or need[base + 1] or need[base + 2]):
-                return
-            wk = ohwi(w)
-            trail = None
-            if WGRAD_TRAIL and all((not need[base + q]) or _sink(t) is not None for q, t in enumerate((w, g, b))):
-                trail = _Trail(dev, xin, dz, scale, dbeta)
-                trail.__enter__()
-            try:
-                _wgrad_body(idx, xin, dz, k, s, pad, scale, dbeta, w, g, b, m, v, base, wk)
-            finally:
-                if trail is not None:
-                    trail.__exit__(None, None, None)
-
-        def _wgrad_body(idx, xin, dz, k, s, pad, scale, dbeta, w, g, b, m, v, base, wk):
-            part, S = K.conv_wgrad_partials([xin], [dz], k, s, pad)
-            rowdot = K.zeros_f32(scale.numel(), scale.device) if need[base + 1] else None
-            grads[5 * idx] = _emit_wgrad(w, part, S, wk, scale, rowdot)
-            if need[base + 1]:
-                # a replicated [copies, C] accumulator is folded here; the fold lands in d beta's flat slot (zero at
-                # this point) or in a new tensor
-                rep = dbeta.dim() == 2
-                bs_fold = (_sink(b) if need[base + 2] else None) if rep else None
-                fold = None if not rep else (bs_fold if bs_fold is not None else torch.empty_like(dbeta[0]))
-                gs = _sink(g)
-                if gs is not None:                      # the slot is zero: plain store == accumulation
-                    K.bn_dgamma(rowdot, dbeta, m, v, eps, out=gs, dbeta_out=fold)
-                    _sunk(g)
-                else:
-                    grads[5 * idx + 1] = K.bn_dgamma(rowdot, dbeta, m, v, eps, dbeta_out=fold)
-                if rep:
-                    dbeta = fold
-            elif dbeta.dim() == 2:
-                dbeta = dbeta.sum(0)
-            if need[base + 2]:
-                bs = _sink(b)
-                if bs is None:
-                    grads[5 * idx + 2] = dbeta
-                else:
-                    if dbeta.data_ptr() != bs.data_ptr():   # (the projection shortcut shares conv3's column sums)
-                        bs.add_(dbeta)
-                    _sunk(b)
-
-        def beta_slot(idx, n):
-            """column sums of dz go straight into d beta's flat slot when it has one (zero at this point)"""
-            s_ = _sink(P[idx][2]) if need[3 + 5 * idx + 2] else None
-            return s_ if s_ is not None else K.zeros_f32(n, dev)
-
-        dz3, db3 = K.relu_bwd_colsum(y, dy.contiguous(), True, colsum_into=beta_slot(2, y.shape[3]))
-        wgrad(2, o2, dz3, 1, 1, 0, s3, db3)
-        dz2 = torch.empty_like(o2)
-        # the epilogues of the two input-gradient convolutions add their column sums into 8 replicated rows (hundreds of
-        # tiles adding to ONE row would serialise on the memory-side atomic unit); wgrad()'s bn_dgamma folds them
-        rep_slot = lambda n: K.zeros_f32(K.COLSUM_COPIES * n, dev).view(K.COLSUM_COPIES, n)
-        db2 = rep_slot(o2.shape[3])
-        K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[2][0]), s3), [dz2], 1, 1, 0, relu_mask=[o2], colsum=db2)
-        wgrad(1, o1, dz2, 3, stride, 1, s2, db2)
-        dz1 = torch.empty_like(o1)
-        db1 = rep_slot(o1.shape[3])
-        K.conv_dgrad([dz2], K.weight_transpose(ohwi(P[1][0]), s2), [dz1], 3, stride, 1, relu_mask=[o1], colsum=db1)
-        wgrad(0, x, dz1, 1, 1, 0, s1, db1)
-        dx = None
-        if need_x:
-            dx = torch.empty_like(x)
-            wt1 = K.weight_transpose(ohwi(P[0][0]), s1)
-            if has_down:
-                K.conv_dgrad([dz1], wt1, [dx], 1, 1, 0)
-                K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[3][0]), sd), [dx], 1, stride, 0, accumulate=True)
-            else:
-                K.conv_dgrad([dz1], wt1, [dx], 1, 1, 0, res=[dz3])      # + identity gradient, in the epilogue
-        if has_down:
-            wgrad(3, x, dz3, 1, stride, 0, sd, db3)
+        b3 = P[2][2]
+        s_ = _sink(b3) if need[3 + 5 * 2 + 2] else None
+        dz3, db3 = K.relu_bwd_colsum(y, dy.contiguous(), True, colsum_into=s_ if s_ is not None else K.zeros_f32(y.shape[3], x.device))
+        dx, grads = _bottleneck_backward(x, o1, o2, s1, s2, s3, sd, P, list(need[3:]), need[0], stride, eps, dz3, db3)
         return (dx, None, None, *grads)
+
+
+def _bottleneck_backward(x, o1, o2, s1, s2, s3, sd, P, need_p, need_x, stride, eps, dz3, db3, out_mask=None):
+    """Backward of one bottleneck given dz3 = dy * (y > 0) and its column sums db3 (a [C] vector that may BE d beta's flat slot,
+    or a replicated [copies, C] accumulator of a gradient convolution's epilogue).  need_p: needs-gradient flags of the block's
+    parameters, 5 per convolution (w, gamma, beta, mean, var).  Returns (dx, grads).  With `out_mask` (the block's own input x,
+    which is the previous block's post-ReLU output) the last input-gradient launch ALSO applies that ReLU's mask and column-sums
+    the result into a fresh replicated accumulator: it then returns ((dz3 of the previous block, its db3), grads) -- the
+    stand-alone ReLU-backward pass between two blocks of a stage disappears (identity-shortcut blocks only)."""
+    has_down = sd is not None
+    dev = x.device
+    grads = [None] * (5 * len(P))
+
+    def wgrad(idx, xin, dz, k, s, pad, scale, dbeta):
+        """dW (scaled by the folded BN), d gamma, d beta of conv `idx`"""
+        w, g, b, m, v = P[idx]
+        base = 5 * idx
+        if not (need_p[base] or need_p[base + 1] or need_p[base + 2]):
+            return
+        wk = ohwi(w)
+        trail = None
+        if WGRAD_TRAIL and all((not need_p[base + q]) or _sink(t) is not None for q, t in enumerate((w, g, b))):
+            trail = _Trail(dev, xin, dz, scale, dbeta)
+            trail.__enter__()
+        try:
+            _wgrad_body(idx, xin, dz, k, s, pad, scale, dbeta, w, g, b, m, v, base, wk)
+        finally:
+            if trail is not None:
+                trail.__exit__(None, None, None)
+
+    def _wgrad_body(idx, xin, dz, k, s, pad, scale, dbeta, w, g, b, m, v, base, wk):
+        part, S = K.conv_wgrad_partials([xin], [dz], k, s, pad)
+        rowdot = K.zeros_f32(scale.numel(), scale.device) if need_p[base + 1] else None
+        grads[5 * idx] = _emit_wgrad(w, part, S, wk, scale, rowdot)
+        if need_p[base + 1]:
+            # a replicated [copies, C] accumulator is folded here; the fold lands in d beta's flat slot (zero at
+            # this point) or in a new tensor
+            rep = dbeta.dim() == 2
+            bs_fold = (_sink(b) if need_p[base + 2] else None) if rep else None
+            fold = None if not rep else (bs_fold if bs_fold is not None else torch.empty_like(dbeta[0]))
+            gs = _sink(g)
+            if gs is not None:                      # the slot is zero: plain store == accumulation
+                K.bn_dgamma(rowdot, dbeta, m, v, eps, out=gs, dbeta_out=fold)
+                _sunk(g)
+            else:
+                grads[5 * idx + 1] = K.bn_dgamma(rowdot, dbeta, m, v, eps, dbeta_out=fold)
+            if rep:
+                dbeta = fold
+        elif dbeta.dim() == 2:
+            dbeta = dbeta.sum(0)
+        if need_p[base + 2]:
+            bs = _sink(b)
+            if bs is None:
+                grads[5 * idx + 2] = dbeta
+            else:
+                if dbeta.data_ptr() != bs.data_ptr():   # (the projection shortcut shares conv3's column sums)
+                    bs.add_(dbeta)
+                _sunk(b)
+
+    wgrad(2, o2, dz3, 1, 1, 0, s3, db3)
+    dz2 = torch.empty_like(o2)
+    # the epilogues of the two input-gradient convolutions add their column sums into 8 replicated rows (hundreds of
+    # tiles adding to ONE row would serialise on the memory-side atomic unit); wgrad()'s bn_dgamma folds them
+    rep_slot = lambda n: K.zeros_f32(K.COLSUM_COPIES * n, dev).view(K.COLSUM_COPIES, n)
+    db2 = rep_slot(o2.shape[3])
+    K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[2][0]), s3), [dz2], 1, 1, 0, relu_mask=[o2], colsum=db2)
+    wgrad(1, o1, dz2, 3, stride, 1, s2, db2)
+    dz1 = torch.empty_like(o1)
+    db1 = rep_slot(o1.shape[3])
+    K.conv_dgrad([dz2], K.weight_transpose(ohwi(P[1][0]), s2), [dz1], 3, stride, 1, relu_mask=[o1], colsum=db1)
+    wgrad(0, x, dz1, 1, 1, 0, s1, db1)
+    dx = None
+    if need_x:
+        dx = torch.empty_like(x)
+        wt1 = K.weight_transpose(ohwi(P[0][0]), s1)
+        if has_down:
+            assert out_mask is None, "the fused ReLU mask needs an identity shortcut (one launch writes every pixel of dx)"
+            K.conv_dgrad([dz1], wt1, [dx], 1, 1, 0)
+            K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[3][0]), sd), [dx], 1, stride, 0, accumulate=True)
+        elif out_mask is not None:      # + identity gradient, the previous block's ReLU mask and its d-beta column sums, in the epilogue
+            db_prev = rep_slot(x.shape[3])
+            K.conv_dgrad([dz1], wt1, [dx], 1, 1, 0, res=[dz3], relu_mask=[out_mask], colsum=db_prev)
+            dx = (dx, db_prev)
+        else:
+            K.conv_dgrad([dz1], wt1, [dx], 1, 1, 0, res=[dz3])      # + identity gradient, in the epilogue
+    if has_down:
+        wgrad(3, x, dz3, 1, stride, 0, sd, db3)
+    return dx, grads
+
+
+class ResLayerFn(Function):
+    """A whole ResNet stage (res_layer.py:57-63: one projection block + identity blocks) as ONE autograd node.  Forward: the
+    launches of the blocks' BottleneckFn, one after the other.  Backward: the blocks' hand-scheduled backward passes chained
+    directly -- the gradient a block hands to its predecessor is produced by ONE input-gradient launch that already carries
+    the predecessor's output-ReLU mask and the column sums for its d beta, so only the LAST block of the stage (whose output
+    also leaves the stage) runs a stand-alone ReLU backward: 3 instead of 13 such passes per step for ResNet-50, and 3 autograd
+    nodes instead of 13."""
+
+    @staticmethod
+    def forward(ctx, x, strides, eps: float, counts, *params):
+        K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
+        dev = x.device
+        blocks, off = [], 0
+        for n in counts:                             # parameters per block: 15 (identity shortcut) or 20 (projection)
+            blocks.append(params[off:off + n])
+            off += n
+        saved, meta = [], []
+
+        def cba(inp, prm, k, s, pad, res, relu):
+            w, g, b, m, v = prm
+            wk = ohwi(w)
+            scale, shift = _bn_fold_cached(g, b, m, v, eps)
+            N, H, W_, _ = inp.shape
+            out = torch.empty((N, K.conv_out_size(H, k, s, pad), K.conv_out_size(W_, k, s, pad), wk.shape[0]),
+                              dtype=inp.dtype, device=dev)
+            K.conv_forward([inp], wk, [out], k, s, pad, scale=scale, shift=shift,
+                           res=None if res is None else [res], relu=relu)
+            return out, scale
+
+        h = x
+        for bp, stride in zip(blocks, strides):
+            has_down = len(bp) == 20
+            P = [bp[5 * i:5 * i + 5] for i in range(4 if has_down else 3)]
+            o1, s1 = cba(h, P[0], 1, 1, 0, None, True)
+            o2, s2 = cba(o1, P[1], 3, stride, 1, None, True)
+            sd, idn = None, h
+            if has_down:
+                idn, sd = cba(h, P[3], 1, stride, 0, None, False)
+            y, s3 = cba(o2, P[2], 1, 1, 0, idn, True)
+            meta.append((stride, has_down, len(saved)))
+            saved += [h, o1, o2, y, s1, s2, s3] + ([sd] if has_down else [])
+            h = y
+        ctx.meta, ctx.eps, ctx.counts, ctx.nsaved = meta, eps, counts, len(saved)
+        ctx.save_for_backward(*saved, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        acts, params = saved[:ctx.nsaved], saved[ctx.nsaved:]
+        need = ctx.needs_input_grad
+        blocks, need_b, off = [], [], 0
+        for n in ctx.counts:
+            blocks.append(params[off:off + n])
+            need_b.append(list(need[4 + off:4 + off + n]))
+            off += n
+        grads_all = [None] * len(params)
+        nb = len(blocks)
+        dz3 = db3 = None
+        dx = None
+        for i in range(nb - 1, -1, -1):
+            stride, has_down, a0 = ctx.meta[i]
+            x, o1, o2, y, s1, s2, s3 = acts[a0:a0 + 7]
+            sd = acts[a0 + 7] if has_down else None
+            bp = blocks[i]
+            P = [bp[5 * j:5 * j + 5] for j in range(4 if has_down else 3)]
+            if i == nb - 1:       # the stage's output gradient arrives from outside: the one stand-alone ReLU backward
+                b3 = P[2][2]
+                s_ = _sink(b3) if need_b[i][5 * 2 + 2] else None
+                dz3, db3 = K.relu_bwd_colsum(y, dy.contiguous(), True,
+                                             colsum_into=s_ if s_ is not None else K.zeros_f32(y.shape[3], x.device))
+            # block i hands block i-1 its dz3 directly when block i has an identity shortcut (x IS block i-1's ReLU output)
+            fuse = i > 0 and not has_down
+            need_x = need[0] if i == 0 else True
+            out, g = _bottleneck_backward(x, o1, o2, s1, s2, s3, sd, P, need_b[i], need_x, stride, ctx.eps, dz3, db3,
+                                          out_mask=x if fuse else None)
+            base = sum(ctx.counts[:i])
+            grads_all[base:base + len(g)] = g
+            if i == 0:
+                dx = out
+            elif fuse:
+                dz3, db3 = out
+            else:                  # (a projection block in the middle of a stage: not a ResNet layout, kept general)
+                prev_y = acts[ctx.meta[i - 1][2] + 3]
+                pb3 = blocks[i - 1][5 * 2 + 2]
+                s_ = _sink(pb3) if need_b[i - 1][5 * 2 + 2] else None
+                dz3, db3 = K.relu_bwd_colsum(prev_y, out, True,
+                                             colsum_into=s_ if s_ is not None else K.zeros_f32(prev_y.shape[3], x.device))
+        return (dx, None, None, None, *grads_all)
 
 
 def _bias_grad(b: Tensor, dy: Tensor, rows: Optional[Tensor] = None):

@@ -325,8 +325,18 @@ class ResNet(nn.Module):
             layer = getattr(self, name)
             ctxm = torch.no_grad() if not torch.is_grad_enabled() else torch.enable_grad()
             with ctxm:
-                for blk in layer:
-                    h = blk(h)
+                if Fn.RES_LAYER_NODE and torch.is_grad_enabled() and all(
+                        any(p.requires_grad for p in blk.parameters()) for blk in layer):
+                    # the stage as ONE autograd node: its backward hands each block's dz3 straight to the block before it
+                    params, counts = [], []
+                    for blk in layer:
+                        pp = blk._params()
+                        params += pp
+                        counts.append(len(pp))
+                    h = Fn.ResLayerFn.apply(h, tuple(blk.stride for blk in layer), layer[0].bn1.eps, tuple(counts), *params)
+                else:
+                    for blk in layer:
+                        h = blk(h)
             if i in self.out_indices:
                 outs.append(_nchw(h))
         return tuple(outs)

@@ -182,3 +182,47 @@ def test_fused_bottleneck_block(cin, planes, stride, down):
     assert relerr(xg.grad.permute(0, 3, 1, 2).cpu(), x.grad) < 1e-4
     for k, p in blk.named_parameters():
         assert relerr(p.grad.cpu(), ref[k].grad) < 3e-4, k
+
+
+@pytest.mark.parametrize("sink", [False, True])
+def test_res_layer_node_equals_the_chain_of_bottleneck_nodes(sink, monkeypatch):
+    """ResLayerFn: a whole stage (projection block + identity blocks, res_layer.py:57-63) as one autograd node whose backward
+    hands each block's dz3 straight to the block before it (the predecessor's ReLU mask and d-beta column sums ride in the
+    epilogue of ONE input-gradient launch).  Same outputs bit for bit and the same gradients (float-atomic order only) as the
+    chain of per-block nodes with their stand-alone ReLU backward passes -- with plain autograd accumulation and with the
+    trainer's flat gradient slots (sink = True)."""
+    from erd_amd import functional as Fn
+    from erd_amd.modules import ResNet
+    from erd_amd.engine import FlatParams
+
+    def build():
+        torch.manual_seed(5)
+        net = ResNet(50, frozen_stages=1, norm_eval=True).cuda().train()
+        with torch.no_grad():
+            for m in net.modules():
+                if hasattr(m, "running_var"):
+                    m.running_var.uniform_(0.5, 1.5); m.running_mean.normal_(0, 0.1); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+        return net
+
+    x = G.randn(7, 2, 3, 96, 128).cuda()
+    res = {}
+    for node in (False, True):
+        monkeypatch.setattr(Fn, "RES_LAYER_NODE", node)
+        net = build()
+        flat = None
+        if sink:
+            named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+            named.reverse()
+            flat = FlatParams(named, x.device)
+            flat.zero_grad()
+        outs = net(x)
+        loss = sum((o.float() * G.randn(20 + i, *o.shape).cuda()).sum() for i, o in enumerate(outs))
+        loss.backward()
+        Fn.trail_join(x.device)
+        torch.cuda.synchronize()
+        res[node] = ([o.detach().clone() for o in outs], {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)
+    assert res[False][1].keys() == res[True][1].keys() and len(res[True][1]) > 100
+    for k, g in res[False][1].items():
+        assert relerr(res[True][1][k].cpu(), g.cpu()) < 2e-5, k

@@ -43,6 +43,68 @@ __global__ __launch_bounds__(256) void mfma_loop(float* sink, unsigned long long
     if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = c1 - c0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
+// hand-placed stream (inline asm, accumulators in VGPRs): NACC independent accumulators visited round-robin, 4 different
+// A operands and NACC different B operands -- the issue pattern of the Winograd kernel's MFMA waves is NACC = 4
+template <int NACC, int W32>
+__global__ __launch_bounds__(256) void mfma_asm_loop(float* sink, unsigned long long* ticks, int iters) {
+    f32x4 acc[NACC];
+    f32x16 acc32[NACC];
+    float a[4], b[NACC];
+    for (int q = 0; q < NACC; ++q) {
+        acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 16; ++r) acc32[q][r] = 0.f;
+        b[q] = 0.25f + 1e-3f * ((threadIdx.x + q) & 15);
+    }
+    for (int m = 0; m < 4; ++m) a[m] = 1e-3f * ((threadIdx.x * 7 + m) & 31);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) {
+                if constexpr (W32) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc32[q]) : "v"(a[m]), "v"(b[q]));
+                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a[m]), "v"(b[q]));
+            }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int q = 0; q < NACC; ++q) s += acc[q][0] + acc[q][3] + acc32[q][5];
+    if (s == 123.456f) sink[0] = s;
+    if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = c1 - c0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+template <int NACC, int W32>
+void run_asm(int wg_per_cu, int iters) {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int grid = prop.multiProcessorCount * wg_per_cu;
+    float* sink;
+    unsigned long long* ticks;
+    hipMalloc(&sink, 4);
+    hipMalloc(&ticks, sizeof(unsigned long long) * 2 * grid);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((mfma_asm_loop<NACC, W32>), dim3(grid), dim3(256), 0, 0, sink, ticks, iters / 10);
+    hipDeviceSynchronize();
+    std::vector<double> tfs;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((mfma_asm_loop<NACC, W32>), dim3(grid), dim3(256), 0, 0, sink, ticks, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flop = W32 ? 32.0 * 32 * 2 * 2 : 16.0 * 16 * 4 * 2;
+        tfs.push_back((double)grid * 4 * 4.0 * NACC * iters * flop / (ms * 1e-3) / 1e12);
+    }
+    std::sort(tfs.begin(), tfs.end());
+    printf("asm stream %-24s %2d accumulators round-robin (VGPR), %d WG/CU x 4 waves: %8.1f TFLOP/s (median of 5; min %.1f max %.1f)\n",
+           W32 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", NACC, wg_per_cu, tfs[2], tfs[0], tfs[4]);
+    hipFree(sink);
+    hipFree(ticks);
+}
+
 template <int KIND, int NACC>
 void run(const char* name, double flop_per_mfma, int wg_per_cu, int iters) {
     hipDeviceProp_t prop;
@@ -86,6 +148,14 @@ int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     printf("%s, %d CUs, clockRate %.0f MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1e3);
+    for (int wg = 1; wg <= 2; ++wg) {
+        run_asm<2, 0>(wg, 20000);
+        run_asm<4, 0>(wg, 10000);
+        run_asm<8, 0>(wg, 5000);
+        run_asm<16, 0>(wg, 2500);
+        run_asm<2, 1>(wg, 10000);
+        run_asm<4, 1>(wg, 5000);
+    }
     for (int wg = 1; wg <= 2; ++wg) {
         run<0, 4>("v_mfma_f32_32x32x2_f32", 32.0 * 32 * 2 * 2, wg, 40000);
         run<0, 2>("v_mfma_f32_32x32x2_f32", 32.0 * 32 * 2 * 2, wg, 80000);
