@@ -50,7 +50,7 @@ class WgradDesc(C.Structure):
                 ("dy", i32 * ERD_MAX_TAPS), ("dx", i32 * ERD_MAX_TAPS),
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
                 ("part", C.c_void_p), ("nsplit", i32), ("bf16_multiplicands", i32),
-                ("x_bf16", i32), ("dz_bf16", i32)]
+                ("x_bf16", i32), ("dz_bf16", i32), ("limbs3", i32)]
 
 
 class BnFoldItem(C.Structure):

@@ -1068,6 +1068,215 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
 }
 
 // -------------------------------------------------------------------------------------------------
+// The three-tap weight gradient in the THREE-LIMB form (erd_wgrad_desc::limbs3): fp32 dz and x, fp32 partial slabs, every
+// product formed on the bf16 matrix cores from exact limb splits of BOTH operands (see conv_igemm_kernel<..., X3>).
+//   * A K-slice is 16 output pixels of one image row (x: 18 entries with the one-pixel halo), as in the fp32 kernel.  The
+//     bf16 MFMA wants 8 consecutive PIXELS of one channel per lane while memory is pixel-major: each thread loads a
+//     4-pixel x 4-channel micro-tile (four 16-B loads), splits its 16 values into limbs (and / sub / and / sub, exact) and
+//     stores them transposed -- 8 bytes (4 pixels of one channel) per limb plane -- into channel-major LDS rows:
+//     dz [3 planes][BMR co][16 px] (32-B rows, chunk XOR-swizzled), x [3 planes][64 ci][18 px] (48-B rows: 16 lanes x 12
+//     banks tile all 64 banks).  Every value is split exactly once.
+//   * tap kx of the kernel row reads x entries k + kx.  A lane holds entries 8h .. 8h+7 as four packed dwords plus the dword
+//     of entries 8h+8, 8h+9: kx = 0 is (d0..d3), kx = 2 is (d1..d4) -- a renaming --, kx = 1 is four v_alignbit_b32.
+//   * 128 (or 64) output channels x 64 input channels x 3 taps per workgroup, 2 x 2 waves of (64 | 32) x 32: 96 accumulator
+//     registers, 36 MFMAs per k16 step and wave for 9 LDS reads and 12 shift operations; LDS double-buffered (42 KB).
+// Partial slabs / split-K / reduce kernel are shared with the other weight-gradient kernels.
+// -------------------------------------------------------------------------------------------------
+#ifndef ERD_W3X3_MINW
+#define ERD_W3X3_MINW 3      // three workgroups per CU (168 registers, 42 KB of LDS each): 181 vs 171 TF at two
+#endif
+template <int FM>
+__global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_kernel(const erd_wgrad_desc p, const int nslices_xcd) {
+    const int nslices = nslices_xcd & 0x3fffffff;
+    constexpr int BK = 16, BX = BK + 2, BMR = FM * 64, BNR = 64;
+    constexpr int A_ROWB = 32, B_ROWB = 48;                    // bytes per LDS row of one plane
+    constexpr int A_PL = BMR * A_ROWB, B_PL = BNR * B_ROWB;    // bytes per plane
+    constexpr int BUF = 3 * (A_PL + B_PL);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* offa = reinterpret_cast<int*>(smem + 2 * BUF);        // [2][BK]
+    int* offb = offa + 2 * BK;                                 // [2][BX]
+
+    const int tid = threadIdx.x;
+    const int nci = (p.Cin + BNR - 1) / BNR, nco = (p.Cout + BMR - 1) / BMR;
+    int wg = blockIdx.x;
+    if (nslices_xcd >> 30) {
+        const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bx = wg % (nci * 3), by = (wg / (nci * 3)) % nco, bz = wg / (nci * 3 * nco);
+    const int ky = bx / nci;
+    const int ci0 = (bx % nci) * BNR;
+    const int co0 = by * BMR;
+    const int per = (nslices + p.nsplit - 1) / p.nsplit;
+    const int kt_begin = bz * per;
+    const int kt_end = min(nslices, kt_begin + per);
+
+    auto compute_offsets = [&](int kt, int slot) {
+        if (tid < BX) {
+            int oa = -1, ob = -1;
+            if (kt < kt_end) {
+                int l = 0, q = kt;
+#pragma unroll 1
+                for (; l < p.nseg - 1; ++l) {
+                    const int cnt = p.seg[l].N * p.seg[l].GH * ((p.seg[l].GW + BK - 1) / BK);
+                    if (q < cnt) break;
+                    q -= cnt;
+                }
+                const erd_wgrad_seg& g = p.seg[l];
+                const int cpr = (g.GW + BK - 1) / BK;
+                const int c = q % cpr;
+                const int rowi = q / cpr;
+                const int a = rowi % g.GH, n = rowi / g.GH;
+                const int bcol = c * BK + tid - 1;
+                const int ih = a + ky - 1;
+                if ((unsigned)bcol < (unsigned)g.IW && (unsigned)ih < (unsigned)g.IH)
+                    ob = (int)(g.x_off + n * g.x_nstride) + (ih * g.IW + bcol) * p.Cin;
+                const int zcol = c * BK + tid;
+                if (tid < BK && zcol < g.GW) oa = (int)(g.dz_off + n * g.dz_nstride) + (a * g.OW + zcol) * p.Cout;
+            }
+            if (tid < BK) offa[slot * BK + tid] = oa;
+            offb[slot * BX + tid] = ob;
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz), 0, (int)(p.dz_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(p.x_elems * 4), 0x00020000);
+
+    // ---- staging roles: threads [0, NA) own a dz micro-tile (4 px x 4 co), threads [128, 128 + 80) an x micro-tile (4 entries x 4 ci)
+    constexpr int NA = (BMR / 4) * 4;                           // dz micro-tiles: (BMR / 4) channel groups x 4 pixel groups
+    const bool is_a = tid < NA, is_b = tid >= 128 && tid < 128 + 80;
+    const int tb = tid - 128;
+    const int cg = is_a ? tid % (BMR / 4) : tb % 16;            // channel group
+    const int pg = is_a ? tid / (BMR / 4) : tb / 16;            // group of 4 pixels (dz: 0..3) / entries (x: 0..4)
+    const int col = is_a ? co0 + cg * 4 : ci0 + cg * 4;
+    const bool cok = is_a ? (col < p.Cout) : (is_b && col < p.Cin);
+    float4 rv[4];
+    auto load_global = [&](int slot) {
+        if (is_a || is_b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = pg * 4 + i;
+                const int o = is_a ? offa[slot * BK + e] : (e < BX ? offb[slot * BX + e] : -1);
+                rv[i] = buf_load16(is_a ? rs_dz : rs_x, (o >= 0 && cok) ? (unsigned)(o + col) * 4u : OOB);
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        if (!(is_a || is_b)) return;
+        constexpr unsigned TOP = 0xffff0000u, SEL = 0x07060302u;
+        const float v[4][4] = {{rv[0].x, rv[0].y, rv[0].z, rv[0].w}, {rv[1].x, rv[1].y, rv[1].z, rv[1].w},
+                               {rv[2].x, rv[2].y, rv[2].z, rv[2].w}, {rv[3].x, rv[3].y, rv[3].z, rv[3].w}};     // [pixel][channel]
+        char* base = smem + buf * BUF + (is_a ? 0 : 3 * A_PL);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float r1[4], r2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r1[i] = v[i][c] - __uint_as_float(__float_as_uint(v[i][c]) & TOP);
+                r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & TOP);
+            }
+            const int row = cg * 4 + c;
+            uint2 hi, mid, lo;
+            hi.x = __builtin_amdgcn_perm(__float_as_uint(v[1][c]), __float_as_uint(v[0][c]), SEL);
+            hi.y = __builtin_amdgcn_perm(__float_as_uint(v[3][c]), __float_as_uint(v[2][c]), SEL);
+            mid.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), SEL);
+            mid.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), SEL);
+            lo.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), SEL);
+            lo.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), SEL);
+            // dz: 32-B rows, 16-B chunk (pg >> 1) swizzled by (row >> 3) & 1; x: 48-B rows, entry e at byte 2 e
+            const int off = is_a ? row * A_ROWB + (((pg >> 1) ^ ((row >> 3) & 1)) << 4) + ((pg & 1) << 3) : row * B_ROWB + pg * 8;
+            const int plane = is_a ? A_PL : B_PL;
+            *reinterpret_cast<uint2*>(base + off) = hi;
+            *reinterpret_cast<uint2*>(base + plane + off) = mid;
+            *reinterpret_cast<uint2*>(base + 2 * plane + off) = lo;
+        }
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    f32x16 acc[3][FM];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    if (kt_begin < kt_end) {
+        compute_offsets(kt_begin, 0);
+        __syncthreads();
+        load_global(0);
+        compute_offsets(kt_begin + 1, 1);
+        store_lds(0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            const bool more = kt + 1 < kt_end;
+            if (more) load_global(buf ^ 1);
+            compute_offsets(kt + 2, buf);
+            const char* Ab = smem + buf * BUF;
+            const char* Bb = Ab + 3 * A_PL;
+            // fragments: dz rows (wm * FM + i) * 32 + li, chunk h; x row wn * 32 + li, entries 8h .. 8h + 9
+            u4v fa[FM][3];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = (wm * FM + i) * 32 + li;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fa[i][pl] = *reinterpret_cast<const u4v*>(Ab + pl * A_PL + row * A_ROWB + ((h ^ ((row >> 3) & 1)) << 4));
+            }
+            const int brow = wn * 32 + li;
+            u4v fb[3];
+            unsigned fe[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fb[pl] = *reinterpret_cast<const u4v*>(Bb + pl * B_PL + brow * B_ROWB + (h << 4));
+                fe[pl] = *reinterpret_cast<const unsigned*>(Bb + pl * B_PL + brow * B_ROWB + (h << 4) + 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bf16x8 xb[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    u4v s_;
+                    if (t == 0) s_ = fb[pl];
+                    else if (t == 2) { s_[0] = fb[pl][1]; s_[1] = fb[pl][2]; s_[2] = fb[pl][3]; s_[3] = fe[pl]; }
+                    else {
+                        s_[0] = __builtin_amdgcn_alignbit(fb[pl][1], fb[pl][0], 16);
+                        s_[1] = __builtin_amdgcn_alignbit(fb[pl][2], fb[pl][1], 16);
+                        s_[2] = __builtin_amdgcn_alignbit(fb[pl][3], fb[pl][2], 16);
+                        s_[3] = __builtin_amdgcn_alignbit(fe[pl], fb[pl][3], 16);
+                    }
+                    xb[pl] = __builtin_bit_cast(bf16x8, s_);
+                }
+#define ERD_W3(APL, BPL)                                                                                              \
+                _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                        \
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][APL]), xb[BPL], acc[t][i], 0, 0, 0);
+                ERD_W3(0, 2) ERD_W3(0, 1) ERD_W3(1, 1) ERD_W3(2, 0) ERD_W3(1, 0) ERD_W3(0, 0)
+#undef ERD_W3
+            }
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* __restrict__ part = p.part + (int64_t)bz * p.Cout * 9 * p.Cin;
+    const int ci = ci0 + wn * 32 + li;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (co < p.Cout) part[((int64_t)co * 9 + ky * 3 + t) * p.Cin + ci] = acc[t][i][r];
+                }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // weight gradient on the bf16 matrix cores (erd_wgrad_desc::bf16_multiplicands): same GEMM over pixels, but the MFMA
 // wants 8 consecutive K values (pixels) of ONE channel per lane while memory is pixel-major.  Each thread therefore
 // loads an 8-pixel x 4-channel micro-tile (8 coalesced 16-B loads), rounds to bf16 and transposes it in registers
@@ -1636,6 +1845,23 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
     static const int variant = getenv("ERD_WGRAD_VARIANT") ? atoi(getenv("ERD_WGRAD_VARIANT")) : 1;   // tuning aid
     const char* row3_env = getenv("ERD_WGRAD_ROW3");          // read per call: tests flip it in-process
     const int row3 = row3_env ? atoi(row3_env) : 1;
+    if (row3 && d->limbs3 && d->Cin % 4 == 0 && erd_wgrad_row3_slices(d) > 0) {
+        // three-limb form: 128 (Cout > 64) or 64 output channels x 64 input channels x 3 taps per workgroup
+        const int nslices = erd_wgrad_row3_slices(d);
+        const int fm = d->Cout > 64 ? 2 : 1;
+        const int nci = (d->Cin + 63) / 64, nco = (d->Cout + fm * 64 - 1) / (fm * 64);
+        const size_t lds = (size_t)2 * 3 * (fm * 64 * 32 + 64 * 48) + 2 * (16 + 18) * sizeof(int);
+        void (*kern)(const erd_wgrad_desc, const int) = fm == 2 ? conv_wgrad_row3_x3_kernel<2> : conv_wgrad_row3_x3_kernel<1>;
+        static bool attr_done3[2] = {false, false};
+        if (!attr_done3[fm - 1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done3[fm - 1] = true;
+        }
+        static const int row3_xcd = getenv("ERD_WGRAD_XCD") ? atoi(getenv("ERD_WGRAD_XCD")) : 1;
+        hipLaunchKernelGGL(kern, dim3(nci * 3 * nco * d->nsplit), dim3(NTHREADS), lds, (hipStream_t)stream, *d,
+                           nslices | (row3_xcd ? (1 << 30) : 0));
+        return erd::check_launch("conv_wgrad_row3_x3");
+    }
     if (row3 && erd_wgrad_row3_slices(d) > 0) {
         const int nslices = erd_wgrad_row3_slices(d);
         const int bme = d->Cout <= 64 ? 64 : (d->Cout <= 96 ? 96 : 128);

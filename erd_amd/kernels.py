@@ -847,6 +847,9 @@ def _shape_tag(d, k: int, stride: int) -> str:
     return f"px{px} {d.Cin}->{d.Cout} k{k}s{stride}"
 
 
+WGRAD_X3 = _os.environ.get("ERD_WGRAD_X3", "1") != "0"      # three-limb form of the three-tap weight gradient in the f32x3 mode (A/B aid)
+
+
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * ntaps
     kt = (npix + 31) // 32
@@ -870,7 +873,7 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     xoff = tuple((x.data_ptr() - xb) // x.element_size() for x in xs)
     zoff = tuple((z.data_ptr() - zb) // z.element_size() for z in dzs)
     cache = _desc_cache()
-    key = ("wgrad", k, stride, pad, _geom(xs), _geom(dzs), xoff, zoff, COMPUTE, _os.environ.get("ERD_WGRAD_ROW3", "1"))
+    key = ("wgrad", k, stride, pad, _geom(xs), _geom(dzs), xoff, zoff, COMPUTE, _os.environ.get("ERD_WGRAD_ROW3", "1"), WGRAD_X3)
     ent = cache.get(key)
     if ent is None:
         ent = cache[key] = _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff)
@@ -911,7 +914,13 @@ def _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff):
     d.bf16_multiplicands = 1 if COMPUTE == "bf16" else 0
     d.x_bf16, d.dz_bf16 = _stored_bf16(xs), _stored_bf16(dzs)
     row3 = int(_lib.load().erd_wgrad_row3_slices(C.byref(d))) if _os.environ.get("ERD_WGRAD_ROW3", "1") != "0" else 0
-    if row3:      # three taps per workgroup, two workgroups per CU: ONE whole dispatch round of (cout, cin, ky, split) workgroups
+    d.limbs3 = 1 if (COMPUTE == "f32x3" and row3 and WGRAD_X3) else 0
+    if row3 and d.limbs3:      # three-limb form: (128 | 64) output channels x 64 input channels x 3 taps per workgroup, one dispatch round
+        bmr = 128 if Cout > 64 else 64
+        groups = ((Cout + bmr - 1) // bmr) * ((Cin + 63) // 64) * 3
+        target = int(_os.environ.get("ERD_WGRAD_ROW3_X3_TARGET", "768"))      # three workgroups per CU: one dispatch round
+        S = int(max(1, min(target // groups, row3 // 16 if row3 >= 16 else 1, 512)))
+    elif row3:      # three taps per workgroup, two workgroups per CU: ONE whole dispatch round of (cout, cin, ky, split) workgroups
         # (measured best: 2 or 3 rounds pay more partial-slab traffic than they gain; a ragged extra round costs 15-40 %)
         bme = 64 if Cout <= 64 else (96 if Cout <= 96 else 128)        # rows of the kernel's output tile (erd_conv_wgrad)
         groups = ((Cout + bme - 1) // bme) * ((Cin + 127) // 128) * 3

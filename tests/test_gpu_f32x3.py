@@ -103,3 +103,34 @@ def test_f32x3_multilevel_and_streamk_launches(K):
             assert rel64(to_nchw(o2), ref) < 6e-7       # (K = 2048: the native kernel reads 3.4e-7 here)
     finally:
         K.WINOGRAD = keep
+
+
+@pytest.mark.parametrize("Cin,Cout,sizes", [(256, 256, [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]), (128, 128, [(26, 30)]),
+                                             (256, 80, [(13, 21), (7, 11)]), (256, 68, [(13, 21)]), (512, 512, [(9, 17)]),
+                                             (64, 64, [(20, 36)])])
+def test_f32x3_three_tap_weight_gradient_is_as_close_to_fp64_as_the_fp32_kernel(K, Cin, Cout, sizes):
+    """the three-limb form of the 3x3 / stride-1 weight gradient (both operands split in the loader, kernel-row taps by register
+    shifts of the packed pixel vectors) against an fp64 evaluation, next to the fp32-MFMA three-tap kernel: ragged widths (not
+    multiples of 16), several levels summed in one launch, 80 / 68 / 64 output channels"""
+    N = 2
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(41, N, A, Cin)
+    dz = G.randn(42, N, A, Cout)
+    ref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64)
+    off = 0
+    for (h, w) in sizes:
+        xl = x[:, off:off + h * w].reshape(N, h, w, Cin).permute(0, 3, 1, 2).double()
+        dl = dz[:, off:off + h * w].reshape(N, h, w, Cout).permute(0, 3, 1, 2).double()
+        ref += torch.nn.grad.conv2d_weight(xl, (Cout, Cin, 3, 3), dl, stride=1, padding=1)
+        off += h * w
+    ref = ref.permute(0, 2, 3, 1)                  # [Cout, 3, 3, Cin]
+    xg, dg = x.cuda(), dz.cuda()
+    err = {}
+    for mode in ("f32", "f32x3"):
+        K.set_compute(mode)
+        part, S = K.conv_wgrad_partials(K.level_views(xg, sizes), K.level_views(dg, sizes), 3, 1, 1)
+        dW = torch.empty((Cout, 3, 3, Cin), device="cuda")
+        K.wgrad_reduce(part, S, dW, None, dW, False, None)
+        err[mode] = rel64(dW.cpu(), ref)
+    print("weight gradient %d -> %d, rel L2 to fp64: fp32 MFMA %.2e | three-limb %.2e" % (Cin, Cout, err["f32"], err["f32x3"]))
+    assert err["f32x3"] <= max(1.5 * err["f32"], 3e-7), err
