@@ -1085,11 +1085,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
 #ifndef ERD_W3X3_MINW
 #define ERD_W3X3_MINW 3      // three workgroups per CU (168 registers, 42 KB of LDS each): 181 vs 171 TF at two
 #endif
-template <int FM>
+// ROW3 = false: the same machinery for every OTHER layer (1x1, stride 2): one tap per workgroup, K-slices = 16 consecutive pixels
+// of the concatenated pixel axis with a per-pixel offset table (as conv_wgrad_kernel), no halo, and -- with a third of the
+// products per loaded byte -- 128 input channels per workgroup (FN = 2: 2 x 2 waves of 64 x 64).
+template <int FM, int FN, bool ROW3>
 __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_kernel(const erd_wgrad_desc p, const int nslices_xcd) {
     const int nslices = nslices_xcd & 0x3fffffff;
-    constexpr int BK = 16, BX = BK + 2, BMR = FM * 64, BNR = 64;
-    constexpr int A_ROWB = 32, B_ROWB = 48;                    // bytes per LDS row of one plane
+    constexpr int NT = ROW3 ? 3 : 1;
+    constexpr int BK = 16, BX = ROW3 ? BK + 2 : BK, BMR = FM * 64, BNR = FN * 64;
+    constexpr int A_ROWB = 32, B_ROWB = ROW3 ? 48 : 32;        // bytes per LDS row of one plane
     constexpr int A_PL = BMR * A_ROWB, B_PL = BNR * B_ROWB;    // bytes per plane
     constexpr int BUF = 3 * (A_PL + B_PL);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1103,15 +1107,46 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
         const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int bx = wg % (nci * 3), by = (wg / (nci * 3)) % nco, bz = wg / (nci * 3 * nco);
-    const int ky = bx / nci;
+    const int nbx = nci * (ROW3 ? 3 : p.ntaps);
+    const int bx = wg % nbx, by = (wg / nbx) % nco, bz = wg / (nbx * nco);
+    const int ky = bx / nci;                                   // ROW3: kernel row; otherwise the tap index
     const int ci0 = (bx % nci) * BNR;
     const int co0 = by * BMR;
     const int per = (nslices + p.nsplit - 1) / p.nsplit;
     const int kt_begin = bz * per;
     const int kt_end = min(nslices, kt_begin + per);
 
+    int P = 0;                                                 // (generic form: pixels of all maps)
+    if (!ROW3)
+        for (int l = 0; l < p.nseg; ++l) P += p.seg[l].N * p.seg[l].GH * p.seg[l].GW;
     auto compute_offsets = [&](int kt, int slot) {
+        if (!ROW3) {
+            if (tid < BK) {
+                int pp = kt * BK + tid, oa = -1, ob = -1;
+                if (pp < P && kt < kt_end) {
+                    int l = 0;
+#pragma unroll 1
+                    for (; l < p.nseg - 1; ++l) {
+                        const int pl = p.seg[l].N * p.seg[l].GH * p.seg[l].GW;
+                        if (pp < pl) break;
+                        pp -= pl;
+                    }
+                    const erd_wgrad_seg& g = p.seg[l];
+                    const int GHW = g.GH * g.GW;
+                    const int n = pp / GHW;
+                    const int rem = pp - n * GHW;
+                    const int a = rem / g.GW;
+                    const int b = rem - a * g.GW;
+                    oa = (int)(g.dz_off + n * g.dz_nstride) + ((a * p.out_stride + p.oy) * g.OW + (b * p.out_stride + p.ox)) * p.Cout;
+                    const int ih = a * p.in_stride + p.dy[ky], iw = b * p.in_stride + p.dx[ky];
+                    if ((unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW)
+                        ob = (int)(g.x_off + n * g.x_nstride) + (ih * g.IW + iw) * p.Cin;
+                }
+                offa[slot * BK + tid] = oa;
+                offb[slot * BX + tid] = ob;
+            }
+            return;
+        }
         if (tid < BX) {
             int oa = -1, ob = -1;
             if (kt < kt_end) {
@@ -1144,10 +1179,12 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
 
     // ---- staging roles: threads [0, NA) own a dz micro-tile (4 px x 4 co), threads [128, 128 + 80) an x micro-tile (4 entries x 4 ci)
     constexpr int NA = (BMR / 4) * 4;                           // dz micro-tiles: (BMR / 4) channel groups x 4 pixel groups
-    const bool is_a = tid < NA, is_b = tid >= 128 && tid < 128 + 80;
+    constexpr int NB = (BNR / 4) * ((BX + 3) / 4);              // x micro-tiles: 16 x 5 with the halo, 32 x 4 without
+    static_assert(NA <= 128 && NB <= 128, "staging roles");
+    const bool is_a = tid < NA, is_b = tid >= 128 && tid < 128 + NB;
     const int tb = tid - 128;
-    const int cg = is_a ? tid % (BMR / 4) : tb % 16;            // channel group
-    const int pg = is_a ? tid / (BMR / 4) : tb / 16;            // group of 4 pixels (dz: 0..3) / entries (x: 0..4)
+    const int cg = is_a ? tid % (BMR / 4) : tb % (BNR / 4);     // channel group
+    const int pg = is_a ? tid / (BMR / 4) : tb / (BNR / 4);     // group of 4 pixels (dz: 0..3) / entries (x: 0..4)
     const int col = is_a ? co0 + cg * 4 : ci0 + cg * 4;
     const bool cok = is_a ? (col < p.Cout) : (is_b && col < p.Cin);
     float4 rv[4];
@@ -1184,7 +1221,7 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
             lo.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), SEL);
             lo.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), SEL);
             // dz: 32-B rows, 16-B chunk (pg >> 1) swizzled by (row >> 3) & 1; x: 48-B rows, entry e at byte 2 e
-            const int off = is_a ? row * A_ROWB + (((pg >> 1) ^ ((row >> 3) & 1)) << 4) + ((pg & 1) << 3) : row * B_ROWB + pg * 8;
+            const int off = (is_a || !ROW3) ? row * A_ROWB + (((pg >> 1) ^ ((row >> 3) & 1)) << 4) + ((pg & 1) << 3) : row * B_ROWB + pg * 8;
             const int plane = is_a ? A_PL : B_PL;
             *reinterpret_cast<uint2*>(base + off) = hi;
             *reinterpret_cast<uint2*>(base + plane + off) = mid;
@@ -1195,13 +1232,15 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
-    f32x16 acc[3][FM];
+    f32x16 acc[NT][FM][FN];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     if (kt_begin < kt_end) {
@@ -1227,51 +1266,62 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
                 for (int pl = 0; pl < 3; ++pl)
                     fa[i][pl] = *reinterpret_cast<const u4v*>(Ab + pl * A_PL + row * A_ROWB + ((h ^ ((row >> 3) & 1)) << 4));
             }
-            const int brow = wn * 32 + li;
-            u4v fb[3];
-            unsigned fe[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                fb[pl] = *reinterpret_cast<const u4v*>(Bb + pl * B_PL + brow * B_ROWB + (h << 4));
-                fe[pl] = *reinterpret_cast<const unsigned*>(Bb + pl * B_PL + brow * B_ROWB + (h << 4) + 16);
-            }
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                bf16x8 xb[3];
+            for (int j = 0; j < FN; ++j) {
+                const int brow = (wn * FN + j) * 32 + li;
+                u4v fb[3];
+                unsigned fe[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    u4v s_;
-                    if (t == 0) s_ = fb[pl];
-                    else if (t == 2) { s_[0] = fb[pl][1]; s_[1] = fb[pl][2]; s_[2] = fb[pl][3]; s_[3] = fe[pl]; }
-                    else {
-                        s_[0] = __builtin_amdgcn_alignbit(fb[pl][1], fb[pl][0], 16);
-                        s_[1] = __builtin_amdgcn_alignbit(fb[pl][2], fb[pl][1], 16);
-                        s_[2] = __builtin_amdgcn_alignbit(fb[pl][3], fb[pl][2], 16);
-                        s_[3] = __builtin_amdgcn_alignbit(fe[pl], fb[pl][3], 16);
+                    if constexpr (ROW3) {
+                        fb[pl] = *reinterpret_cast<const u4v*>(Bb + pl * B_PL + brow * B_ROWB + (h << 4));
+                        fe[pl] = *reinterpret_cast<const unsigned*>(Bb + pl * B_PL + brow * B_ROWB + (h << 4) + 16);
+                    } else {
+                        fb[pl] = *reinterpret_cast<const u4v*>(Bb + pl * B_PL + brow * B_ROWB + ((h ^ ((brow >> 3) & 1)) << 4));
+                        fe[pl] = 0u;
                     }
-                    xb[pl] = __builtin_bit_cast(bf16x8, s_);
                 }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bf16x8 xb[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        u4v s_;
+                        if (t == 0) s_ = fb[pl];
+                        else if (t == 2) { s_[0] = fb[pl][1]; s_[1] = fb[pl][2]; s_[2] = fb[pl][3]; s_[3] = fe[pl]; }
+                        else {
+                            s_[0] = __builtin_amdgcn_alignbit(fb[pl][1], fb[pl][0], 16);
+                            s_[1] = __builtin_amdgcn_alignbit(fb[pl][2], fb[pl][1], 16);
+                            s_[2] = __builtin_amdgcn_alignbit(fb[pl][3], fb[pl][2], 16);
+                            s_[3] = __builtin_amdgcn_alignbit(fe[pl], fb[pl][3], 16);
+                        }
+                        xb[pl] = __builtin_bit_cast(bf16x8, s_);
+                    }
 #define ERD_W3(APL, BPL)                                                                                              \
-                _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                        \
-                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][APL]), xb[BPL], acc[t][i], 0, 0, 0);
-                ERD_W3(0, 2) ERD_W3(0, 1) ERD_W3(1, 1) ERD_W3(2, 0) ERD_W3(1, 0) ERD_W3(0, 0)
+                    _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                    \
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][APL]), xb[BPL], acc[t][i][j], 0, 0, 0);
+                    ERD_W3(0, 2) ERD_W3(0, 1) ERD_W3(1, 1) ERD_W3(2, 0) ERD_W3(1, 0) ERD_W3(0, 0)
 #undef ERD_W3
+                }
             }
             if (more) store_lds(buf ^ 1);
             __syncthreads();
         }
     }
-    float* __restrict__ part = p.part + (int64_t)bz * p.Cout * 9 * p.Cin;
-    const int ci = ci0 + wn * 32 + li;
-    if (ci < p.Cin) {
+    const int ntaps_all = ROW3 ? 9 : p.ntaps;
+    float* __restrict__ part = p.part + (int64_t)bz * p.Cout * ntaps_all * p.Cin;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+    for (int j = 0; j < FN; ++j) {
+        const int ci = ci0 + (wn * FN + j) * 32 + li;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (co < p.Cout) part[((int64_t)co * 9 + ky * 3 + t) * p.Cin + ci] = acc[t][i][r];
+                    if (co < p.Cout) part[((int64_t)co * ntaps_all + (ROW3 ? ky * 3 + t : ky)) * p.Cin + ci] = acc[t][i][j][r];
                 }
     }
 }
@@ -1851,7 +1901,7 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
         const int fm = d->Cout > 64 ? 2 : 1;
         const int nci = (d->Cin + 63) / 64, nco = (d->Cout + fm * 64 - 1) / (fm * 64);
         const size_t lds = (size_t)2 * 3 * (fm * 64 * 32 + 64 * 48) + 2 * (16 + 18) * sizeof(int);
-        void (*kern)(const erd_wgrad_desc, const int) = fm == 2 ? conv_wgrad_row3_x3_kernel<2> : conv_wgrad_row3_x3_kernel<1>;
+        void (*kern)(const erd_wgrad_desc, const int) = fm == 2 ? conv_wgrad_row3_x3_kernel<2, 1, true> : conv_wgrad_row3_x3_kernel<1, 1, true>;
         static bool attr_done3[2] = {false, false};
         if (!attr_done3[fm - 1]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1861,6 +1911,22 @@ extern "C" int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream) {
         hipLaunchKernelGGL(kern, dim3(nci * 3 * nco * d->nsplit), dim3(NTHREADS), lds, (hipStream_t)stream, *d,
                            nslices | (row3_xcd ? (1 << 30) : 0));
         return erd::check_launch("conv_wgrad_row3_x3");
+    }
+    if (d->limbs3 && d->Cin % 4 == 0) {
+        // three-limb form of every other layer (1x1, stride 2): one tap, 128 x 128 channels per workgroup, 16-pixel slices of the
+        // concatenated pixel axis
+        const int nslices = (int)((npix + 15) / 16);
+        const int nci = (d->Cin + 127) / 128, nco = (d->Cout + 127) / 128;
+        const size_t lds = (size_t)2 * 3 * (128 * 32 + 128 * 32) + 2 * (16 + 16) * sizeof(int);
+        void (*kern)(const erd_wgrad_desc, const int) = conv_wgrad_row3_x3_kernel<2, 2, false>;
+        static bool attr_done1 = false;
+        if (!attr_done1) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done1 = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(nci * d->ntaps * nco * d->nsplit), dim3(NTHREADS), lds, (hipStream_t)stream, *d,
+                           nslices | (xcd_order_enabled() ? (1 << 30) : 0));
+        return erd::check_launch("conv_wgrad_x3");
     }
     if (row3 && erd_wgrad_row3_slices(d) > 0) {
         const int nslices = erd_wgrad_row3_slices(d);

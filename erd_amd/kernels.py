@@ -847,6 +847,7 @@ def _shape_tag(d, k: int, stride: int) -> str:
     return f"px{px} {d.Cin}->{d.Cout} k{k}s{stride}"
 
 
+WGRAD_X3_GENERIC = _os.environ.get("ERD_WGRAD_X3_GENERIC", "1") != "0"      # ... and of the 1x1 / stride-2 layers
 WGRAD_X3 = _os.environ.get("ERD_WGRAD_X3", "1") != "0"      # three-limb form of the three-tap weight gradient in the f32x3 mode (A/B aid)
 
 
@@ -873,7 +874,7 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     xoff = tuple((x.data_ptr() - xb) // x.element_size() for x in xs)
     zoff = tuple((z.data_ptr() - zb) // z.element_size() for z in dzs)
     cache = _desc_cache()
-    key = ("wgrad", k, stride, pad, _geom(xs), _geom(dzs), xoff, zoff, COMPUTE, _os.environ.get("ERD_WGRAD_ROW3", "1"), WGRAD_X3)
+    key = ("wgrad", k, stride, pad, _geom(xs), _geom(dzs), xoff, zoff, COMPUTE, _os.environ.get("ERD_WGRAD_ROW3", "1"), WGRAD_X3, WGRAD_X3_GENERIC)
     ent = cache.get(key)
     if ent is None:
         ent = cache[key] = _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff)
@@ -914,7 +915,7 @@ def _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff):
     d.bf16_multiplicands = 1 if COMPUTE == "bf16" else 0
     d.x_bf16, d.dz_bf16 = _stored_bf16(xs), _stored_bf16(dzs)
     row3 = int(_lib.load().erd_wgrad_row3_slices(C.byref(d))) if _os.environ.get("ERD_WGRAD_ROW3", "1") != "0" else 0
-    d.limbs3 = 1 if (COMPUTE == "f32x3" and row3 and WGRAD_X3) else 0
+    d.limbs3 = 1 if (COMPUTE == "f32x3" and WGRAD_X3 and (row3 or WGRAD_X3_GENERIC)) else 0
     if row3 and d.limbs3:      # three-limb form: (128 | 64) output channels x 64 input channels x 3 taps per workgroup, one dispatch round
         bmr = 128 if Cout > 64 else 64
         groups = ((Cout + bmr - 1) // bmr) * ((Cin + 63) // 64) * 3
@@ -926,6 +927,10 @@ def _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff):
         groups = ((Cout + bme - 1) // bme) * ((Cin + 127) // 128) * 3
         target = int(_os.environ.get("ERD_WGRAD_ROW3_TARGET", "512"))
         S = int(max(1, min(target // groups, row3 // 16 if row3 >= 16 else 1, 512)))     # floor: whole dispatch rounds
+    elif d.limbs3:      # three-limb form of the other layers: 128 x 128 channels, one tap per workgroup, one dispatch round of three per CU
+        tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * k * k
+        kt = (npix + 15) // 16
+        S = int(max(1, min(int(_os.environ.get("ERD_WGRAD_X3_TARGET", "768")) // tiles, kt // 8 if kt >= 8 else 1, 512)))
     else:
         S = _pick_nsplit(npix, Cout, Cin, k * k)
     d.nsplit = S

@@ -52,6 +52,8 @@ def test_f32x3_convolutions_are_as_close_to_fp64_as_the_native_fp32_kernels(K, N
     rowscale = 0.5 + G.rand(14, Cout)
     xd = x.double().requires_grad_(True)
     gref = torch.autograd.grad(F.conv2d(xd, w.double(), None, s, p), xd, dy.double() * rowscale.double().view(1, -1, 1, 1))[0]
+    wd = w.double().requires_grad_(True)
+    wref = torch.autograd.grad(F.conv2d(x.double(), wd, None, s, p), wd, dy.double())[0].permute(0, 2, 3, 1)      # [Cout, k, k, Cin]
     wg = w.permute(0, 2, 3, 1).contiguous().cuda()
     xg, dyg = nhwc(x), nhwc(dy)
     err = {}
@@ -66,10 +68,14 @@ def test_f32x3_convolutions_are_as_close_to_fp64_as_the_native_fp32_kernels(K, N
             wt = K.weight_transpose(wg, rowscale.cuda())
             dx = torch.zeros((N, H, W, Cin), device="cuda")
             K.conv_dgrad([dyg], wt, [dx], k, s, p)
+            part, S = K.conv_wgrad_partials([xg], [dyg], k, s, p)
+            dW = torch.empty_like(wg)
+            K.wgrad_reduce(part, S, wg, None, dW, False, None)
         finally:
             K.WINOGRAD = keep
-        err[mode] = (rel64(to_nchw(out), ref), rel64(to_nchw(out2), ref2), rel64(to_nchw(dx), gref))
-    print("rel L2 to fp64 (plain / epilogue / input gradient): native fp32 MFMA %.2e %.2e %.2e | f32x3 %.2e %.2e %.2e" % (err["f32"] + err["f32x3"]))
+        err[mode] = (rel64(to_nchw(out), ref), rel64(to_nchw(out2), ref2), rel64(to_nchw(dx), gref), rel64(dW.cpu(), wref))
+    print("rel L2 to fp64 (plain / epilogue / input gradient / weight gradient): native fp32 MFMA %.2e %.2e %.2e %.2e | f32x3 %.2e %.2e %.2e %.2e"
+          % (err["f32"] + err["f32x3"]))
     for a, b in zip(err["f32x3"], err["f32"]):
         assert a <= max(1.5 * b, 2e-7), err
 
