@@ -262,8 +262,8 @@ def main():
     ap.add_argument("--compute", choices=["f32x3", "f32", "bf16"], default="f32x3",
                     help="f32x3 (default; BASELINE configs[1], the headline): fp32 maps, fp32 accumulation, fp32 results; the direct "
                          "implicit-GEMM launches form each fp32 product on the bf16 matrix cores from exact three-limb splits of both "
-                         "multiplicands (what is dropped is below 2^-23 of the product; gfx950's fp32 MFMA runs at 1/16 of the bf16 rate), "
-                         "Winograd and weight-gradient launches run on the fp32 matrix cores.  f32: every launch on the fp32 matrix cores "
+                         "multiplicands (what is dropped is below 2^-23 of the product; gfx950's fp32 MFMA runs at 1/16 of the bf16 rate), so do "
+                         "the weight-gradient launches; Winograd launches run on the fp32 matrix cores.  f32: every launch on the fp32 matrix cores "
                          "(the A/B sibling).  bf16: BASELINE configs[2] -- the 1x1 / 3x3 convolutions on the bf16 matrix cores with fp32 "
                          "accumulation, feature maps and their gradients STORED as bf16; head outputs, statistics, losses, parameters "
                          "and parameter gradients stay fp32")
@@ -397,9 +397,9 @@ def main():
                  ("r101_70_10", "f32", False): "BASELINE configs[3], per-GPU leg, fp32", ("r101_70_10", "bf16", False): "BASELINE configs[3], per-GPU leg, bf16",
                  ("r50_40_40", "f32", True): "BASELINE configs[4], per-GPU leg, fp32", ("r50_40_40", "bf16", True): "BASELINE configs[4], per-GPU leg, bf16"}.get(
                      (args.arch, prec, args.mixed_res), "a combination BASELINE.json does not name")
-        arithmetic = {"f32x3": "fp32 maps / accumulation / results; direct implicit-GEMM products on the bf16 matrix cores from exact three-limb "
-                               "splits of both fp32 multiplicands (6 of 9 limb products, dropped part < 2^-23 of a product); Winograd F(2x2,3x3) "
-                               "and weight gradients on the fp32 matrix cores",
+        arithmetic = {"f32x3": "fp32 maps / accumulation / results; the products of the direct implicit-GEMM and weight-gradient launches are formed "
+                               "on the bf16 matrix cores from exact three-limb splits of both fp32 multiplicands (6 of 9 limb products, dropped "
+                               "part < 2^-23 of a product); Winograd F(2x2,3x3) launches on the fp32 matrix cores",
                       "f32": "fp32 throughout, every GEMM-shaped launch on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                       "bf16": "bf16 matrix cores, bf16-stored maps, fp32 accumulate / statistics / losses"}[args.compute]
         res = "mixed resolution " + "/".join(f"{h}x{w}" for h, w in MIXED_SHAPES) + " (round-robin, each padded to /32)" if args.mixed_res \
@@ -444,13 +444,17 @@ def main():
             # executed flops per algorithmic flop, and the matrix pipe they run on: Winograd 16/36 on the fp32 pipe; the three-limb
             # form of the direct launches 6 bf16 MFMA flops per fp32 flop on the bf16 pipe
             x3 = args.compute == "f32x3"
-            execf = WINO_EXECUTED if sym == "wino_conv_kernel" else (6.0 if (x3 and sym == "conv_igemm_kernel") else 1.0)
-            if x3 and sym == "conv_igemm_kernel":
+            X3_SYMS = ("conv_igemm_kernel", "conv_wgrad_row3_kernel", "conv_wgrad_kernel")      # launch classes that run in the three-limb form
+            execf = WINO_EXECUTED if sym == "wino_conv_kernel" else (6.0 if (x3 and sym in X3_SYMS) else 1.0)
+            if x3 and sym in X3_SYMS:
                 peak_tf = BF16_MFMA_PEAK_TFLOPS
             alg_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
             # PMC counters cannot be read from inside this process: `traffic` / `mfma_busy_pmc` are STATIC values from the
             # committed profile of the same command (fp32 only; the profile names its commit) -- pointers, not measurements
-            traffic, traffic_src = pmc_traffic_per_launch(sym, args.compute)
+            # (rocprof's symbol of the class: the three-limb weight gradients are instantiations of one kernel template)
+            pmc_sym = {"conv_wgrad_row3_kernel": "conv_wgrad_row3_x3_kernel<2, 1", "conv_wgrad_kernel": "conv_wgrad_row3_x3_kernel<2, 2"}.get(sym, sym) \
+                if x3 else sym
+            traffic, traffic_src = pmc_traffic_per_launch(pmc_sym, args.compute)
             out["roofline"] = {"bound": "mfma", "kernel": sym, "classes": [c for c in SYMBOLS[sym] if c in ktime],
                                "achieved": round(alg_tf * execf, 2), "peak": peak_tf, "unit": "TFLOP/s",
                                "frac": round(alg_tf * execf / peak_tf, 4),
@@ -465,7 +469,7 @@ def main():
                                "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                                "gflop_per_launch": round(dom["flop"] / dom["launches"] / 1e9, 3),
                                "algorithmic_bytes_per_launch": int(dom["min_bytes"] / dom["launches"])}
-            out["roofline"]["mfma_busy_pmc"], out["roofline"]["mfma_busy_source"] = pmc_mfma_busy(sym, args.compute)
+            out["roofline"]["mfma_busy_pmc"], out["roofline"]["mfma_busy_source"] = pmc_mfma_busy(pmc_sym, args.compute)
             out["roofline"]["mfma_busy_static"] = True
             # ---- step level, three ways, all over the un-instrumented step time of the timed region and the same peak:
             #  step_frac           the ALGORITHMIC work of the reference's step (both copies of the frozen trunk)
@@ -478,7 +482,8 @@ def main():
             step_s = dt / args.steps
             skipped = (TRUNK_GFLOP_PER_IMAGE if shared else 0.0) * rel_area
             per_step = lambda classes: sum(ktime[c]["flop"] for c in classes if c in ktime) / rsteps / 1e9     # GFLOP per step (rank 0's batch)
-            wino_alg, igemm_alg = per_step(SYMBOLS["wino_conv_kernel"]), per_step(SYMBOLS["conv_igemm_kernel"]) if x3 else 0.0
+            wino_alg = per_step(SYMBOLS["wino_conv_kernel"])
+            igemm_alg = sum(per_step(SYMBOLS[k_]) for k_ in X3_SYMS) if x3 else 0.0      # (every three-limb class, not only the implicit GEMM)
             exec_gflop_step = args.batch * (g_img - skipped) - wino_alg * (1.0 - WINO_EXECUTED)
             pipe_s = ((exec_gflop_step - igemm_alg) / step_peak + igemm_alg * 6.0 / BF16_MFMA_PEAK_TFLOPS) * 1e-3
             out["roofline"]["step_gflop_per_image"] = round(g_img, 1)

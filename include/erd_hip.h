@@ -164,8 +164,10 @@ typedef struct {
     int x_bf16, dz_bf16;    /* 1: the x / dz maps are stored as bf16 (offsets, strides, extents stay in elements); only
                              * with bf16_multiplicands */
     int limbs3;             /* 1 ("f32x3"): fp32 maps and fp32 partial slabs, but every product dz * x is formed on the bf16 matrix
-                             * cores from exact three-limb splits of both values (see erd_conv_desc::w_x3).  Served by the
-                             * three-tap kernel of the 3x3 / stride-1 layers; other layers ignore the flag. */
+                             * cores from exact three-limb splits of both values (see erd_conv_desc::w_x3): both operands are
+                             * split in the kernel's transposing loader (4 pixels x 4 channels per thread).  3x3 / stride-1 layers:
+                             * three taps of a kernel row per workgroup (the taps are register shifts of the packed pixel vectors);
+                             * every other layer: one tap, 128 x 128 channels per workgroup.  Cin % 4 == 0. */
 } erd_wgrad_desc;
 int erd_conv_wgrad(const erd_wgrad_desc* d, erd_stream_t stream);
 /* > 0: the layer takes the three-taps-per-workgroup kernel (3x3, stride 1, pad 1, fp32) and this is its number of
