@@ -199,6 +199,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
 
     if (is_mma) {
         // ------------------------------------------------------------------ matrix waves
+#ifdef ERD_WINO_MMA_PRIO
+        __builtin_amdgcn_s_setprio(ERD_WINO_MMA_PRIO);
+#endif
         const int j = lane & 15, kq = lane >> 4;
         const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.U), 0, (int)((size_t)16 * ncb16 * nks * 1024), 0x00020000);
@@ -423,7 +426,10 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
         //  buffer loads (out-of-image and padding entries carry an offset beyond the buffer: they return zeros), LDS
         //  addresses that are VGPR bases + immediates (the buffer parity and the transform half are template parameters),
         //  the buffer resource of the look-ahead item in SGPRs.)
-        __builtin_amdgcn_s_setprio(3);
+#ifndef ERD_WINO_DATA_PRIO
+#define ERD_WINO_DATA_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(ERD_WINO_DATA_PRIO);
         const int dt = tid & 255;
         const int t_chunk = dt & 3, t_tile = (dt >> 2) & 31, t_half = __builtin_amdgcn_readfirstlane(dt >> 7);
         WinoItem la = decode(item0);                          // the item of the look-ahead pointer (3 slices ahead of g)
