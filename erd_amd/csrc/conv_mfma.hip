@@ -136,8 +136,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
     // else is allocated.  The row table therefore lives INSIDE the region: at its start while a tile is set up (before the
     // first operand slice is stored) and behind the epilogue's staging area once the K loop is over (recomputed: 128 threads,
     // two divisions each); the broadcast word of the stream-K fix-up sits next to it.
-    constexpr int ROWS_EPI_OFF = X3 ? ((STAGE_BYTES + 255) / 256 * 256) : REGION;
-    static_assert(!X3 || ROWS_EPI_OFF + BM * (int)sizeof(RowInfo) + 16 <= OPER_BYTES, "f32x3: row table does not fit behind the staging area");
+    // (f32x3: the epilogue stages each wave's 32 rows in its own block: 4 x 32 x (BN + 4) floats)
+    constexpr int WSTAGE_BYTES = 32 * (BN + 4) * 4;
+    constexpr int ROWS_EPI_OFF = X3 ? ((4 * WSTAGE_BYTES + 255) / 256 * 256) : REGION;
+    static_assert(!X3 || ROWS_EPI_OFF + BM * (int)sizeof(RowInfo) + 64 + 4 * (BN / 4) * 16 <= OPER_BYTES,
+                  "f32x3: row table + column-sum scratch do not fit behind the staging blocks");
     RowInfo* rows = reinterpret_cast<RowInfo*>(smem + (X3 ? 0 : REGION));     // [BM]
     RowInfo* rows_epi = reinterpret_cast<RowInfo*>(smem + ROWS_EPI_OFF);
     int* bcast = reinterpret_cast<int*>(reinterpret_cast<RowInfo*>(smem + ROWS_EPI_OFF) + BM);                // [4]
@@ -620,8 +623,86 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         constexpr int SLD = BN + 4;
         constexpr int C4N = BN / 4;                             // float4 columns of the tile
         constexpr int RPS = NTHREADS / C4N;                     // rows stored per sweep
+        bool wave_epilogue_done = false;
+        if constexpr (X3) {
+            // f32x3 (4 x 1 waves): every wave owns 32 complete output rows, so it stages them in its OWN LDS block and writes them
+            // out by itself -- all four waves at once and without workgroup barriers between passes (the shared form below is
+            // four sequential passes with two barriers each: 14 k of a tile's 56 k cycles on the K = 256 layers).
+            {   // (Cout % 4 == 0: erd_conv_igemm sends other launches to the fp32 kernel)
+                wave_epilogue_done = true;
+                __syncthreads();                                // the row table behind the staging blocks is complete
+                float* wst = reinterpret_cast<float*>(smem + wave * WSTAGE_BYTES);
+                constexpr int RPW = 64 / C4N, NIT = 32 / RPW;   // rows per wave-instruction, instructions per block
+                const int c4 = lane % C4N, rsub = lane / C4N;
+                const int co = n0 + c4 * 4;
+                const bool cvalid = co < p.Cout;
+                // residual / mask rows of the first half are requested before the accumulators are staged
+                const OutT* pf_src = res ? res : msk;
+                constexpr int NPH = NIT >= 16 ? 4 : 2, NPQ = NIT / NPH;      // phases, rows per lane and phase (register budget)
+                float4 pf[NPQ];
+                auto prefetch = [&](int it0) {
+                    if (pf_src && cvalid) {
 #pragma unroll
-        for (int half = 0; half < WAVES_M; ++half) {
+                        for (int q = 0; q < NPQ; ++q) {
+                            const int oo = rows_epi[wave * 32 + (it0 + q) * RPW + rsub].out_off;
+                            if (oo >= 0) pf[q] = erd::ld4(pf_src + oo + co);
+                        }
+                    }
+                };
+                prefetch(0);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wst[((r & 3) + 8 * (r >> 2) + 4 * h) * SLD + j * 32 + li] = acc[0][j][r];
+                __builtin_amdgcn_wave_barrier();                // (LDS operations of one wave execute in order)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cvalid && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+                if (cvalid && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
+                float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int hf = 0; hf < NPH; ++hf) {
+                    if (hf > 0) prefetch(hf * NPQ);
+#pragma unroll
+                    for (int q = 0; q < NPQ; ++q) {
+                        const int rr = (hf * NPQ + q) * RPW + rsub;
+                        const int oo = rows_epi[wave * 32 + rr].out_off;
+                        if (oo < 0 || !cvalid) continue;
+                        float4 v = *reinterpret_cast<const float4*>(wst + rr * SLD + c4 * 4);
+                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                        if (has_alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
+                        if (res) { const float4 rv = pf[q]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if (msk) {
+                            const float4 mv = res ? erd::ld4(msk + oo + co) : pf[q];
+                            v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                            v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                        }
+                        erd::st4(out + oo + co, v);
+                        csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+                    }
+                }
+                if (p.colsum) {      // lanes that share a column group, then the four waves through LDS, one atomic per channel
+#pragma unroll
+                    for (int o = C4N; o < 64; o <<= 1) {
+                        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+                    }
+                    float4* red = reinterpret_cast<float4*>(smem + ROWS_EPI_OFF + BM * sizeof(RowInfo) + 64);      // [4][C4N], behind table + broadcast word
+                    if (lane < C4N) red[wave * C4N + lane] = cvalid ? csum : make_float4(0.f, 0.f, 0.f, 0.f);
+                    __syncthreads();
+                    if (tid < C4N && n0 + tid * 4 < p.Cout) {
+                        float4 t = red[tid];
+                        for (int q = 1; q < 4; ++q) { const float4 v = red[q * C4N + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                        float* cs = p.colsum + (p.colsum_copies > 1 ? (int64_t)(blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0);
+                        const int cc0 = n0 + tid * 4;
+                        atomicAdd(cs + cc0 + 0, t.x); atomicAdd(cs + cc0 + 1, t.y); atomicAdd(cs + cc0 + 2, t.z); atomicAdd(cs + cc0 + 3, t.w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < (X3 ? 0 : WAVES_M); ++half) {
             __syncthreads();                                    // operand tiles / previous half fully consumed
             // residual / ReLU-mask rows of this half are requested NOW: their latency hides behind the staging below
             // (inside the store loop every row would wait for its own load: ~1 us x 8 dependent iterations per half)
@@ -1765,7 +1846,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     // short K loops (K = taps x Cin below ERD_X3_MIN_K) gain nothing from a faster loop: they are set-up / epilogue bound and
     // want the fp32 kernel's four small workgroups per CU (the three-limb kernel holds 80 KB of LDS: two per CU)
     static const int x3_min_k = getenv("ERD_X3_MIN_K") ? atoi(getenv("ERD_X3_MIN_K")) : 0;
-    if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0 && (d->ntaps * d->Cin >= x3_min_k || !d->w)) {
+    if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0 && (d->Cout % 4 == 0 || !d->w) && (d->ntaps * d->Cin >= x3_min_k || !d->w)) {
+        ERD_REQUIRE(d->Cout % 4 == 0, "conv: the three-limb kernel stores 16-byte rows (Cout %% 4 == 0); pass `w` for Cout=%d", d->Cout);
         // "f32x3": fp32 maps and results, products on the bf16 matrix cores through exact three-limb splits (see the kernel)
         if (seg_taps_any) return launch_igemm<128, 128, 4, 1, 32, 2, false, true, false, false, true>(d, st);
         if (d->Cout <= 64) return launch_igemm<128, 64, 4, 1, 32, 2, false, false, false, false, true>(d, st);
