@@ -101,7 +101,7 @@ typedef struct {
     int in_bf16, out_bf16;
     /* optional ("f32x3" mode): the same weights as three bf16 LIMB planes, [3][Cout][wrow] (erd_split3 / erd_weight_transpose_x3):
      * plane 0 = the upper 16 bits of each fp32 weight, plane 1 = the upper 16 bits of the remainder, plane 2 = what is left
-     * -- w == p0 + p1 + p2 EXACTLY.  When set (and Cin % 4 == 0; otherwise the launch needs `w`) maps, accumulation
+     * -- w == p0 + p1 + p2 EXACTLY.  When set (and Cin % 4 == 0, Cout % 4 == 0; otherwise the launch needs `w`) maps, accumulation
      * and results stay fp32 but every product a*w is formed on the bf16 matrix cores as the sum of the six limb products of
      * weight >= 2^-16 (the activation is split the same way in registers): the dropped terms are below 2^-23 |a*w|, fp32's own
      * rounding of that product.  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate; six bf16 MFMAs cost 3/8 of one fp32 MFMA. */
