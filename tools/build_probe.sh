@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../erd_amd/csrc"
 mkdir -p ../lib/abl
 n=$1; f=$2; shift 2
-base=$(basename $f .hip)
+base=${PROBE_BASE:-$(basename $f .hip)}
 extra=""
 case $base in losses|leaf_ops|predict) extra="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f -o /tmp/${base}_probe_$n.o
