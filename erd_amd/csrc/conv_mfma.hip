@@ -495,9 +495,15 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 const int cur = kk & 1;
+#ifndef ERD_IG_NOFRAG      // (timing probe: every k-step re-uses the first one's fragments)
                 if (kk + 1 < KSTEPS) read_frags(kk + 1, cur ^ 1);
+#endif
                 // next slice's global loads, a few per k-step, issued under this step's MFMAs
+#ifdef ERD_IG_NOLOAD       // (timing probe: the K loop re-uses the first slices' registers)
+                if (false) {
+#else
                 if (fetch) {
+#endif
 #pragma unroll
                     for (int q = 0; q < APS; ++q)
                         if (kk * APS + q < AJ) load_a(kk * APS + q, fset);
@@ -510,6 +516,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
                         if (BF) {
+#ifdef ERD_IG_NOMFMA       // (timing probe: everything but the matrix instructions)
+                            acc[i][j][kk] += fa[cur][i].x * fb[cur][j].y;
+                            continue;
+#endif
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 __builtin_bit_cast(bf16x8, fa[cur][i]), __builtin_bit_cast(bf16x8, fb[cur][j]),
                                 acc[i][j], 0, 0, 0);
@@ -526,8 +536,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                     __builtin_amdgcn_sched_group_barrier(0x8, FM * FN * 4, 0);    // then this step's MFMAs
                 }
             }
+#ifndef ERD_IG_NOSYNC      // (timing probe, with ERD_IG_NOLOAD: no LDS refill and no barrier between slices)
             if (more) store_lds(buf ^ 1, PD2 ? (par ^ 1) : 0);
             __syncthreads();
+#endif
         };
         if constexpr (X3) {
             for (int kt = ks; kt < ke; ++kt) k_slice_x3(kt, (kt - ks) & 1);
@@ -1750,7 +1762,8 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     const size_t oper = X3 ? (size_t)2 * (BM * 8 + 3 * BN * 4) * sizeof(float4) : (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4);
     const size_t stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
     // (f32x3: the row table and the fix-up's broadcast word live inside the operand region -- see the kernel)
-    const size_t lds = X3 ? oper : (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16;
+    static const size_t lds_pad = getenv("ERD_IG_LDS_PAD") ? (size_t)atoi(getenv("ERD_IG_LDS_PAD")) : 0;   // occupancy experiments
+    const size_t lds = (X3 ? oper : (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16) + lds_pad;
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB, X3>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
