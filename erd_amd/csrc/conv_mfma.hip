@@ -106,31 +106,32 @@ int xcd_order_enabled() {
 // MFMAs.  One K-slice = 32 channels = two k16 steps.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false,
           bool OB = false, bool X3 = false>
-__global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
                                                                      const SkWs ws) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;   // threads: four waves, or eight on the 256-row tiles of the bf16 mode
     constexpr int FM = BM / (WAVES_M * 32);
     constexpr int FN = BN / (WAVES_N * 32);
     constexpr int CH = BKT / 4;              // 16-B chunks per K-slice row (8 for BK=32, 4 for BK=16)
-    constexpr int RPP = NTHREADS / CH;       // rows staged per pass
+    constexpr int RPP = NT / CH;       // rows staged per pass
     constexpr int AJ = BM / RPP;             // float4 loads per thread for A
     constexpr int BJ = BN / RPP;
     constexpr int KPC = BF ? 8 : 4;          // k-values per 16-B chunk
     constexpr int BK = CH * KPC;             // k-values per K-slice
     constexpr bool SGB = ERD_SGB;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(WAVES_M * WAVES_N == 4 || (WAVES_M * WAVES_N == 8 && BF && !X3), "4 waves (8: bf16 matrix cores only)");
     static_assert(BF || (!AB && !OB), "bf16 storage only with the bf16 matrix cores");
     static_assert(!X3 || (!BF && BKT == 32 && WAVES_N == 1 && FM == 1), "f32x3: fp32 maps, 32-channel slices, 4 x 1 waves");
     constexpr unsigned ABYTES = AB ? 2u : 4u;   // bytes per stored input value
     constexpr int CHB = X3 ? 4 : CH;            // 16-B chunks per K-slice row of ONE weight plane (f32x3: 8 bf16 per chunk)
     constexpr int NPL = X3 ? 3 : 1;             // weight planes in LDS
-    constexpr int RPPB = NTHREADS / CHB;        // weight rows staged per pass
+    constexpr int RPPB = NT / CHB;        // weight rows staged per pass
     constexpr int BJX = BN / RPPB;              // 16-B loads per thread and plane for B (f32x3)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* As = reinterpret_cast<float4*>(smem);                 // [2][BM*CH]
     float4* Bs = As + 2 * BM * CH;                                 // [2][BN*CH]   (f32x3: [2][3 planes][BN*4])
     constexpr int OPER_BYTES = 2 * (BM * CH + NPL * BN * CHB) * 16;
-    constexpr int STAGE_BYTES = 64 * (BN + 4) * 4 + NTHREADS * 16;  // epilogue staging (+ column-sum scratch) re-uses the operand region
+    constexpr int STAGE_BYTES = 64 * (BN + 4) * 4 + NT * 16;  // epilogue staging (+ column-sum scratch) re-uses the operand region
     constexpr int REGION = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
     // f32x3: the operand region is 80 KB at 128 x 128 -- exactly half of the CU's LDS, two workgroups per CU only if nothing
     // else is allocated.  The row table therefore lives INSIDE the region: at its start while a tile is set up (before the
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
                         u32x4 v;
                         v.x = __float_as_uint(acc[i][j][4 * g]); v.y = __float_as_uint(acc[i][j][4 * g + 1]);
                         v.z = __float_as_uint(acc[i][j][4 * g + 2]); v.w = __float_as_uint(acc[i][j][4 * g + 3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, slab_off + (unsigned)(((i * FN + j) * 4 + g) * NTHREADS * 16), 0, 16 /* sc1 */);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, slab_off + (unsigned)(((i * FN + j) * 4 + g) * NT * 16), 0, 16 /* sc1 */);
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                                rs_slab, so + (unsigned)(((i * FN + j) * 4 + g) * NTHREADS * 16), 0, 16 /* sc1 */);
+                                rs_slab, so + (unsigned)(((i * FN + j) * 4 + g) * NT * 16), 0, 16 /* sc1 */);
                             acc[i][j][4 * g] += __uint_as_float(v.x); acc[i][j][4 * g + 1] += __uint_as_float(v.y);
                             acc[i][j][4 * g + 2] += __uint_as_float(v.z); acc[i][j][4 * g + 3] += __uint_as_float(v.w);
                         }
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void conv_igemm_kernel(const erd_co
         float* stage = reinterpret_cast<float*>(smem);          // [64][BN + 4]
         constexpr int SLD = BN + 4;
         constexpr int C4N = BN / 4;                             // float4 columns of the tile
-        constexpr int RPS = NTHREADS / C4N;                     // rows stored per sweep
+        constexpr int RPS = NT / C4N;                     // rows stored per sweep
         bool wave_epilogue_done = false;
         if constexpr (X3) {
             // f32x3 (4 x 1 waves): every wave owns 32 complete output rows, so it stages them in its OWN LDS block and writes them
@@ -1749,6 +1750,7 @@ int num_cus() {
 template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false, bool OB = false,
           bool X3 = false>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
+    constexpr int NT = WM * WN * 64;
     constexpr int BK = (BKT / 4) * (BF ? 8 : 4);
     int tiles = 0;
     for (int s = 0; s < d->nseg; ++s) {
@@ -1760,7 +1762,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     if (tiles == 0) return 0;
     const int nkt = d->ntaps * ((d->Cin + BK - 1) / BK);
     const size_t oper = X3 ? (size_t)2 * (BM * 8 + 3 * BN * 4) * sizeof(float4) : (size_t)2 * (BM + BN) * (BKT / 4) * sizeof(float4);
-    const size_t stage = (size_t)64 * (BN + 4) * 4 + NTHREADS * 16;
+    const size_t stage = (size_t)64 * (BN + 4) * 4 + NT * 16;
     // (f32x3: the row table and the fix-up's broadcast word live inside the operand region -- see the kernel)
     static const size_t lds_pad = getenv("ERD_IG_LDS_PAD") ? (size_t)atoi(getenv("ERD_IG_LDS_PAD")) : 0;   // occupancy experiments
     const size_t lds = (X3 ? oper : (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16) + lds_pad;
@@ -1806,7 +1808,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
         G = slots;
         ws.whole_tiles = 1;
     }
-    hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), lds, st, *d, tiles, ws);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NT), lds, st, *d, tiles, ws);
     return erd::check_launch("conv_igemm");
 }
 
@@ -1848,6 +1850,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
             if (d->Cout <= 64) return launch_igemm<128, 64, 2, 2, 32, 2, true, false, AB_, OB_>(d, st); \
             return launch_igemm<128, 128, 2, 2, 32, 2, true, false, AB_, OB_>(d, st);                   \
         } while (0)
+        // (256 x 128 tiles on eight waves, one workgroup per CU -- launch_igemm<256, 128, 4, 2, 32, 1, true, ...>, 25 % fewer operand
+        //  bytes per flop -- measured 6 % SLOWER than two co-resident 128 x 128 workgroups: DESIGN 7a)
         if (d->in_bf16 && d->out_bf16) ERD_BF_LAUNCH(true, true);
         if (d->in_bf16) ERD_BF_LAUNCH(true, false);
         if (d->out_bf16) ERD_BF_LAUNCH(false, true);
