@@ -819,350 +819,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
 }
 
 // -------------------------------------------------------------------------------------------------
-// Producer / consumer form of the three-limb implicit GEMM ("f32x3") for the THIN 1x1 / stride-1 layers: K = Cin <= 256, i.e. a
-// plain GEMM out[m][co] = sum_k in[m][k] w[co][k] over the dense pixel axis, whose tiles are all set-up, first-load latency and
-// epilogue in the kernel above (phase trace, DESIGN 7a: 5 k cycles of set-up + 15 k of K loop + 11 k of epilogue per tile, serial,
-// two tiles per CU in flight; twice the HBM bound).  Here one persistent 512-thread workgroup per CU splits the roles, as the
-// Winograd kernel does:
-//   * 4 DATA waves run the loaders of the kernel above (global -> registers -> LDS, same layouts and swizzles), always two
-//     slices ahead of the multiplication and straight across tile boundaries: the first slices of tile t+1 travel while tile t
-//     is still being multiplied.  They also carry the EPILOGUE of tile t-1 -- staged rows -> scale / shift / residual / ReLU /
-//     mask -> 16-byte stores, column sums -- in portions next to the loads of tile t, so that stores travel under MFMAs;
-//   * 4 MATRIX waves (one per SIMD) own 32 rows x 128 couts each: per 32-channel slice two k16 steps of six limb products on
-//     v_mfma_f32_32x32x16_bf16, nothing else but their fragment reads and limb splits; after a tile's last slice they drop
-//     their accumulators into their own staging block and go on.
-//   * One barrier per slice: "slice g+1 is in LDS and slice g has been read".  Operand stages 2 x 40 KB, staging 4 x 16.5 KB.
-//   * Static schedule: workgroup b runs on XCD b % 8; XCD x owns the contiguous eighth x of the tile list (n-tile fastest, so the
-//     n-tiles of a pixel tile meet in one L2) and its workgroups take those tiles round-robin -- all tiles cost the same.
-// -------------------------------------------------------------------------------------------------
-#ifdef ERD_PC_TRACE
-__device__ unsigned long long g_pc_trace[256 * 8];
-#define PC_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define PC_ACC(a, v) a += __builtin_amdgcn_s_memtime() - v
-#else
-#define PC_T0(v)
-#define PC_ACC(a, v)
-#endif
-constexpr int PC_A_F4 = 128 * 8;                               // float4s of an A stage: 128 rows x 8 chunks of 4 fp32
-constexpr int PC_B_F4 = 3 * 128 * 4;                           // 3 limb planes x 128 cout rows x 4 chunks of 8 bf16
-constexpr int PC_STAGE_F4 = PC_A_F4 + PC_B_F4;                 // 40 KB
-constexpr int PC_SLD = 128 + 4;
-constexpr int PC_WST_BYTES = 32 * PC_SLD * 4;
-constexpr int PC_STG_OFF = 2 * PC_STAGE_F4 * 16;
-constexpr int PC_RED_OFF = PC_STG_OFF + 4 * PC_WST_BYTES;      // [16][32] float4: column-sum partials of the sixteen row groups
-constexpr int PC_LDS = PC_RED_OFF + 16 * 32 * 16;
-
-// PM: epilogue portions whose residual / mask rows are requested one step ahead (registers): 6 covers K >= 128 (16 portions
-// within three or seven steps); two-slice tiles (K = 64) take 8 that way and the other 8 with the latency exposed
-template <int PM>
-__global__ __launch_bounds__(768, 1) void conv_x3_pc_kernel(const erd_conv_desc p, const int M, const int ntn, const int nitems,
-                                                            int* __restrict__ cnt_unused) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* const stage0 = reinterpret_cast<float4*>(smem);
-    const int tid = threadIdx.x;
-    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const bool is_c = wave_id >= 8;                             // waves 0-7 move data, waves 8-11 multiply
-    const int wave = wave_id & 3;
-    const int Cin = p.Cin, Cout = p.Cout;
-    const int nkt = Cin / 32;                                  // >= 2 (checked by the launcher)
-    const erd_conv_seg& sg = p.seg[0];
-    // static schedule: XCD x owns the contiguous eighth x of the tile list (n-tile fastest: the n-tiles of a pixel tile meet in one
-    // L2), its workgroups take those tiles round-robin -- all tiles cost the same, a counter would buy nothing
-    const int xcd = blockIdx.x & 7, wpx = (int)gridDim.x >> 3;
-    const int it_lo = (int)((long long)nitems * xcd / 8), it_hi = (int)((long long)nitems * (xcd + 1) / 8);
-    auto item_of = [&](int k) __attribute__((always_inline)) -> int {
-        const int i = it_lo + ((int)blockIdx.x >> 3) + k * wpx;
-        return i < it_hi ? i : -1;
-    };
-    int item = item_of(0);
-    const int PORT = (8 + nkt - 2) / (nkt - 1);                // epilogue portions (16 rows each) per slice step: all 8 within nkt - 1 steps
-
-    if (item >= 0 && is_c) {
-        // ------------------------------------------------------------------ matrix waves
-        const int li = lane & 31, h = lane >> 5;
-        f32x16 acc[4];
-    #pragma unroll
-        for (int j = 0; j < 4; ++j)
-    #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        auto multiply = [&](int buf) __attribute__((always_inline)) {                             // one 32-channel slice: see k_slice_x3 of conv_igemm_kernel
-            const float4* Ab = stage0 + buf * PC_STAGE_F4;
-            const float4* Bb = Ab + PC_A_F4;
-            const int arow = wave * 32 + li;
-            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-            constexpr unsigned TOP = 0xffff0000u, SEL = 0x07060302u;
-            auto pack_top = [&](const float (&v)[8]) {
-                u4v P;
-    #pragma unroll
-                for (int e = 0; e < 4; ++e) P[e] = __builtin_amdgcn_perm(__float_as_uint(v[2 * e + 1]), __float_as_uint(v[2 * e]), SEL);
-                return __builtin_bit_cast(bf16x8, P);
-            };
-            auto read_a = [&](int kk, float (&x)[8]) {
-                const int ca = 4 * kk + 2 * h;
-                const float4 x0 = Ab[arow * 8 + (ca ^ ((arow >> 1) & 7))], x1 = Ab[arow * 8 + ((ca + 1) ^ ((arow >> 1) & 7))];
-                x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
-            };
-            float4 wb[4][3];
-            auto read_b = [&](int kk, const int pl) {
-                const int cbk = 2 * kk + h;
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = j * 32 + li;
-                    wb[j][pl] = Bb[pl * 512 + row * 4 + (cbk ^ ((row >> 2) & 3))];
-                }
-            };
-    #define ERD_PC(AV, PL)                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV, __builtin_bit_cast(bf16x8, wb[j][PL]), acc[j], 0, 0, 0);
-            float x[8], xn[8];
-            read_a(0, x);
-            read_b(0, 2);
-            read_b(0, 1);
-            read_b(0, 0);
-    #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (kk == 0) read_a(1, xn);
-                const bf16x8 ah = pack_top(x);
-                ERD_PC(ah, 2)
-                if (kk == 0) read_b(1, 2);
-                ERD_PC(ah, 1)
-                ERD_PC(ah, 0)
-                float r1[8], r2[8];
-    #pragma unroll
-                for (int e = 0; e < 8; ++e) r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & TOP);
-                const bf16x8 am = pack_top(r1);
-                ERD_PC(am, 1)
-                if (kk == 0) read_b(1, 1);
-                ERD_PC(am, 0)
-    #pragma unroll
-                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & TOP);
-                const bf16x8 al = pack_top(r2);
-                ERD_PC(al, 0)
-                if (kk == 0) {
-                    read_b(1, 0);
-    #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = xn[e];
-                }
-            }
-    #undef ERD_PC
-        };
-
-        __syncthreads();                                       // slice 0 of the first tile is in stage 0
-        unsigned long long t_bar = 0, t_mul = 0, t_steps = 0; (void)t_bar; (void)t_mul; (void)t_steps;
-        PC_T0(t_begin);
-        int k = 0, g = 0;
-        for (;;) {
-            const int next_item = item_of(k + 1);
-            for (int s = 0; s < nkt; ++s, ++g) {
-                PC_T0(tm);
-                multiply(g & 1);
-                PC_ACC(t_mul, tm);
-                if (s == nkt - 1) {                            // the data waves have emptied the staging blocks one barrier ago
-                    float* wst = reinterpret_cast<float*>(smem + PC_STG_OFF + wave * PC_WST_BYTES);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            wst[((r & 3) + 8 * (r >> 2) + 4 * h) * PC_SLD + j * 32 + li] = acc[j][r];
-                            acc[j][r] = 0.f;
-                        }
-                }
-                PC_T0(tb);
-                __syncthreads();
-                PC_ACC(t_bar, tb);
-                ++t_steps;
-            }
-            if (next_item < 0) break;
-            ++k;
-        }
-#ifdef ERD_PC_TRACE
-        if (wave == 0 && lane == 0 && blockIdx.x < 256) {
-            g_pc_trace[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
-            g_pc_trace[blockIdx.x * 8 + 1] = t_bar;
-            g_pc_trace[blockIdx.x * 8 + 2] = t_mul;
-            g_pc_trace[blockIdx.x * 8 + 3] = t_steps;
-        }
-#endif
-        __syncthreads();                                       // (the data waves' last epilogue)
-    } else if (item >= 0) {
-        // ------------------------------------------------------------------ data waves
-        const int chunk = tid & 7, r0 = tid >> 3;              // A: thread -> (row r0 + 64 j, 16-B chunk)
-        const int chunkb = tid & 3, rb0 = tid >> 2;            // B: thread -> (cout row rb0, 16-B chunk of 8 bf16) of every plane
-        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
-        const unsigned plane_b = (unsigned)((long long)Cout * p.wrow * 2);
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_x3), 0, (int)((long long)Cout * p.wrow * 6), 0x00020000);
-        // TWO slices travel in registers (set = slice parity) while a third is multiplied: 80 KB in flight per CU, what the two
-        // co-resident workgroups of the stream-K kernel have
-        float4 ra[2][2], rb[2][3];
-        unsigned a_base[2], bx_base;
-        int cur_k = 0, cur_s = 0, cur_item = item;             // the slice to request next
-        auto setup = [&](int it) __attribute__((always_inline)) {
-            const int mt = it / ntn, nt = it - mt * ntn;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int m = mt * 128 + r0 + 64 * j;
-                a_base[j] = m < M ? (unsigned)(m * Cin + chunk * 4) * 4u : OOB;
-            }
-            const int co = nt * 128 + rb0;
-            bx_base = co < Cout ? (unsigned)(co * p.wrow + chunkb * 8) * 2u : OOB;
-        };
-        // request the cursor's slice into register set `set` (nothing once the tiles are used up) and move the cursor on
-        auto issue = [&](auto set_c) __attribute__((always_inline)) {
-            constexpr int set = decltype(set_c)::value;
-            if (cur_item < 0) return;
-            const unsigned ad = (unsigned)cur_s * 128u, bd = (unsigned)(p.wk[0] + cur_s * 32) * 2u;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) ra[set][j] = buf_load16(rs_in, a_base[j] == OOB ? OOB : a_base[j] + ad);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) rb[set][pl] = buf_load16(rs_w, bx_base == OOB ? OOB : bx_base + bd + (unsigned)pl * plane_b);
-            if (++cur_s == nkt) {
-                cur_s = 0;
-                cur_item = item_of(++cur_k);
-                if (cur_item >= 0) setup(cur_item);
-            }
-        };
-        // (storing a set that was never requested -- behind the last tile -- writes stale registers into a stage nobody reads)
-        auto store = [&](auto set_c) __attribute__((always_inline)) {
-            constexpr int set = decltype(set_c)::value;
-            float4* As = stage0 + set * PC_STAGE_F4;           // slice parity = register set = stage
-            float4* Bs = As + PC_A_F4;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = r0 + 64 * j;
-                As[row * 8 + (chunk ^ ((row >> 1) & 7))] = ra[set][j];
-            }
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) Bs[pl * 512 + rb0 * 4 + (chunkb ^ ((rb0 >> 2) & 3))] = rb[set][pl];
-        };
-        // epilogue job: tile (epi_m0, epi_n0), next portion epi_q (8 = nothing to do)
-        using OutT = float;
-        OutT* __restrict__ out = reinterpret_cast<OutT*>(sg.out);
-        const OutT* res = reinterpret_cast<const OutT*>(sg.res);
-        const OutT* msk = reinterpret_cast<const OutT*>(sg.mask);
-        const int c4 = tid & 31, rsub = tid >> 5;              // float4 column, row inside a group of sixteen
-        int epi_m0 = 0, epi_n0 = 0, epi_q = 8, cs_n0 = -1;
-        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4* const red = reinterpret_cast<float4*>(smem + PC_RED_OFF);
-        // residual rows (or mask rows when there is no residual) of the portions the NEXT step stores are requested one step ahead
-        const OutT* pf_src = res ? res : msk;
-        float4 pf[PM];
-        auto prefetch = [&](int m0, int n0, int q0, int nport) __attribute__((always_inline)) {
-            const int co = n0 + c4 * 4;
-            if (pf_src == nullptr || co >= Cout) return;
-#pragma unroll
-            for (int u = 0; u < PM; ++u) {
-                const int q = q0 + u, m = m0 + q * 16 + rsub;
-                if (u < nport && q < 8 && m < M) pf[u] = erd::ld4(pf_src + (long long)m * Cout + co);
-            }
-        };
-        auto drain = [&](int nport) __attribute__((always_inline)) {
-            const int co = epi_n0 + c4 * 4;
-            const bool cvalid = co < Cout;
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cvalid && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
-            if (cvalid && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
-#pragma unroll
-            for (int u = 0; u < PM; ++u) {
-                const int q = epi_q + u, r = q * 16 + rsub, m = epi_m0 + r;
-                if (!(u < nport && q < 8 && m < M && cvalid)) continue;
-                const float* st = reinterpret_cast<const float*>(smem + PC_STG_OFF + (r >> 5) * PC_WST_BYTES) + (r & 31) * PC_SLD + c4 * 4;
-                float4 v = *reinterpret_cast<const float4*>(st);
-                const long long off = (long long)m * Cout + co;
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (res) { v.x += pf[u].x; v.y += pf[u].y; v.z += pf[u].z; v.w += pf[u].w; }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (msk) {
-                    const float4 mv = res ? erd::ld4(msk + off) : pf[u];
-                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
-                    v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
-                }
-                erd::st4(out + off, v);
-                csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
-            }
-            epi_q = min(8, epi_q + nport);
-            if (epi_q == 8 && p.colsum) {                     // this tile's partial column sums: combined after the next barrier
-                red[rsub * 32 + c4] = csum;
-                csum = make_float4(0.f, 0.f, 0.f, 0.f);
-                cs_n0 = epi_n0;
-            }
-        };
-        auto colsum_flush = [&]() __attribute__((always_inline)) {                            // (after a barrier behind the write of `red`)
-            if (cs_n0 >= 0 && tid < 32 && cs_n0 + tid * 4 < Cout) {
-                float4 t = red[tid];
-#pragma unroll
-                for (int q = 1; q < 16; ++q) { const float4 v = red[q * 32 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-                float* cs = p.colsum + (p.colsum_copies > 1 ? (int64_t)(blockIdx.x & (p.colsum_copies - 1)) * Cout : 0) + cs_n0 + tid * 4;
-                atomicAdd(cs + 0, t.x); atomicAdd(cs + 1, t.y); atomicAdd(cs + 2, t.z); atomicAdd(cs + 3, t.w);
-            }
-            cs_n0 = -1;
-        };
-        // ---- prologue: slice 0 of the first tile into stage 0, slices 1 and 2 on their way
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        setup(cur_item);
-        issue(S0{});
-        issue(S1{});
-        store(S0{});
-        issue(S0{});
-        __syncthreads();
-        int k = 0;
-        int mt = item / ntn, nt = item - mt * ntn;
-        // one slice step: stage `par` is being multiplied; the other one receives slice g + 1 from its register set, which then
-        // takes the request for slice g + 3
-        unsigned long long d_store = 0, d_drain = 0, d_bar = 0; (void)d_store; (void)d_drain; (void)d_bar;
-        auto step = [&](auto par_c, const int s) __attribute__((always_inline)) {
-            using Other = std::integral_constant<int, decltype(par_c)::value ^ 1>;
-            colsum_flush();
-            PC_T0(ts);
-            store(Other{});
-            issue(Other{});
-            PC_ACC(d_store, ts);
-            PC_T0(td);
-            if (epi_q < 8 && s < nkt - 1) {
-                drain(min(PORT, PM));                          // (requested one step ago)
-                for (int todo = PORT - PM; todo > 0 && epi_q < 8; todo -= PM) {      // two-slice tiles: the rest, latency exposed
-                    prefetch(epi_m0, epi_n0, epi_q, min(todo, PM));
-                    drain(min(todo, PM));
-                }
-            }
-            if (s == nkt - 1) prefetch(mt * 128, nt * 128, 0, min(PORT, PM));   // the next step starts on THIS tile's epilogue
-            else if (epi_q < 8 && s + 1 < nkt - 1) prefetch(epi_m0, epi_n0, epi_q, min(PORT, PM));
-            PC_ACC(d_drain, td);
-            PC_T0(tb);
-            __syncthreads();
-            PC_ACC(d_bar, tb);
-        };
-        for (;;) {
-            const int next_item = item_of(k + 1);
-            for (int s = 0; s < nkt; s += 2) {                 // (nkt is even: a tile starts on stage 0)
-                step(S0{}, s);
-                step(S1{}, s + 1);
-            }
-            // tile k is complete in the staging blocks: it becomes the epilogue job
-            epi_m0 = mt * 128; epi_n0 = nt * 128; epi_q = 0;
-            if (next_item < 0) break;
-            item = next_item;
-            mt = item / ntn; nt = item - mt * ntn;
-            ++k;
-        }
-#ifdef ERD_PC_TRACE
-        if (tid == 0 && blockIdx.x < 256) {
-            g_pc_trace[blockIdx.x * 8 + 4] = d_store;
-            g_pc_trace[blockIdx.x * 8 + 5] = d_drain;
-            g_pc_trace[blockIdx.x * 8 + 6] = d_bar;
-        }
-#endif
-        // ---- the last tile's epilogue (nothing left to overlap it with)
-        colsum_flush();
-        drain(min(PORT, PM));                                  // (requested during the last slice)
-        while (epi_q < 8) { prefetch(epi_m0, epi_n0, epi_q, PM); drain(PM); }
-        __syncthreads();
-        colsum_flush();
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // weight gradient: G[co][t][ci] = sum_p dz[p][co] * x[p+tap t][ci]; K = pixels (split over gridDim.z)
 // LDS tiles are k-major ([32 px][128 ch], exactly the global layout); fragments by ds_read_b32.
 // -------------------------------------------------------------------------------------------------
@@ -2156,38 +1812,6 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     return erd::check_launch("conv_igemm");
 }
 
-// the producer / consumer kernel serves: one dense map, one tap at offset zero, stride 1 (a plain GEMM over the pixel axis)
-bool x3_pc_ok(const erd_conv_desc* d, int min_rounds, int max_k) {
-    if (d->nseg != 1 || d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0 || d->in_stride != 1 || d->out_stride != 1 || d->oy != 0 || d->ox != 0)
-        return false;
-    const erd_conv_seg& g = d->seg[0];
-    if (g.alpha || g.ntaps != 0 || d->in_bf16 || d->out_bf16) return false;
-    if (d->Cin % 64 != 0 || d->Cin > max_k || d->Cout % 4 != 0 || d->wrow % 8 != 0 || d->wk[0] % 8 != 0) return false;
-    const int64_t ghw = (int64_t)g.GH * g.GW;
-    if (g.in_nstride != ghw * d->Cin || g.out_nstride != ghw * d->Cout || g.IH != g.GH || g.IW != g.GW || g.OH != g.GH || g.OW != g.GW)
-        return false;
-    if (d->colsum && d->colsum_copies > 1 && (d->colsum_copies & (d->colsum_copies - 1)) != 0) return false;
-    const int64_t M = (int64_t)g.N * ghw;
-    if (M * d->Cout >= (1ll << 31)) return false;
-    const int64_t items = ((M + 127) / 128) * ((d->Cout + 127) / 128);
-    return num_cus() % 8 == 0 && items >= (int64_t)min_rounds * num_cus();
-}
-
-int launch_x3_pc(const erd_conv_desc* d, hipStream_t st) {
-    const erd_conv_seg& g = d->seg[0];
-    const int M = g.N * g.GH * g.GW;
-    const int ntn = (d->Cout + 127) / 128, nitems = ((M + 127) / 128) * ntn;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pc_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pc_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
-        attr_done = true;
-    }
-    if (d->Cin / 32 < 4) hipLaunchKernelGGL(conv_x3_pc_kernel<4>, dim3(num_cus()), dim3(768), PC_LDS, st, *d, M, ntn, nitems, (int*)nullptr);
-    else hipLaunchKernelGGL(conv_x3_pc_kernel<3>, dim3(num_cus()), dim3(768), PC_LDS, st, *d, M, ntn, nitems, (int*)nullptr);
-    return erd::check_launch("conv_x3_pc");
-}
-
 }  // namespace
 
 extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
@@ -2241,11 +1865,6 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     static const int x3_min_k = getenv("ERD_X3_MIN_K") ? atoi(getenv("ERD_X3_MIN_K")) : 0;
     if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0 && (d->Cout % 4 == 0 || !d->w) && (d->ntaps * d->Cin >= x3_min_k || !d->w)) {
         ERD_REQUIRE(d->Cout % 4 == 0, "conv: the three-limb kernel stores 16-byte rows (Cout %% 4 == 0); pass `w` for Cout=%d", d->Cout);
-        // thin 1x1 / stride-1 layers: the producer / consumer kernel (ERD_X3_PC=0 keeps every launch on the kernel below)
-        const int pc = getenv("ERD_X3_PC") ? atoi(getenv("ERD_X3_PC")) : 0;       // (read per call while the kernel is opt-in: tests toggle it)
-        static const int pc_rounds = getenv("ERD_X3_PC_ROUNDS") ? atoi(getenv("ERD_X3_PC_ROUNDS")) : 3;
-        static const int pc_max_k = getenv("ERD_X3_PC_MAX_K") ? atoi(getenv("ERD_X3_PC_MAX_K")) : 256;
-        if (pc && x3_pc_ok(d, pc_rounds, pc_max_k)) return launch_x3_pc(d, st);
         // "f32x3": fp32 maps and results, products on the bf16 matrix cores through exact three-limb splits (see the kernel)
         if (seg_taps_any) return launch_igemm<128, 128, 4, 1, 32, 2, false, true, false, false, true>(d, st);
         if (d->Cout <= 64) return launch_igemm<128, 64, 4, 1, 32, 2, false, false, false, false, true>(d, st);
@@ -2312,11 +1931,6 @@ int launch_wgrad(const erd_wgrad_desc* d, hipStream_t st) {
 }
 }  // namespace
 
-#ifdef ERD_PC_TRACE
-extern "C" int erd_pc_trace(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_trace), sizeof(g_pc_trace));
-}
-#endif
 #ifdef ERD_IGEMM_TRACE
 extern "C" int erd_igemm_trace(unsigned long long* out) {
     (void)hipDeviceSynchronize();
