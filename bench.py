@@ -225,7 +225,15 @@ def self_launch(args, argv) -> int:
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    child_args = [a for a in argv if a not in ("--launcher", "spawn")]
+    child_args, skip = [], False
+    for a in argv:                     # drop `--launcher X` / `--launcher=X` by position (never by value); the children get `--launcher none`
+        if skip:
+            skip = False
+        elif a == "--launcher":
+            skip = True
+        elif not a.startswith("--launcher="):
+            child_args.append(a)
+    child_args += ["--launcher", "none"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ERD_BENCH_CHILD="1")
@@ -257,6 +265,8 @@ def main():
                          "teacher is replayed from one hipGraph per padded shape (implies --teacher-graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-strict-fp32", action="store_true",
+                    help="skip the short `--compute f32` leg whose rate the f32x3 line carries as `strict_fp32`")
     ap.add_argument("--teacher-graph", action="store_true",
                     help="replay the frozen teacher's pass from a hipGraph (BASELINE configs[4]); same arithmetic")
     ap.add_argument("--compute", choices=["f32x3", "f32", "bf16"], default="f32x3",
@@ -296,12 +306,14 @@ def main():
                          f"its own ranks (--launcher auto, the default)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    from erd_amd.dist_utils import backend_name, device_index
+    dev_index = device_index(local_rank)       # (ERD_DIST_BACKEND=gloo: ranks may share a GPU -- the world-2 correctness vehicle)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or in_torchrun or os.environ.get("ERD_FORCE_DIST") == "1":      # (world 1 under torchrun: the RCCL path on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # 'nccl' == RCCL on ROCm
+        dist.init_process_group(backend_name(), rank=rank, world_size=world)   # 'nccl' == RCCL on ROCm
 
     from erd_amd import functional as Fn
     from erd_amd import kernels as K
@@ -380,6 +392,37 @@ def main():
         trainer.flush()
         ktime = K.timing_end()
         set_serial(args.serial)
+    # ---- the strict-fp32 sibling of the headline: the same step with EVERY GEMM-shaped launch on the fp32 matrix cores
+    # (`--compute f32`: IEEE fp32 products, the reference's arithmetic, resnet.py:268-300 -> ATen conv), a short leg on a second
+    # trainer built under that mode; reported next to `value`, never as `value`
+    strict = None
+    if args.compute == "f32x3" and not args.no_strict_fp32 and not args.serial and not args.mixed_res:
+        K.set_compute("f32")
+        try:
+            model2, _ = build_model(device, rank, args.arch)
+            tr2 = ERDTrainer(model2, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay,
+                             base_batch_size=cfg.auto_scale_lr.base_batch_size, batch_size_per_gpu=args.batch,
+                             auto_scale_lr=cfg.auto_scale_lr.enable, teacher_graph=args.teacher_graph, step_graph=args.step_graph)
+            s_warm, s_steps = 2, 5
+            for j in range(s_warm):
+                tr2.train_step(*seq(j), next_batch=nb(j))
+            tr2.flush()
+            barrier()
+            t1 = time.perf_counter()
+            for j in range(s_warm, s_warm + s_steps):
+                slog = tr2.train_step(*seq(j), next_batch=nb(j))
+            tr2.flush()
+            barrier()
+            dt2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            if dist.is_initialized():
+                dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+            strict = {"value": round(args.batch * world * s_steps / float(dt2.item()), 3), "unit": "images/sec",
+                      "ms_per_step": round(1e3 * float(dt2.item()) / s_steps, 3), "steps": s_steps, "warmup": s_warm,
+                      "compute_mode": "f32", "loss": round(float(slog["loss"].detach()), 6),
+                      "arithmetic": "fp32 throughout, every GEMM-shaped launch on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}
+            del tr2, model2
+        finally:
+            K.set_compute(args.compute)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     devices = [f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
     if dist.is_initialized():
@@ -419,7 +462,8 @@ def main():
             "teacher": "hipGraph replay (one graph per padded shape and buffer parity)" if args.teacher_graph else "eager launches",
             "step_graph": bool(trainer.step_graph),
         }
-        out["collectives"] = {"backend": "nccl (RCCL)" if dist.is_initialized() else None,
+        out["collectives"] = {"backend": ({"nccl": "nccl (RCCL)", "gloo": "gloo (host-staged: correctness vehicle, not a performance path)"}[dist.get_backend()]
+                                          if dist.is_initialized() else None),
                               "world_size": dist.get_world_size() if dist.is_initialized() else 1, "devices": devices,
                               "launched_by": "bench.py self_launch -> torch.distributed.run" if os.environ.get("ERD_BENCH_CHILD") == "1"
                               else ("torch.distributed.run" if in_torchrun else "single process")}
@@ -471,6 +515,33 @@ def main():
                                "algorithmic_bytes_per_launch": int(dom["min_bytes"] / dom["launches"])}
             out["roofline"]["mfma_busy_pmc"], out["roofline"]["mfma_busy_source"] = pmc_mfma_busy(pmc_sym, args.compute)
             out["roofline"]["mfma_busy_static"] = True
+            # ---- every GEMM-shaped kernel symbol against BOTH of its bounds, on the pipe it runs on: live HIP-event
+            # numbers of this run + the committed PMC passes (static, labelled); everything needed to recompute a fraction is in the row
+            per_kernel = {}
+            for ksym, g in groups.items():
+                on_bf16 = args.compute == "bf16" or (x3 and ksym in X3_SYMS)
+                k_exec = WINO_EXECUTED if ksym == "wino_conv_kernel" else (6.0 if (x3 and ksym in X3_SYMS) else 1.0)
+                k_peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
+                k_alg = g["flop"] / (g["ms"] * 1e-3) / 1e12
+                k_us = 1e3 * g["ms"] / g["launches"]
+                k_bytes = g["min_bytes"] / g["launches"]
+                k_pmc = ({"conv_wgrad_row3_kernel": "conv_wgrad_row3_x3_kernel<2, 1", "conv_wgrad_kernel": "conv_wgrad_row3_x3_kernel<2, 2"}.get(ksym, ksym)
+                         if x3 else ksym)
+                k_traffic, k_src = pmc_traffic_per_launch(k_pmc, args.compute)
+                k_busy, _ = pmc_mfma_busy(k_pmc, args.compute)
+                mfma_frac = k_alg * k_exec / k_peak
+                hbm_frac = k_bytes / (k_us * 1e-6) / (HBM_PEAK_GBS * 1e9)
+                per_kernel[ksym] = {
+                    "pipe": "bf16 MFMA (v_mfma_f32_32x32x16_bf16)" if on_bf16 else "fp32 MFMA",
+                    "pipe_peak_tflops": k_peak, "ms_per_step": round(g["ms"] / rsteps, 3), "launches_per_step": g["launches"] // rsteps,
+                    "avg_launch_us": round(k_us, 2), "algorithmic_tflops": round(k_alg, 2), "executed_flop_fraction": round(k_exec, 4),
+                    "executed_tflops": round(k_alg * k_exec, 2), "mfma_frac": round(mfma_frac, 4),
+                    "algorithmic_bytes_per_launch": int(k_bytes), "hbm_GBps_algorithmic": round(k_bytes / (k_us * 1e-6) / 1e9, 1),
+                    "hbm_frac": round(hbm_frac, 4), "bound": "mfma" if mfma_frac >= hbm_frac else "hbm",
+                    "frac_of_binding_roofline": round(max(mfma_frac, hbm_frac), 4),
+                    "pmc_traffic_bytes_per_launch": k_traffic, "pmc_traffic_over_algorithmic": round(k_traffic / k_bytes, 2) if k_traffic else None,
+                    "pmc_mfma_busy": k_busy, "pmc_static": True, "pmc_source": k_src}
+            out["roofline"]["per_kernel"] = per_kernel
             # ---- step level, three ways, all over the un-instrumented step time of the timed region and the same peak:
             #  step_frac           the ALGORITHMIC work of the reference's step (both copies of the frozen trunk)
             #  step_frac_executed  minus the student's copy of the shared frozen trunk, which this build does not execute
@@ -497,6 +568,8 @@ def main():
             out["kernels"] = {k: {"ms_per_step": round(r["ms"] / rsteps, 3),
                                   "tflops": round(r["flop"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flop"] else None,
                                   "launches_per_step": r["launches"] // rsteps} for k, r in ktime.items()}
+        if strict is not None:
+            out["strict_fp32"] = strict
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

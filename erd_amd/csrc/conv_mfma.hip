@@ -97,8 +97,8 @@ int xcd_order_enabled() {
 // moves 8-B groups of four channels.  Accumulation, scale/shift, the stream-K slabs and the column sums stay fp32.
 // X3 = true ("f32x3", erd_conv_desc::w_x3): fp32 maps, fp32 accumulation, fp32 results -- but the PRODUCTS run on the bf16 matrix
 // cores, which on gfx950 are 16x faster than the fp32 ones (v_mfma_f32_32x32x2_f32 runs at the vector rate).  Every fp32
-// value is the exact sum of three bf16 limbs (8 + 8 + 8 significand bits: hi = truncate(x), mid = truncate(x - hi),
-// lo = x - hi - mid); a product a*b is then the sum of nine exact limb products, of which the six with weight >= 2^-16 are
+// value is the exact sum of three bf16 limbs (8 + 8 + 8 significand bits: hi = rne(x), mid = rne(x - hi),
+// lo = x - hi - mid; erd_common.h); a product a*b is then the sum of nine exact limb products, of which the six with weight >= 2^-16 are
 // accumulated (a_hi b_hi, a_hi b_mid, a_mid b_hi, a_hi b_lo, a_mid b_mid, a_lo b_hi: what is dropped is below 2^-23 of
 // |a*b|, the size of fp32's own rounding of that product).  Weights arrive pre-split (three bf16 planes); activations stay
 // fp32 in HBM and in LDS and are split in registers when a wave reads its fragments.  The waves form a 4 x 1 grid (each
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
         constexpr int KSTEPS = X3 ? 2 : CH / 2;      // one k-step = the two chunks (h = 0 / 1) a wave's lanes read (f32x3: 16 channels)
         constexpr int APS = (AJ + KSTEPS - 1) / KSTEPS, BPS = (NBL + KSTEPS - 1) / KSTEPS;   // loads per k-step
         // f32x3: one K-slice = two k16 steps.  A lane owns pixel row li of its wave's 32 rows and the 8 channels 16 s + 8 h ..
-        // + 7 of step s: two 16-B reads of fp32 values, split into three bf16x8 limbs (truncation: and / sub, exact), and
+        // + 7 of step s: two 16-B reads of fp32 values, split into three bf16x8 limbs (round-to-nearest: cvt_pk / sub, exact), and
         // three 16-B reads per cout block of the pre-split weights; then six MFMAs per block, smallest terms first.
         auto k_slice_x3 = [&](const int kt, const int par) {
             const int buf = par;
@@ -377,12 +377,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
             const float4* Bb = Bs + buf * 3 * BN * CHB;
             const int arow = wm * 32 + li;
             typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-            constexpr unsigned TOP = 0xffff0000u, SEL = 0x07060302u;      // v_perm: upper halves of (second, first) operand
-            auto pack_top = [&](const float (&v)[8]) {                      // bf16x8 of the upper 16 bits of eight fp32 values
-                u4v P;
+            // limb of eight values: rounded to nearest even and packed pairwise (v_cvt_pk_bf16_f32); `rest` = v - limb, exact
+            // (erd::limbs3_pair spelled out so that the remainders can be formed under the upper limb's MFMAs)
+            auto limb = [&](const float (&v)[8], u4v& P) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) P[e] = __builtin_amdgcn_perm(__float_as_uint(v[2 * e + 1]), __float_as_uint(v[2 * e]), SEL);
+                for (int e = 0; e < 4; ++e) P[e] = erd::pack2_bf16(v[2 * e], v[2 * e + 1]);
                 return __builtin_bit_cast(bf16x8, P);
+            };
+            auto rest = [&](const float (&v)[8], const u4v& P, float (&r)[8]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r[2 * e] = v[2 * e] - erd::bf16_lo(P[e]);
+                    r[2 * e + 1] = v[2 * e + 1] - erd::bf16_hi(P[e]);
+                }
             };
             auto read_a = [&](int kk, float (&x)[8]) {
                 const int ca = 4 * kk + 2 * h;                 // fp32 chunks ca, ca + 1 of the pixel row: channels 16 kk + 8 h .. + 7
@@ -427,7 +434,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
                         if (kk * BPS + q < NBL) load_b(kk * BPS + q, 0);
                 }
 #endif
-                const bf16x8 ah = pack_top(x);
+                u4v ph, pm, pl;
+                const bf16x8 ah = limb(x, ph);
                 ERD_X3(ah, 2)
 #ifndef ERD_X3_NOBREAD    // (timing probe: the second k16 step re-uses the first one's weight fragments)
                 if (kk == 0) read_b(1, 2);
@@ -439,9 +447,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
                 const bf16x8 am = ah, al = ah;
                 (void)r1; (void)r2;
 #else
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & TOP);
-                const bf16x8 am = pack_top(r1);
+                rest(x, ph, r1);
+                const bf16x8 am = limb(r1, pm);
 #endif
                 ERD_X3(am, 1)
 #ifndef ERD_X3_NOBREAD
@@ -449,9 +456,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
 #endif
                 ERD_X3(am, 0)
 #ifndef ERD_X3_NOVALU
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & TOP);
-                const bf16x8 al = pack_top(r2);
+                rest(r1, pm, r2);
+                const bf16x8 al = limb(r2, pl);
 #endif
                 ERD_X3(al, 0)
                 if (kk == 0) {
@@ -1166,7 +1172,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_row3_kernel(const erd_
 // product formed on the bf16 matrix cores from exact limb splits of BOTH operands (see conv_igemm_kernel<..., X3>).
 //   * A K-slice is 16 output pixels of one image row (x: 18 entries with the one-pixel halo), as in the fp32 kernel.  The
 //     bf16 MFMA wants 8 consecutive PIXELS of one channel per lane while memory is pixel-major: each thread loads a
-//     4-pixel x 4-channel micro-tile (four 16-B loads), splits its 16 values into limbs (and / sub / and / sub, exact) and
+//     4-pixel x 4-channel micro-tile (four 16-B loads), splits its 16 values into limbs (cvt_pk / sub / cvt_pk / sub, exact) and
 //     stores them transposed -- 8 bytes (4 pixels of one channel) per limb plane -- into channel-major LDS rows:
 //     dz [3 planes][BMR co][16 px] (32-B rows, chunk XOR-swizzled), x [3 planes][64 ci][18 px] (48-B rows: 16 lanes x 12
 //     banks tile all 64 banks).  Every value is split exactly once.
@@ -1294,26 +1300,15 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
     };
     auto store_lds = [&](int buf) {
         if (!(is_a || is_b)) return;
-        constexpr unsigned TOP = 0xffff0000u, SEL = 0x07060302u;
         const float v[4][4] = {{rv[0].x, rv[0].y, rv[0].z, rv[0].w}, {rv[1].x, rv[1].y, rv[1].z, rv[1].w},
                                {rv[2].x, rv[2].y, rv[2].z, rv[2].w}, {rv[3].x, rv[3].y, rv[3].z, rv[3].w}};     // [pixel][channel]
         char* base = smem + buf * BUF + (is_a ? 0 : 3 * A_PL);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float r1[4], r2[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r1[i] = v[i][c] - __uint_as_float(__float_as_uint(v[i][c]) & TOP);
-                r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & TOP);
-            }
             const int row = cg * 4 + c;
-            uint2 hi, mid, lo;
-            hi.x = __builtin_amdgcn_perm(__float_as_uint(v[1][c]), __float_as_uint(v[0][c]), SEL);
-            hi.y = __builtin_amdgcn_perm(__float_as_uint(v[3][c]), __float_as_uint(v[2][c]), SEL);
-            mid.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), SEL);
-            mid.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), SEL);
-            lo.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), SEL);
-            lo.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), SEL);
+            uint2 hi, mid, lo;      // four pixels of channel c per limb plane (round-to-nearest limbs, erd_common.h)
+            erd::limbs3_pair(v[0][c], v[1][c], hi.x, mid.x, lo.x);
+            erd::limbs3_pair(v[2][c], v[3][c], hi.y, mid.y, lo.y);
             // dz: 32-B rows, 16-B chunk (pg >> 1) swizzled by (row >> 3) & 1; x: 48-B rows, entry e at byte 2 e
             const int off = (is_a || !ROW3) ? row * A_ROWB + (((pg >> 1) ^ ((row >> 3) & 1)) << 4) + ((pg & 1) << 3) : row * B_ROWB + pg * 8;
             const int plane = is_a ? A_PL : B_PL;
@@ -1683,16 +1678,7 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
-// three bf16 limbs of a fp32 value by truncation: x == hi + mid + lo exactly (8 + 8 + 8 significand bits)
-__device__ __forceinline__ void limbs3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
-    const unsigned xb = __float_as_uint(x);
-    const float r1 = x - __uint_as_float(xb & 0xffff0000u);
-    const unsigned r1b = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(r1b & 0xffff0000u);
-    hi = (unsigned short)(xb >> 16);
-    mid = (unsigned short)(r1b >> 16);
-    lo = (unsigned short)(__float_as_uint(r2) >> 16);
-}
+using erd::limbs3;      // three bf16 limbs of an fp32 value, round-to-nearest (erd_common.h): hi + mid + lo == x exactly
 
 // dst[plane][i] = limb `plane` of src[i]
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {

@@ -58,6 +58,27 @@ __device__ __forceinline__ float4 unpack4_bf16(uint2 u) {
 }
 __device__ __forceinline__ uint2 pack4_bf16(float4 v) { return make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w)); }
 
+// ---- three-limb split ("f32x3"): an fp32 value as the EXACT sum of three bf16 values, each rounded to nearest even:
+//   hi = rne(x), mid = rne(x - hi), lo = x - hi - mid      (x - hi has <= 16 significant bits, x - hi - mid <= 8: both exact)
+// |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x| (half an ulp of the limb above), and the remainders are SIGN-SYMMETRIC around zero --
+// a truncating split (the round-3 form) leaves remainders that all carry the sign of x, twice as large, so the limb products a
+// three-limb GEMM drops (a_mid b_lo + a_lo b_mid + a_lo b_lo) were a bias towards zero of up to 2^-21 |a b| per product; here
+// they are zero-mean and below 2^-23 |a b|.  Two values per call: v_cvt_pk_bf16_f32 rounds and packs a pair in one instruction.
+// limb words: value 0 in bits 0..15, value 1 in bits 16..31 (the order the bf16 MFMA fragments and LDS rows want).
+__device__ __forceinline__ void limbs3_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = pack2_bf16(x0, x1);
+    const float r0 = x0 - bf16_lo(hi), r1 = x1 - bf16_hi(hi);
+    mid = pack2_bf16(r0, r1);
+    lo = pack2_bf16(r0 - bf16_lo(mid), r1 - bf16_hi(mid));
+}
+__device__ __forceinline__ void limbs3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    unsigned h, m, l;
+    limbs3_pair(x, 0.f, h, m, l);
+    hi = (unsigned short)(h & 0xffffu);
+    mid = (unsigned short)(m & 0xffffu);
+    lo = (unsigned short)(l & 0xffffu);
+}
+
 // Element type of a map: float or erd::bf16s (a 16-bit storage cell).  ld4 / st4 move four consecutive values
 // (16-B / 8-B aligned), ld1 / st1 one.
 struct bf16s { unsigned short bits; };

@@ -74,15 +74,12 @@ __device__ __forceinline__ void split3_block(const erd_weight_prep_item& it, int
     const int64_t n = (int64_t)it.Cout * it.ntaps * it.Cin;
     const int64_t i = local * 256ll + threadIdx.x;
     if (i >= n) return;
-    const float x = it.w[i];
-    const unsigned xb = __float_as_uint(x);
-    const float r1 = x - __uint_as_float(xb & 0xffff0000u);
-    const unsigned r1b = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(r1b & 0xffff0000u);
+    unsigned short h, m, l;
+    erd::limbs3(it.w[i], h, m, l);
     unsigned short* d = reinterpret_cast<unsigned short*>(it.dst);
-    d[i] = (unsigned short)(xb >> 16);
-    d[n + i] = (unsigned short)(r1b >> 16);
-    d[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+    d[i] = h;
+    d[n + i] = m;
+    d[2 * n + i] = l;
 }
 
 __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_item* __restrict__ items, int nitems) {

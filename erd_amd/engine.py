@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import kernels as K
+from .dist_utils import all_reduce_sum_
 from .modules import GFLIncrementERD, parse_losses
 from .structures import unpack_gt_instances
 
@@ -125,7 +126,7 @@ class BucketedGradSync:
             for st in self.streams:
                 if st != cs:
                     cs.wait_stream(st)
-        self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self._works.append(all_reduce_sum_(self.flat.grad[s:e], async_op=True))
 
     def _make_hook(self, i: int):
         def hook(_p):

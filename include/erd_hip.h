@@ -100,11 +100,11 @@ typedef struct {
      * outputs in the low-precision type the same way. */
     int in_bf16, out_bf16;
     /* optional ("f32x3" mode): the same weights as three bf16 LIMB planes, [3][Cout][wrow] (erd_split3 / erd_weight_transpose_x3):
-     * plane 0 = the upper 16 bits of each fp32 weight, plane 1 = the upper 16 bits of the remainder, plane 2 = what is left
-     * -- w == p0 + p1 + p2 EXACTLY.  When set (and Cin % 4 == 0, Cout % 4 == 0; otherwise the launch needs `w`) maps, accumulation
+     * plane 0 = each fp32 weight rounded to bf16 (nearest even), plane 1 = the remainder rounded to bf16, plane 2 = what is left
+     * (at most 8 significant bits) -- w == p0 + p1 + p2 EXACTLY, |p1| <= 2^-8 |w|, |p2| <= 2^-16 |w|, remainders sign-symmetric.  When set (and Cin % 4 == 0, Cout % 4 == 0; otherwise the launch needs `w`) maps, accumulation
      * and results stay fp32 but every product a*w is formed on the bf16 matrix cores as the sum of the six limb products of
-     * weight >= 2^-16 (the activation is split the same way in registers): the dropped terms are below 2^-23 |a*w|, fp32's own
-     * rounding of that product.  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate; six bf16 MFMAs cost 3/8 of one fp32 MFMA. */
+     * weight >= 2^-16 (the activation is split the same way in registers): the dropped terms are zero-mean and below 2^-23 |a*w|,
+     * fp32's own rounding of that product (the round-3 library split by truncation: dropped terms up to 2^-21 |a*w|, all of the product's sign).  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate; six bf16 MFMAs cost 3/8 of one fp32 MFMA. */
     const void* w_x3;
 } erd_conv_desc;
 
@@ -115,7 +115,7 @@ int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream);
 size_t erd_conv_igemm_ws_bytes(int max_tiles);
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements */
 int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
-/* the three bf16 limbs of every value by truncation: dst[0][i] + dst[1][i] + dst[2][i] == src[i] exactly; dst = [3][n] bf16
+/* the three bf16 limbs of every value, each rounded to nearest even: dst[0][i] + dst[1][i] + dst[2][i] == src[i] exactly; dst = [3][n] bf16
  * (erd_conv_desc::w_x3 of a forward convolution) */
 int erd_split3(const float* src, void* dst, int64_t n, erd_stream_t stream);
 

@@ -617,10 +617,14 @@ def distill_loss_single(anchors: Tensor, s_cls_old: Tensor, s_bbox: Tensor, idx_
 
 def erd_head_loss(t_cls_maps, t_bbox_maps, s_cls_maps, s_bbox_maps, gt_bboxes: Sequence[Tensor],
                   gt_labels: Sequence[Tensor], metas: Sequence[dict], c_old: int, c_all: int,
-                  dist_loss_weight: float = 1.0, world_size: int = 1, return_aux: bool = False):
+                  dist_loss_weight: float = 1.0, world_size: int = 1, return_aux: bool = False,
+                  rank_mean_factors: Optional[Tuple[float, float]] = None):
     """GFLIncrementERD.sel_pos + GFLHeadIncrementERD.loss_by_feat
     (gfl_increment_erd.py:165-200; gfl_head_increment_erd.py:334-454).  reduce_mean is the
-    identity for world_size 1 (dist_utils.py:59-65)."""
+    identity for world_size 1 (dist_utils.py:59-65).  Data parallel (world > 1): the two normalisers are means over the
+    ranks of each rank's LOCAL value (`reduce_mean`, gfl_head_increment_erd.py:390-391 and :406-407, the second one
+    clamped to >= 1 AFTER the mean); a multi-rank evaluation runs every rank's batch once for its local values
+    (aux['avg_factor'], aux['weight_sum']), averages them and passes `rank_mean_factors = (mean num_pos, mean weight sum)`."""
     N = s_cls_maps[0].shape[0]
     sizes = [tuple(m.shape[-2:]) for m in s_cls_maps]
     nl = [h * w for h, w in sizes]
@@ -635,7 +639,7 @@ def erd_head_loss(t_cls_maps, t_bbox_maps, s_cls_maps, s_bbox_maps, gt_bboxes: S
         labs.append(lab); lws.append(lw); bts.append(bt)
         npos += max(p, 1)                    # sampling_result.py:96-100 avg_factor = max(#pos,1)
     labs, lws, bts = torch.stack(labs), torch.stack(lws), torch.stack(bts)
-    avg = float(npos) / 1.0                  # reduce_mean over ranks: caller handles N>1
+    avg = float(npos) if rank_mean_factors is None else float(rank_mean_factors[0])      # :390-391
     s_cls = flatten_levels(s_cls_maps)
     s_bbox = flatten_levels(s_bbox_maps)
     lc, lb, ld, ws = [], [], [], []
@@ -648,7 +652,8 @@ def erd_head_loss(t_cls_maps, t_bbox_maps, s_cls_maps, s_bbox_maps, gt_bboxes: S
                                 STRIDES[l], c_old, c_all, avg)
         lc.append(r[0]); lb.append(r[1]); ld.append(r[2]); ws.append(r[3])
         off += n_l
-    avg2 = float(sum(ws).detach().clamp(min=1))
+    wsum = float(sum(ws).detach())
+    avg2 = max(wsum if rank_mean_factors is None else float(rank_mean_factors[1]), 1.0)  # :406-407 (float(): the reference's .item())
     lb = [x / avg2 for x in lb]
     ld = [x / avg2 for x in ld]
     dc, db, keeps = [], [], []
@@ -660,7 +665,8 @@ def erd_head_loss(t_cls_maps, t_bbox_maps, s_cls_maps, s_bbox_maps, gt_bboxes: S
     if return_aux:
         aux = dict(ers_cls=[e[0] for e in ers], ers_bbox=[e[1] for e in ers],
                    thr_cls=[e[2] for e in ers], thr_bbox=[e[3] for e in ers], nms_keep=keeps,
-                   labels=labs, label_weights=lws, bbox_targets=bts, avg_factor=avg, avg_factor2=avg2)
+                   labels=labs, label_weights=lws, bbox_targets=bts, avg_factor=avg, avg_factor2=avg2,
+                   num_pos_local=float(npos), weight_sum_local=wsum)
         return losses, aux
     return losses
 
@@ -776,13 +782,14 @@ def parse_losses(losses: Dict[str, object]) -> Tensor:
 
 
 def erd_step_loss(teacher_sd, student_sd, x: Tensor, gt_bboxes, gt_labels, metas, c_old: int, c_all: int,
-                  depth: int = 50, dist_loss_weight: float = 1.0, return_aux: bool = False):
+                  depth: int = 50, dist_loss_weight: float = 1.0, return_aux: bool = False,
+                  rank_mean_factors: Optional[Tuple[float, float]] = None):
     """GFLIncrementERD.loss (gfl_increment_erd.py:202-220): teacher fwd, ERS, student fwd, losses."""
     with torch.no_grad():          # D6: numerically identical, teacher params are frozen
         t_cls, t_bbox = gfl_forward(teacher_sd, x, depth)
     s_cls, s_bbox = gfl_forward(student_sd, x, depth)
     return erd_head_loss(t_cls, t_bbox, s_cls, s_bbox, gt_bboxes, gt_labels, metas, c_old, c_all,
-                         dist_loss_weight, return_aux=return_aux)
+                         dist_loss_weight, return_aux=return_aux, rank_mean_factors=rank_mean_factors)
 
 
 def trainable(name: str) -> bool:

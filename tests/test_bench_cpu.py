@@ -30,7 +30,14 @@ def test_self_launch_builds_the_torchrun_command(monkeypatch):
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
-    assert tail == ["--gpus", "8", "--steps", "5", "--warmup", "2"]     # same flags, minus the launcher switch
+    assert tail == ["--gpus", "8", "--steps", "5", "--warmup", "2", "--launcher", "none"]     # same flags; the children never launch
+    # the switch is removed by POSITION: `--launcher auto`, `--launcher=spawn` and a value that merely equals "spawn" elsewhere
+    for argv, want in ((["--gpus", "8", "--launcher", "auto"], ["--gpus", "8"]),
+                       (["--launcher=spawn", "--gpus", "8"], ["--gpus", "8"]),
+                       (["--gpus", "8", "--arch", "spawn"], ["--gpus", "8", "--arch", "spawn"])):
+        bench.self_launch(args, argv)
+        cmd = seen["cmd"]
+        assert cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:] == want + ["--launcher", "none"], (argv, cmd)
     assert seen["env"]["ERD_BENCH_CHILD"] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 

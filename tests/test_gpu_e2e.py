@@ -208,24 +208,37 @@ def test_trainer_three_steps_follow_oracle_sgd_trajectory():
     _, _, d_eps = oracle_run(1e-6)
     den = sum(float(d_ref[k].pow(2).sum()) for k in names)
     self_err = (sum(float((d_eps[k] - d_ref[k]).pow(2).sum()) for k in names) / den) ** 0.5
-    got = []
-    for it in range(3):
-        x, boxes, labels, metas = batches[it % 2]
-        got.append(float(tr.train_step(x.cuda(), make_samples(boxes, labels, metas))["loss"]))
-    tr.flush()
-    torch.cuda.synchronize()
-    assert np.allclose(got, ref_loss, rtol=2e-3), (got, ref_loss)
-    params = dict(model.named_parameters())
-    num = sum(float(((params[k].detach().cpu() - ssd[k]).double() - d_ref[k]).pow(2).sum()) for k in names)
-    err = (num / den) ** 0.5
-    # Observed: 1.6e-2 with the direct launches on the native fp32 MFMA, 5.2e-2 in the three-limb form (which is the CLOSER
-    # of the two to fp64 kernel by kernel, test_gpu_f32x3.py) and 5e-2 when the student's frozen trunk ran on the Winograd
-    # kernels -- against `self_err`, the displacement error of the oracle's own trajectory from weights perturbed by 1e-6.
-    # The per-step losses above are the tight check (2e-3); this one catches a wrong lr / momentum / weight decay (a factor
-    # of two in any of them reads > 0.3 here).
-    print("3-step displacement rel L2 err: %.2e (the oracle's own, from weights x (1 + 1e-6 noise): %.2e); losses %s vs %s"
-          % (err, self_err, got, ref_loss))
-    assert den > 0 and err < max(3e-2, 3.0 * self_err) and err < 0.15, (err, self_err)
+    # Both fp32 forms of the direct launches, each with its OWN named bound: "f32" (every launch on the fp32 matrix
+    # cores) keeps the original 3e-2; "f32x3" (three-limb products, the default) is held to the larger of 3e-2 and three times
+    # `self_err`, the displacement error of the oracle's own trajectory from weights perturbed by 1e-6 -- at 123x153 a handful
+    # of ReLU / ATSS decisions sit on their thresholds and which implementation owns a flip is chance (observed in round 3 with
+    # truncating limbs: 1.6e-2 native, 5.2e-2 three-limb; the full-size, 48-seed statistics are profiles/r04_parity_seeds.json).
+    # The per-step losses are the tight check (2e-3); the displacement catches a wrong lr / momentum / weight decay (a factor of
+    # two in any of them reads > 0.3 here).
+    from erd_amd import kernels as K
+    errs = {}
+    for mode in ("f32", K.DEFAULT_COMPUTE):
+        K.set_compute(mode)
+        try:
+            model = build_erd(tsd, ssd)
+            tr = ERDTrainer(model, lr=0.02, momentum=0.9, weight_decay=1e-4, batch_size_per_gpu=2, auto_scale_lr=False,
+                            warmup_iters=3, warmup_start_factor=0.5)
+            got = []
+            for it in range(3):
+                x, boxes, labels, metas = batches[it % 2]
+                got.append(float(tr.train_step(x.cuda(), make_samples(boxes, labels, metas))["loss"]))
+            tr.flush()
+            torch.cuda.synchronize()
+        finally:
+            K.set_compute(K.DEFAULT_COMPUTE)
+        assert np.allclose(got, ref_loss, rtol=2e-3), (mode, got, ref_loss)
+        params = dict(model.named_parameters())
+        num = sum(float(((params[k].detach().cpu() - ssd[k]).double() - d_ref[k]).pow(2).sum()) for k in names)
+        errs[mode] = err = (num / den) ** 0.5
+        print("%s: 3-step displacement rel L2 err: %.2e (the oracle's own, from weights x (1 + 1e-6 noise): %.2e); losses %s vs %s"
+              % (mode, err, self_err, got, ref_loss))
+        bound = 3e-2 if mode == "f32" else min(max(3e-2, 3.0 * self_err), 0.15)
+        assert den > 0 and err < bound, (mode, err, bound, self_err)
     # frozen parts did not move; the teacher is untouched
     for k, v in ssd.items():
         if k not in names and v.dtype == torch.float32:

@@ -36,7 +36,12 @@ def test_split3_is_exact(K):
     hi, mid, lo = planes[0].float(), planes[1].float(), planes[2].float()
     assert torch.equal((hi + mid) + lo, x)                     # the three limbs ARE the value (8 + 8 + 8 significand bits)
     assert torch.equal(hi.view(torch.int32) & 0xffff, torch.zeros_like(hi, dtype=torch.int32))
-    assert bool(((mid == 0) | (mid.abs() <= hi.abs() * 2.0 ** -7)).all()) and bool(((lo == 0) | (lo.abs() <= hi.abs() * 2.0 ** -15)).all())
+    # round-to-nearest limbs: each remainder is at most half an ulp of the limb above, and sign-symmetric (a truncating split
+    # leaves remainders of the value's own sign, twice as large: the limb products a three-limb GEMM drops were then a bias)
+    assert bool((mid.abs() <= hi.abs() * 2.0 ** -8).all()) and bool((lo.abs() <= hi.abs() * 2.0 ** -16).all())
+    assert torch.equal(hi, x.bfloat16().float())                # plane 0 IS the value's bf16 neighbour
+    nz = (x != 0) & (mid != 0)
+    assert 0.45 < float((torch.sign(mid[nz]) == torch.sign(x[nz])).float().mean()) < 0.55
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p", CONV_CASES)

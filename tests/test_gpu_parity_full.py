@@ -69,8 +69,11 @@ def test_ers_index_sets_over_32_full_size_images(nets):
                         assert m < 1e-5, (wino, mode, b0 + i, a, m)
     print("ERS sets vs the CPU oracle over %d full-size images, images (anchors) that differ: %s"
           % (nimg, ", ".join("%s teacher / %s: %d (%d)" % ("Winograd" if w else "direct", m, v[0], v[1]) for (w, m), v in stats.items())))
+    # north_star: "ERS index masks bit-exact".  The DEFAULT configuration (Winograd teacher, three-limb direct launches) must match
+    # the oracle on every one of the 32 images (measured: 0 differing in all four configurations since round 2); the three A/B
+    # configurations may each own at most one image with a single anchor ON the threshold (checked above: margin < 1e-5)
+    assert stats[(True, K.DEFAULT_COMPUTE)] == [0, 0], stats
     assert all(v[0] <= 1 for v in stats.values()), stats
-    assert stats[(True, "f32x3")][0] <= stats[(False, "f32")][0] + 1, stats      # the default teacher is not worse than the all-native-direct one
 
 
 def test_benched_batch_of_four_losses_and_ers_vs_oracle(nets):
@@ -99,29 +102,37 @@ SEEDS_FP64 = (7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)
 
 def test_full_size_gradients_anchored_to_fp64(nets):
     """Twelve full-size steps (seeds 7-18), each evaluated three times: the oracle in fp64 (the truth), the oracle in fp32 (the
-    reference's own arithmetic) and the HIP path.  Relative L2 distance to fp64 as median over the 175 gradient tensors /
-    all elements (= the whole gradient) / worst tensor, measured in round 2:
-        seed   cpu fp32                      hip
-          7    4.7e-4  4.1e-4  2.5e-3        6.8e-4  4.2e-4  2.3e-3
-          8    3.4e-3  1.8e-3  4.8e-3        5.7e-4  5.9e-4  2.3e-3
-          9    4.9e-4  5.1e-4  3.1e-3        1.1e-3  7.8e-4  3.2e-3
-         10    8.7e-4  5.4e-4  1.7e-3        9.0e-4  5.9e-4  1.8e-3
-      11-18    whole gradient 7.0 3.2 3.8 5.9 0.6 3.4 5.9 3.9 e-4 | 8.9 3.9 5.0 6.6 1.0 4.2 3.7 5.3 e-4
+    reference's own arithmetic) and the HIP path in both fp32 forms of its direct launches.  Relative L2 distance to fp64 as
+    median over the 175 gradient tensors / all elements (= the whole gradient) / worst tensor.
+
     A ReLU whose pre-activation is ~1e-7 takes one side in one fp32 summation order and the other side in another; ONE such
     flip moves every gradient tensor upstream by ~1e-3 and a small-norm one (a BN bias gradient: a sum over a map with heavy
-    cancellation) by up to 1e-2.  Which implementation owns a flip is chance: over these twelve seeds the whole gradient is
-    more than 1e-3 from fp64 on 1 seed for the fp32 CPU reference (seed 8: 1.76e-3), on 0 seeds for the HIP path with the
-    direct launches on the native fp32 MFMA (worst 8.9e-4) and on 2 seeds in the default three-limb form (seed 8: 1.74e-3 --
-    the reference's own flip, median 3.36e-3 for both -- and seed 12: 1.13e-3), while kernel by kernel the three-limb form is
-    the CLOSER of the two to fp64 (test_gpu_f32x3.py).  Per-seed comparisons between implementations therefore say nothing;
-    the statements are over ALL twelve seeds, for both fp32 forms of the direct launches:
-      A. every seed: losses within 1e-3 of the fp32 reference and of fp64; the WHOLE gradient within 2.5e-3 of fp64 (a flip or
-         two -- no implementation, the reference included, is within 1e-3 on every seed) and within 1e-3 on the median seed
-         (north_star's bar, against the exact gradients);
-      B. means over the seeds: this implementation's whole-gradient distance, per-tensor median and worst tensor are each at
-         most 1.25 x the reference's own (it is as close to the truth as the reference's arithmetic is);
-      C. worst single tensor <= 5e-3 on every seed (a systematic error in one layer -- the Winograd double store of round 2
-         read 1.1e-2 here -- shows up in this column first)."""
+    cancellation) by up to 1e-2.  Which implementation owns a flip on a given seed is chance, and the distribution is
+    heavy-tailed -- twelve seeds cannot tell chance from a 20 % shift.  The statistics that CAN are in
+    profiles/r04_parity_seeds.json (tools/parity_seeds.py: 48 seeds, 7-54, same evaluation; tests/test_parity_seeds_profile.py
+    asserts what this docstring quotes from it).  Whole-gradient distance to fp64 over the 48 seeds:
+                                   mean +- s.e.m.        median     seeds > 1e-3   worst seed
+        cpu fp32 (the reference)   9.6e-4 +- 1.7e-4      5.8e-4     10             6.3e-3
+        hip "f32" (fp32 MFMA)      6.1e-4 +- 0.7e-4      4.9e-4      6             2.8e-3
+        hip "f32x3" (default)      7.1e-4 +- 0.9e-4      4.4e-4     10             2.9e-3
+        (round 3's truncating limbs 8.6e-4 +- 1.3e-4     6.3e-4     11             4.6e-3: the round-to-nearest split is the closer)
+    Both HIP forms are closer to fp64 than the reference's own arithmetic; between the two the paired difference over the 48
+    seeds is +1.0e-4 +- 0.7e-4 (1.3 standard errors; the median favours the three-limb form): not distinguishable.  On random
+    12-seed subsets of those 48 the ratio of the two forms' means ranges from 0.6 to 2.4 (90th percentile 1.48), and the
+    three-limb form has more than one seed above 1e-3 beyond the reference's count on 11 % of the subsets -- so the assertions
+    here, on the PINNED seeds 7-18, are (values measured on these seeds in brackets):
+      A. every seed, both forms: losses within 1e-3 of the fp32 reference and of fp64.
+         "f32": the whole gradient within 1e-3 of fp64 on EVERY seed -- the original bound [worst 8.9e-4].
+         "f32x3": its own, named bound: the number of seeds above 1e-3 at most the reference's own count + 1 [1 vs 1], no seed
+         above 2.5e-3 [worst 1.2e-3], the median seed within 1e-3;
+      B. means over the seeds (whole gradient, per-tensor median, worst tensor) at most 1.25 x the reference's own [f32x3:
+         1.14 / 1.00 / 1.20; f32: 0.95 / 0.93 / 1.03], and the three-limb mean at most 1.5 x the native form's [1.21; 1.5 is the
+         90th percentile of that ratio over 12-seed subsets of the 48 -- the bound a 12-seed sample supports; "<= 1.1" is asserted
+         where it can be, on the 48-seed medians in test_parity_seeds_profile.py];
+      C. worst single tensor <= 6e-3 on every pinned seed [f32x3 worst 4.98e-3 on seed 13, f32 3.5e-3; the reference's own
+         4.8e-3] -- a systematic error in one layer (the Winograd double store of round 2 read 1.1e-2 on three seeds in a row)
+         shows up in this column first.  Over the 48 seeds single flips put it at up to 8.3e-3 for both HIP forms and 1.3e-2
+         for the reference, so this is a pinned-seed tripwire, not a statistical statement; B's worst-tensor MEAN is the latter."""
     from erd_amd import parse_losses
     tsd, ssd, _ = nets
     names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
@@ -184,9 +195,16 @@ def test_full_size_gradients_anchored_to_fp64(nets):
               % ((len(SEEDS_FP64),) + tuple(cpu.mean(0)) + (mode,) + tuple(hip.mean(0))))
         print("seeds with the whole gradient more than 1e-3 from fp64: cpu fp32 %d, hip %s %d (of %d)"
               % (int((cpu[:, 1] > 1e-3).sum()), mode, int((hip[:, 1] > 1e-3).sum()), len(SEEDS_FP64)))
-        assert (hip[:, 1] <= 2.5e-3).all() and float(np.median(hip[:, 1])) <= 1e-3, (mode, hip[:, 1])    # A
+        above, above_cpu = int((hip[:, 1] > 1e-3).sum()), int((cpu[:, 1] > 1e-3).sum())
+        if mode == "f32":                                                                            # A, the original bound
+            assert (hip[:, 1] <= 1e-3).all(), (mode, hip[:, 1])
+        else:                                                                                        # A, the three-limb form's own
+            assert above <= above_cpu + 1 and (hip[:, 1] <= 2.5e-3).all() and float(np.median(hip[:, 1])) <= 1e-3, (mode, hip[:, 1], cpu[:, 1])
         assert (hip.mean(0) <= 1.25 * cpu.mean(0)).all(), (mode, hip.mean(0), cpu.mean(0))          # B
-        assert (hip[:, 2] <= 5e-3).all(), (mode, hip[:, 2])                                         # C
+        assert (hip[:, 2] <= 6e-3).all(), (mode, hip[:, 2])                                         # C
+    x3, f32 = np.array(hip_rows["f32x3"]), np.array(hip_rows["f32"])
+    print("three-limb / native means over the 12 seeds (median, whole gradient, worst tensor): %s" % (x3.mean(0) / f32.mean(0),))
+    assert x3[:, 1].mean() <= 1.5 * f32[:, 1].mean(), (x3[:, 1].mean(), f32[:, 1].mean())             # B, between the two forms
 
 
 def test_benched_trainer_configuration_follows_the_oracle_trajectory_at_full_size(nets, monkeypatch):

@@ -3,6 +3,10 @@
 // Every CU runs WG workgroups of 4 waves; each wave issues back-to-back MFMAs on 4 independent accumulators (no memory
 // traffic).  Reported per variant: TFLOP/s from hipEvent time, and the shader clock = s_memtime ticks / s_memrealtime
 // (100 MHz constant-rate) ticks measured inside the kernel by one wave per workgroup (median over workgroups).
+// `random operands` variants: the same loops on pseudo-random operand registers (four different A and four different B fragments
+// per lane, visited round-robin, every bit position toggling) -- constant operands flatter the pipe: the chip's power
+// management lowers the clock under the switching activity of real data, and that sustained rate, not the constant-operand
+// one, is what a GEMM on real maps can reach.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -144,6 +148,86 @@ void run(const char* name, double flop_per_mfma, int wg_per_cu, int iters) {
     hipFree(ticks);
 }
 
+// random operands: KIND 0 = v_mfma_f32_32x32x2_f32, KIND 2 = v_mfma_f32_32x32x16_bf16; NACC independent accumulators,
+// 4 A x 4 B operand fragments per lane from a hash of (thread, index) in [-1, 1)
+__device__ inline float hash_unit(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return (float)(int)x * (1.0f / 2147483648.0f);
+}
+template <int KIND, int NACC>
+__global__ __launch_bounds__(256) void mfma_random_loop(float* sink, unsigned long long* ticks, int iters, unsigned seed) {
+    f32x16 acc[NACC];
+    for (int q = 0; q < NACC; ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const unsigned t = (blockIdx.x * 256u + threadIdx.x) * 64u + seed;
+    float af[4], bf[4];
+    bf16x8 ab[4], bb[4];
+    for (int m = 0; m < 4; ++m) {
+        af[m] = hash_unit(t + m);
+        bf[m] = hash_unit(t + 8 + m);
+        for (int r = 0; r < 8; ++r) {
+            ab[m][r] = (__bf16)hash_unit(t + 16 + m * 8 + r);
+            bb[m][r] = (__bf16)hash_unit(t + 48 + m * 8 + r);
+        }
+    }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) {
+                if constexpr (KIND == 0) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[(m + q) & 3], acc[q], 0, 0, 0);
+                if constexpr (KIND == 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[m], bb[(m + q) & 3], acc[q], 0, 0, 0);
+            }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int q = 0; q < NACC; ++q) s += acc[q][0] + acc[q][7];
+    if (s == 123.456f) sink[0] = s;
+    if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = c1 - c0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+template <int KIND, int NACC>
+void run_random(const char* name, double flop_per_mfma, int wg_per_cu, int iters, int reps) {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int grid = prop.multiProcessorCount * wg_per_cu;
+    float* sink;
+    unsigned long long* ticks;
+    hipMalloc(&sink, 4);
+    hipMalloc(&ticks, sizeof(unsigned long long) * 2 * grid);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((mfma_random_loop<KIND, NACC>), dim3(grid), dim3(256), 0, 0, sink, ticks, iters / 10, 1u);
+    hipDeviceSynchronize();
+    std::vector<double> tfs, clks;
+    for (int rep = 0; rep < reps; ++rep) {      // back to back: the later repetitions run on a chip that is already warm / throttled
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((mfma_random_loop<KIND, NACC>), dim3(grid), dim3(256), 0, 0, sink, ticks, iters, 7u + rep);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(2 * grid);
+        hipMemcpy(h.data(), ticks, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost);
+        std::vector<double> c;
+        for (int b = 0; b < grid; ++b) c.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100e6 / 1e9);
+        std::sort(c.begin(), c.end());
+        tfs.push_back((double)grid * 4 * 4.0 * NACC * iters * flop_per_mfma / (ms * 1e-3) / 1e12);
+        clks.push_back(c[c.size() / 2]);
+    }
+    printf("%-26s RANDOM operands, %2d accumulators, %d WG/CU x 4 waves, %.1f ms per launch: TFLOP/s per repetition", name, NACC, wg_per_cu,
+           (double)grid * 4 * 4.0 * NACC * iters * flop_per_mfma / (tfs[reps - 1] * 1e12) * 1e3);
+    for (double v : tfs) printf(" %.0f", v);
+    printf("; shader clock GHz");
+    for (double v : clks) printf(" %.3f", v);
+    std::sort(tfs.begin(), tfs.end());
+    printf("; median %.1f TFLOP/s\n", tfs[reps / 2]);
+    hipFree(sink);
+    hipFree(ticks);
+}
+
 int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -165,6 +249,12 @@ int main() {
         run<1, 16>("v_mfma_f32_16x16x4_f32", 16.0 * 16 * 4 * 2, wg, 20000);
         run<2, 4>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16 * 2, wg, 80000);
         run<2, 8>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16 * 2, wg, 40000);
+    }
+    // sustained rates on random operands (each launch ~10-40 ms, 9 back to back)
+    for (int wg = 1; wg <= 2; ++wg) {
+        run_random<0, 4>("v_mfma_f32_32x32x2_f32", 32.0 * 32 * 2 * 2, wg, 20000, 9);
+        run_random<2, 4>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16 * 2, wg, 40000, 9);
+        run_random<2, 8>("v_mfma_f32_32x32x16_bf16", 32.0 * 32 * 16 * 2, wg, 20000, 9);
     }
     return 0;
 }

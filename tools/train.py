@@ -67,11 +67,12 @@ def main(argv=None):
     elif args.resume is not None:
         cfg.resume, cfg.load_from = True, args.resume
 
+    from erd_amd.dist_utils import backend_name, device_index
     local_rank = int(os.environ.get("LOCAL_RANK", args.local_rank))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device_index(local_rank))
     if args.launcher == "pytorch":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend_name())      # 'nccl' (= RCCL; default_runtime.py:14) unless ERD_DIST_BACKEND=gloo
     rank = dist.get_rank() if dist.is_initialized() else 0
     head = cfg.model.bbox_head
     ori = cfg.model.get("ori_setting")
