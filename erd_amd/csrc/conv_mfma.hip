@@ -460,6 +460,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
                 const bf16x8 al = limb(r2, pl);
 #endif
                 ERD_X3(al, 0)
+#ifdef ERD_X3_NINE        // accuracy probe (tools/build_probe.sh): the three limb products the production form drops (weight 2^-24 and below)
+                ERD_X3(am, 2)
+                ERD_X3(al, 1)
+                ERD_X3(al, 2)
+#endif
                 if (kk == 0) {
 #ifndef ERD_X3_NOBREAD
                     read_b(1, 0);
@@ -1848,6 +1853,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     //  the fp32 activation chunks are 4 wide and zero-filled past Cin -- and 16-byte buffer loads need dword alignment only)
     // short K loops (K = taps x Cin below ERD_X3_MIN_K) gain nothing from a faster loop: they are set-up / epilogue bound and
     // want the fp32 kernel's four small workgroups per CU (the three-limb kernel holds 80 KB of LDS: two per CU)
+    // thin 1x1 layers (Cin <= 128): activations stationary in registers, weights streamed (conv_thin.hip; bit-identical results)
+    if (erd::conv_thin_x3_ok(d)) return erd::conv_thin_x3(d, st);
     static const int x3_min_k = getenv("ERD_X3_MIN_K") ? atoi(getenv("ERD_X3_MIN_K")) : 0;
     if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0 && (d->Cout % 4 == 0 || !d->w) && (d->ntaps * d->Cin >= x3_min_k || !d->w)) {
         ERD_REQUIRE(d->Cout % 4 == 0, "conv: the three-limb kernel stores 16-byte rows (Cout %% 4 == 0); pass `w` for Cout=%d", d->Cout);

@@ -1,0 +1,329 @@
+// Thin-K 1x1 convolutions in the three-limb form ("f32x3") with the ACTIVATIONS STATIONARY in registers.
+//
+// Why a second kernel.  The stream-K implicit GEMM (conv_mfma.hip) computes one 128 x 128 output tile per workgroup pass:
+// tile set-up (row table, first loads), a K loop, an epilogue -- serial phases, two workgroups per CU.  On the 1x1 layers with
+// K = Cin <= 128 the K loop is 2-4 slices: of a tile's 31.5 k cycles (128 -> 512 on 100 x 168, round-3 phase trace) 15.0 k are
+// K loop and 16.5 k are set-up and epilogue during which that workgroup's matrix pipe share idles; the activation tile is
+// re-read and re-split into limbs once per 128 output channels (Cout / 128 times), and every launch ends in a ragged
+// dispatch round.  Measured 103 us against ~21 us of matrix work / ~21 us of HBM traffic.
+//
+// This kernel turns the loop nest around for K <= 128:
+//   * a workgroup (4 waves, wave w owns pixel rows 32 w .. 32 w + 31 of a 128-row tile) loads its activation rows ONCE, splits
+//     them into bf16 limbs ONCE (erd::limbs3_pair) and keeps all K / 16 MFMA A-fragments of all three limbs in registers
+//     (K = 128: 96 VGPRs);
+//   * it then walks the output channels in blocks of 32: the block's three weight planes (3 x 32 x K bf16 = 24 KB at K = 128)
+//     arrive through a double-buffered LDS ring, one barrier per block, 6 x K / 16 MFMAs per wave and block -- the SAME MFMA
+//     sequence per accumulator as the stream-K kernel (k16 steps ascending; per step hi x lo, hi x mid, hi x hi, mid x mid,
+//     mid x hi, lo x hi), so results are bit-identical to it;
+//   * a block's epilogue (accumulators -> the wave's private LDS block -> 128-byte row segments with scale / shift / residual /
+//     ReLU / mask / column sums, 16-byte stores) is issued by the wave right behind the block's MFMAs and drains while the next
+//     block's MFMAs run: no tile-level phases;
+//   * work = (pixel tile, cout block) pairs in tile-major order, cut into G equal contiguous ranges for a persistent grid of
+//     two workgroups per CU: no ragged round, and no fix-up (an output block is owned by one workgroup).
+// Bytes per 128 rows x N couts: the activation rows once (K x 512 B) + the weight planes once (6 N K B) instead of N / 128
+// times both.  LDS 68 KB -> two workgroups per CU.
+//
+// Serves: one tap (1x1), Cin in {64, 128}, Cout % 32 == 0, fp32 maps, w_x3 planes; forward (stride 1 or 2) and the
+// input-gradient forms (res / mask / colsum / alpha / accumulate) through the same descriptor as erd_conv_igemm, which
+// dispatches here (ERD_THIN=0: off, A/B aid).
+#include <algorithm>
+#include "erd_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x7fffffffu;      // past num_records of any buffer we build: the load returns zeros
+
+__device__ __forceinline__ u4v buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+struct TRow {
+    int in_off;    // element offset of the row's input pixel (channel 0); -1: outside the map / past the end -> zeros
+    int out_off;   // element offset of the row's output pixel; -1: row past the end
+};
+
+constexpr int SLD = 36;                    // floats per staged row (32 couts + 4: rows land on different banks)
+
+template <int KS>                          // K / 16: MFMA k-steps of the whole reduction (4: Cin = 64, 8: Cin = 128)
+__global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_desc p, const int mtiles, const int nb, const int xcd_order) {
+    constexpr int K = KS * 16;
+    constexpr int CPR = K / 8;                         // 16-byte chunks (8 bf16) per weight row
+    constexpr int UNIT_B = 3 * 32 * K * 2;             // one cout block's three planes
+    constexpr int NQ = UNIT_B / 16 / 256;              // 16-byte loads per thread and block (6 at K = 128, 3 at K = 64)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                                     // [2][UNIT_B]
+    float* stage = reinterpret_cast<float*>(smem + 2 * UNIT_B);            // [4 waves][32][SLD]
+    TRow* rows = reinterpret_cast<TRow*>(smem + 2 * UNIT_B + 4 * 32 * SLD * 4);   // [128]
+    float* red = reinterpret_cast<float*>(rows + 128);                    // [2][4 waves][32]: column sums on their way to one atomic per channel
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;
+    int wg = blockIdx.x;
+    if (xcd_order) {       // workgroup b runs on XCD b % 8: a contiguous chunk of the work list per XCD (conv_igemm_kernel)
+        const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long T = (long long)mtiles * nb;
+    const long long t_begin = T * wg / G, t_end = T * (wg + 1) / G;
+    if (t_begin >= t_end) return;
+
+    const unsigned plane_b = (unsigned)((long long)p.Cout * p.wrow * 2);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_x3), 0, (int)(3u * plane_b), 0x00020000);
+    // this thread's share of a block's weight planes: (plane, row, chunk) of load q, the same for every block
+    unsigned w_off[NQ];
+    int l_off[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = q * 256 + tid;
+        const int pl = idx / (32 * CPR), rem = idx - pl * 32 * CPR, row = rem / CPR, ch = rem - row * CPR;
+        w_off[q] = (unsigned)pl * plane_b + (unsigned)(row * p.wrow + p.wk[0] + ch * 8) * 2u;
+        const int sw = CPR == 16 ? (ch ^ (row & 15)) : (ch ^ ((row >> 1) & 7));     // conflict-free 16-lane fragment reads
+        l_off[q] = ((pl * 32 + row) * CPR + sw) * 16;
+    }
+    u4v rb[NQ];
+    auto load_unit = [&](long long t) {
+        const unsigned cb_off = (unsigned)((int)(t % nb) * 32 * p.wrow) * 2u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rb[q] = buf_load16(rs_w, w_off[q] + cb_off);
+    };
+    auto store_unit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<u4v*>(ring + buf * UNIT_B + l_off[q]) = rb[q];
+    };
+
+    u4v ah[KS], am[KS], al[KS];            // the wave's activation rows: limb fragments of every k16 step
+    int pend_cb = -1;                      // cout block whose column sums wait in `red` for their atomics
+    float* const cs_row = p.colsum ? p.colsum + (p.colsum_copies > 1 ? (int64_t)(blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) : nullptr;
+    const float alpha_dummy = 1.f;
+
+    load_unit(t_begin);
+    int it = 0;                            // blocks done by this workgroup: parity of the LDS ring / of `red`
+#pragma unroll 1
+    for (int mt = (int)(t_begin / nb); (long long)mt * nb < t_end; ++mt) {
+        // ---- a pixel tile: row table, then this wave's activation rows -> limb fragments ------------------------------------
+        int seg_i = 0, mt_in_seg = mt;
+        {
+#pragma unroll 1
+            for (; seg_i < p.nseg - 1; ++seg_i) {
+                const int M = p.seg[seg_i].N * p.seg[seg_i].GH * p.seg[seg_i].GW;
+                const int tiles = (M + 127) / 128;
+                if (mt_in_seg < tiles) break;
+                mt_in_seg -= tiles;
+            }
+            const erd_conv_seg& sg = p.seg[seg_i];
+            __syncthreads();               // the previous tile's epilogues are done with the row table
+            if (tid < 128) {
+                const int GHW = sg.GH * sg.GW, M = sg.N * GHW, m = mt_in_seg * 128 + tid;
+                TRow ri;
+                ri.in_off = -1;
+                ri.out_off = -1;
+                if (m < M) {
+                    const int n = m / GHW, rem = m - n * GHW, a = rem / sg.GW, b = rem - a * sg.GW;
+                    const int ih = a * p.in_stride + p.dy[0], iw = b * p.in_stride + p.dx[0];
+                    if ((unsigned)ih < (unsigned)sg.IH && (unsigned)iw < (unsigned)sg.IW)
+                        ri.in_off = (int)(n * sg.in_nstride) + (ih * sg.IW + iw) * p.Cin;
+                    ri.out_off = (int)(n * sg.out_nstride) + ((a * p.out_stride + p.oy) * sg.OW + (b * p.out_stride + p.ox)) * p.Cout;
+                }
+                rows[tid] = ri;
+            }
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+            const int ibase = rows[wave * 32 + li].in_off;
+            // lane (li, h) holds channels 16 s + 8 h .. + 7 of pixel row li for every step s: two 16-byte loads per step
+            u4v xa[KS], xb[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const unsigned o = ibase < 0 ? OOB : (unsigned)(ibase + 16 * s + 8 * h) * 4u;
+                xa[s] = buf_load16(rs_in, o);
+                xb[s] = buf_load16(rs_in, ibase < 0 ? OOB : o + 16u);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {      // value pair e of the step: words (2 e, 2 e + 1) of the eight fp32 values
+                    const u4v& x = e < 2 ? xa[s] : xb[s];
+                    unsigned hi, mid, lo;
+                    erd::limbs3_pair(__uint_as_float(x[(e & 1) * 2]), __uint_as_float(x[(e & 1) * 2 + 1]), hi, mid, lo);
+                    ah[s][e] = hi; am[s][e] = mid; al[s][e] = lo;
+                }
+            }
+        }
+        const erd_conv_seg& sg = p.seg[seg_i];
+        const long long tile_t0 = (long long)mt * nb;
+        const int cb_begin = (int)(t_begin > tile_t0 ? t_begin - tile_t0 : 0), cb_end = (int)(t_end < tile_t0 + nb ? t_end - tile_t0 : nb);
+#pragma unroll 1
+        for (int cb = cb_begin; cb < cb_end; ++cb, ++it) {
+        const long long t = tile_t0 + cb;
+        const int buf = it & 1;
+        store_unit(buf);                   // this block's planes: registers -> LDS (the buffer was last read two blocks ago)
+        if (t + 1 < t_end) load_unit(t + 1);
+        __syncthreads();
+        // ---- column sums of the PREVIOUS block: four waves' partial rows -> one atomic per channel ------------------------
+        if (pend_cb >= 0 && tid < 32) {
+            const float* rp = red + ((it - 1) & 1) * 128;
+            atomicAdd(cs_row + pend_cb * 32 + tid, (rp[tid] + rp[32 + tid]) + (rp[64 + tid] + rp[96 + tid]));
+        }
+        // ---- residual / mask rows of this block are requested before its MFMAs ---------------------------------------------
+        const int c4 = lane & 7, rsub = lane >> 3;
+        const int co = cb * 32 + c4 * 4;
+        const float* res = sg.res;
+        const float* msk = sg.mask;
+        const float* pf_src = res ? res : msk;
+        int oo[4];
+        float4 pf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            oo[q] = rows[wave * 32 + q * 8 + rsub].out_off;
+            if (pf_src && oo[q] >= 0) pf[q] = *reinterpret_cast<const float4*>(pf_src + oo[q] + co);
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
+        const float alpha = *(sg.alpha ? sg.alpha : &alpha_dummy);
+        // ---- the block's products: 6 MFMAs per k16 step, the stream-K kernel's order -----------------------------------------
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const char* Bb = ring + buf * UNIT_B;
+        // (weight fragments are read ONE step ahead by hand and the schedule is pinned per step: left alone the compiler hoists
+        //  every step's LDS reads to the top of the block -- 96 more live registers -- and spills the limb fragments)
+        bf16x8 wf[2][3];
+        auto read_w = [&](int s, int slot) {
+            const int ch = 2 * s + h;
+            const int sw = CPR == 16 ? (ch ^ (li & 15)) : (ch ^ ((li >> 1) & 7));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[slot][pl] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 32 + li) * CPR + sw) * 16);
+        };
+        read_w(0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) read_w(s + 1, (s + 1) & 1);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[s]), a1 = __builtin_bit_cast(bf16x8, am[s]), a2 = __builtin_bit_cast(bf16x8, al[s]);
+            const bf16x8 w0 = wf[s & 1][0], w1 = wf[s & 1][1], w2 = wf[s & 1][2];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc, 0, 0, 0);
+#ifdef ERD_X3_NINE        // accuracy probe, as in conv_igemm_kernel: the three dropped limb products
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w2, acc, 0, 0, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue of the block, wave-private: accumulators -> LDS -> 128-byte row segments ------------------------------
+        float* wst = stage + wave * 32 * SLD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wst[((r & 3) + 8 * (r >> 2) + 4 * h) * SLD + li] = acc[r];
+        __builtin_amdgcn_wave_barrier();               // (LDS operations of one wave execute in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (oo[q] < 0) continue;
+            float4 v = *reinterpret_cast<const float4*>(wst + (q * 8 + rsub) * SLD + c4 * 4);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (sg.alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
+            if (res) { const float4 rv = pf[q]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (msk) {
+                const float4 mv = res ? *reinterpret_cast<const float4*>(msk + oo[q] + co) : pf[q];
+                v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(sg.out + oo[q] + co) = v;
+            csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+        }
+        if (cs_row) {      // lanes that share a column group (lane bits 3..5), then the wave's row of `red`
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+            }
+            if (lane < 8) *reinterpret_cast<float4*>(red + (it & 1) * 128 + wave * 32 + lane * 4) = csum;
+            pend_cb = cb;
+        }
+        __builtin_amdgcn_wave_barrier();               // the staging block is re-used by the next block's accumulators
+        }
+    }
+    if (pend_cb >= 0) {
+        __syncthreads();
+        if (tid < 32) {
+            const float* rp = red + ((it - 1) & 1) * 128;
+            atomicAdd(cs_row + pend_cb * 32 + tid, (rp[tid] + rp[32 + tid]) + (rp[64 + tid] + rp[96 + tid]));
+        }
+    }
+}
+
+int num_cus_thin() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int KS>
+int launch_thin(const erd_conv_desc* d, hipStream_t st) {
+    constexpr int K = KS * 16;
+    int mtiles = 0;
+    for (int s = 0; s < d->nseg; ++s) mtiles += (int)(((int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW + 127) / 128);
+    const int nb = d->Cout / 32;
+    if (mtiles == 0) return 0;
+    const size_t lds = (size_t)2 * (3 * 32 * K * 2) + 4 * 32 * SLD * 4 + 128 * sizeof(TRow) + 2 * 4 * 32 * 4;
+    auto kern = conv_thin_x3_kernel<KS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    static const int xcd = getenv("ERD_XCD") ? atoi(getenv("ERD_XCD")) : 1;
+    const long long T = (long long)mtiles * nb;
+    // two workgroups per CU at K = 128 (226 registers, 68 KB of LDS); three at K = 64 (154 registers, 45 KB).  ERD_THIN_WGS: A/B aid
+    static const int wgs_env = getenv("ERD_THIN_WGS") ? atoi(getenv("ERD_THIN_WGS")) : 0;
+    const int per_cu = wgs_env > 0 ? wgs_env : (KS == 4 ? 3 : 2);
+    const int G = (int)std::min<long long>(T, (long long)per_cu * num_cus_thin());
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, *d, mtiles, nb, xcd ? 1 : 0);
+    return erd::check_launch("conv_thin_x3");
+}
+
+}  // namespace
+
+namespace erd {
+
+// does this launch fit the activation-stationary kernel?  (erd_conv_igemm asks before it picks a stream-K variant)
+static int g_thin_on = -1;      // -1: not decided yet (ERD_THIN, default on)
+
+int conv_thin_enable(int on) {
+    if (g_thin_on < 0) g_thin_on = getenv("ERD_THIN") ? atoi(getenv("ERD_THIN")) : 1;
+    const int prev = g_thin_on;
+    if (on >= 0) g_thin_on = on ? 1 : 0;
+    return prev;
+}
+
+bool conv_thin_x3_ok(const erd_conv_desc* d) {
+    const int on = conv_thin_enable(-1);
+    if (!on || !d->w_x3 || d->w_bf16 || d->in_bf16 || d->out_bf16 || d->ntaps != 1) return false;
+    if (!(d->Cin == 64 || d->Cin == 128) || d->Cout % 32 != 0 || d->wrow % 8 != 0 || d->wk[0] % 8 != 0) return false;
+    for (int s = 0; s < d->nseg; ++s)
+        if (d->seg[s].ntaps > 0) return false;
+    return true;
+}
+
+int conv_thin_x3(const erd_conv_desc* d, hipStream_t st) {
+    return d->Cin == 64 ? launch_thin<4>(d, st) : launch_thin<8>(d, st);
+}
+
+}  // namespace erd
+
+extern "C" int erd_conv_thin_enable(int on) { return erd::conv_thin_enable(on); }

@@ -864,8 +864,11 @@ extern "C" int erd_gn_relu_fwd(const void* c, void* y, const float* gamma, const
     const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
     hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
+#ifndef ERD_GN_NOSTATS      // timing probe (tools/build_probe.sh): the upper bound of what statistics fused into the producing
+                            // convolution's output stage could save -- the pass is simply not run (results are wrong)
     ERD_MAP(map_type, hipLaunchKernelGGL((gn_stats_kernel<256, 32, T>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st,
                                          (const T*)c, stats_ws, A, *lv, chs));
+#endif
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nst + 255) / 256), dim3(256), 0, st, stats_ws, mean_rstd, N, G, *lv,
                        C / G, eps);
     ERD_MAP(map_type, hipLaunchKernelGGL((gn_apply_kernel<256, 32, T>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st,

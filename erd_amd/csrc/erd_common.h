@@ -10,6 +10,10 @@ namespace erd {
 
 void set_error(const char* fmt, ...);
 
+// conv_thin.hip: the activation-stationary three-limb kernel for 1x1 convolutions with Cin <= 128 (erd_conv_igemm dispatches to it)
+bool conv_thin_x3_ok(const erd_conv_desc* d);
+int conv_thin_x3(const erd_conv_desc* d, hipStream_t st);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

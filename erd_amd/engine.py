@@ -44,7 +44,7 @@ def _storage_view(flat: Tensor, off: int, p: Tensor) -> Tensor:
 
 
 class FlatParams:
-    def __init__(self, named_params: Sequence, device, bucket_bytes: int = 32 << 20):
+    def __init__(self, named_params: Sequence, device, bucket_bytes: int = 32 << 20, tail_bytes: int = 4 << 20):
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         offs, total = [], 0
@@ -71,6 +71,18 @@ class FlatParams:
             if (end - start) * 4 >= bucket_bytes or i == len(self.params) - 1:
                 self.buckets.append((start, end, members))
                 start, members = end, []
+        # the LAST bucket's all-reduce is the only one nothing of the backward pass is left to hide: with the teacher of step
+        # t+1 running next to backward(t) it sits between backward(t) and forward(t+1) on the main stream.  Keep it short:
+        # the tail of the layout (the parameters whose gradients land last: the first trainable block) becomes its own
+        # bucket of at most `tail_bytes` (a 1.5 MB all-reduce instead of up to `bucket_bytes`)
+        if len(self.params) > 1 and self.buckets:
+            s0, e0, mem = self.buckets[-1]
+            cut = len(mem)
+            while cut > 1 and (e0 - offs[mem[cut - 1]]) * 4 <= tail_bytes:
+                cut -= 1
+            if cut < len(mem) and (e0 - offs[mem[cut]]) * 4 <= tail_bytes and (e0 - s0) * 4 > tail_bytes:
+                mid = offs[mem[cut]]
+                self.buckets[-1:] = [(s0, mid, mem[:cut]), (mid, e0, mem[cut:])]
         self.bucket_of = {}
         for b, (_, _, mem) in enumerate(self.buckets):
             for i in mem:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERD_ABI_VERSION 3
+#define ERD_ABI_VERSION 4
 #define ERD_MAX_SEG 5   /* FPN levels batched in one launch */
 #define ERD_MAX_TAPS 9
 
@@ -113,6 +113,12 @@ typedef struct {
  * and, run on dz with transformed weights, their convolution_backward (input grad). */
 int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream);
 size_t erd_conv_igemm_ws_bytes(int max_tiles);
+/* ABI v4.  erd_conv_igemm sends three-limb 1x1 launches with Cin in {64, 128} and Cout % 32 == 0 to an activation-stationary
+ * kernel (csrc/conv_thin.hip: the pixel rows' limb fragments stay in registers, the output channels stream past them in blocks
+ * of 32; the same MFMA sequence per accumulator as the stream-K kernel, i.e. bit-identical results).  on = 0 / 1 switches that
+ * dispatch for the process (A/B runs and the bit-identity test), on < 0 only queries; returns the previous setting.
+ * Default: on (environment ERD_THIN=0: off). */
+int erd_conv_thin_enable(int on);
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements */
 int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
 /* the three bf16 limbs of every value, each rounded to nearest even: dst[0][i] + dst[1][i] + dst[2][i] == src[i] exactly; dst = [3][n] bf16

@@ -100,10 +100,13 @@ def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path, H, W, bucket_
         back = [res[r]["reduce_mean"][it][1] for r in range(WORLD)]
         assert torch.equal(back[0], back[1])
         assert torch.equal(back[0], sum(s / WORLD for s in sent))                 # divide, then sum, in fp32: the reference's order
+        # (the second entry is a sum of sigmoid(student logit) over a few dozen positives: at step 0 both sides evaluate the same
+        #  weights; after an update the two trajectories' weights differ by their ~1e-3 gradient noise, and so do these logits)
+        tol = 2e-4 if it == 0 else 3e-3
         for r in range(WORLD):
             assert float(sent[r][0]) == local[r][0]                                # sum of max(num_pos, 1) over the rank's images: an integer
-            assert float(sent[r][1]) == pytest.approx(local[r][1], rel=2e-4)       # sum of the positives' quality scores (student logits)
-        assert float(back[0][0]) == float(fac[0]) and float(back[0][1]) == pytest.approx(float(fac[1]), rel=2e-4)
+            assert float(sent[r][1]) == pytest.approx(local[r][1], rel=tol), (it, r)   # sum of the positives' quality scores (student logits)
+        assert float(back[0][0]) == float(fac[0]) and float(back[0][1]) == pytest.approx(float(fac[1]), rel=tol)
     # ---- both ranks hold the same gradient / parameters, bit for bit -------------------------------------------------------------
     for k in res[0]["grad0"]:
         assert torch.equal(res[0]["grad0"][k], res[1]["grad0"][k]), k

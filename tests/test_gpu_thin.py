@@ -1,0 +1,129 @@
+"""GPU: the activation-stationary three-limb kernel for thin 1x1 convolutions (csrc/conv_thin.hip; Cin in {64, 128}: layer1 / layer2 of
+the ResNet, resnet.py:268-300 conv1 / conv3 and their input gradients).  It issues the SAME MFMA sequence per accumulator as the
+stream-K implicit GEMM it replaces on these shapes, so every form -- plain, folded-BN + residual + ReLU epilogue, input gradient with
+residual / ReLU mask / column sums, accumulate, stride 2, several levels in one launch, ragged last tile -- must be BIT-identical to
+that kernel (erd_conv_thin_enable(0)), and as close to an fp64 evaluation as it is."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import golden_inputs as G
+from test_gpu_kernels import nhwc, to_nchw
+
+
+@pytest.fixture()
+def K():
+    from erd_amd import kernels as K, _lib
+    K.set_compute("f32x3")
+    lib = _lib.load()
+    prev = lib.erd_conv_thin_enable(-1)
+    yield K
+    lib.erd_conv_thin_enable(prev)
+    K.set_compute(K.DEFAULT_COMPUTE)
+
+
+def both(K, fn):
+    """run fn() with the thin kernel on and off -> (on, off)"""
+    from erd_amd import _lib
+    lib = _lib.load()
+    out = []
+    for on in (1, 0):
+        lib.erd_conv_thin_enable(on)
+        out.append(fn())
+    lib.erd_conv_thin_enable(1)
+    return out
+
+
+CASES = [  # N, Cin, Cout, H, W, stride
+    (2, 128, 512, 25, 42, 1),      # 2100 pixels: 16 full tiles + a ragged one
+    (1, 64, 256, 30, 44, 1),
+    (2, 128, 128, 13, 21, 1),
+    (2, 64, 64, 17, 9, 1),
+    (1, 128, 32, 40, 40, 1),
+    (2, 128, 256, 26, 40, 2),      # stride-2 1x1 (a projection shortcut's shape)
+    (4, 128, 512, 100, 168, 1),    # layer2's expanding convolution at BASELINE size
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,s", CASES)
+def test_thin_forward_forms_are_bit_identical_to_the_stream_k_kernel(K, N, Cin, Cout, H, W, s):
+    x = G.randn(1, N, Cin, H, W)
+    w = G.randn(2, Cout, Cin, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    scale, shift = 0.5 + G.rand(3, Cout), G.randn(4, Cout, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), None, s, 0)
+    OH, OW = ref.shape[2:]
+    res = G.randn(5, N, Cout, OH, OW)
+    ref2 = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xg, rg = nhwc(x), nhwc(res)
+
+    def run():
+        out = torch.empty((N, OH, OW, Cout), device="cuda")
+        K.conv_forward([xg], wg, [out], 1, s, 0)
+        out2 = torch.empty_like(out)
+        K.conv_forward([xg], wg, [out2], 1, s, 0, scale=scale.cuda(), shift=shift.cuda(), res=[rg], relu=True)
+        out3 = rg.clone()                                     # residual aliasing the output
+        K.conv_forward([xg], wg, [out3], 1, s, 0, res=[out3])
+        return out, out2, out3
+
+    (a, a2, a3), (b, b2, b3) = both(K, run)
+    assert torch.equal(a, b) and torch.equal(a2, b2) and torch.equal(a3, b3)
+    e1 = float((to_nchw(a).double() - ref).norm() / ref.norm())
+    e2 = float((to_nchw(a2).double() - ref2).norm() / ref2.norm())
+    print("thin %d->%d on %dx%d/%d: rel L2 to fp64 plain %.2e, epilogue %.2e" % (Cin, Cout, H, W, s, e1, e2))
+    assert e1 < 3e-7 and e2 < 3e-7
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 512, 128, 25, 42), (1, 256, 64, 30, 44), (4, 512, 128, 100, 168)])
+def test_thin_input_gradient_forms(K, N, Cin, Cout, H, W):
+    """the input gradient of a REDUCING 1x1 convolution (Cin -> Cout = 64 / 128) is a thin GEMM K = Cout -> N = Cin with the fused
+    bottleneck epilogue: + the shortcut's gradient, x the ReLU mask of the block input, column sums for its d beta"""
+    dz = G.randn(1, N, Cout, H, W)
+    w = G.randn(2, Cout, Cin, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    rowscale = 0.5 + G.rand(3, Cout)
+    short = G.randn(4, N, Cin, H, W)
+    mask = G.randn(5, N, Cin, H, W)
+    ref = F.conv_transpose2d(dz.double() * rowscale.double().view(1, -1, 1, 1), w.double())
+    ref_m = (ref + short.double()) * (mask.double() > 0)
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    dzg, sg, mg = nhwc(dz), nhwc(short), nhwc(mask)
+
+    def run():
+        wt = K.weight_transpose(wg, rowscale.cuda())
+        dx = torch.empty((N, H, W, Cin), device="cuda")
+        K.conv_dgrad([dzg], wt, [dx], 1, 1, 0)
+        dx2 = torch.empty_like(dx)
+        cs = torch.zeros((8, Cin), device="cuda")
+        K.conv_dgrad([dzg], wt, [dx2], 1, 1, 0, res=[sg], relu_mask=[mg], colsum=cs)
+        dx3 = sg.clone()
+        K.conv_dgrad([dzg], wt, [dx3], 1, 1, 0, accumulate=True)
+        return dx, dx2, cs.sum(0), dx3
+
+    (a, a2, ca, a3), (b, b2, cb, b3) = both(K, run)
+    assert torch.equal(a, b) and torch.equal(a2, b2) and torch.equal(a3, b3)
+    assert torch.allclose(ca, cb, rtol=1e-5, atol=1e-4)                     # (float atomics: order-dependent in both kernels)
+    assert float((to_nchw(a).double() - ref).norm() / ref.norm()) < 3e-7
+    assert float((to_nchw(a2).double() - ref_m).norm() / ref_m.norm()) < 3e-7
+    assert torch.allclose(ca.cpu().double(), ref_m.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+def test_thin_several_levels_in_one_launch(K):
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    N, Cin, Cout = 2, 128, 96
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(21, N, A, Cin)
+    w = G.randn(22, Cout, Cin, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xg = x.cuda()
+
+    def run():
+        out = torch.empty((N, A, Cout), device="cuda")
+        K.conv_forward(K.level_views(xg, sizes), wg, K.level_views(out, sizes), 1, 1, 0)
+        return out
+
+    a, b = both(K, run)
+    assert torch.equal(a, b)
+    ref = (x.double() @ w.double().view(Cout, Cin).t())
+    assert float((a.cpu().double() - ref).norm() / ref.norm()) < 3e-7

@@ -1,0 +1,40 @@
+"""CPU: the statements README / DESIGN / tests/test_gpu_parity_full.py make about the fp32 forms' distance to an fp64 evaluation
+are read off profiles/r04_parity_seeds.json (tools/parity_seeds.py on the GPU box, merged by tools/parity_merge.py) -- this test
+recomputes them from the committed per-seed rows, so a quoted number cannot drift from the data (">= 48
+full-size seeds ... and assert what the 48 support").  No GPU, no oracle: arithmetic on a JSON file."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parity_seed_statistics_support_the_documented_claims():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_seeds.json")))
+    rows = {k: np.array(v) for k, v in d["rows"].items()}
+    n = len(d["seeds"])
+    assert n >= 48 and len(set(d["seeds"])) == n and all(len(v) == n for v in rows.values())
+    cpu, x3, f32 = rows["cpu_f32"], rows["hip_f32x3"], rows["hip_f32"]
+    whole = lambda a: a[:, 1]
+    sem = lambda a: float(a.std(ddof=1) / np.sqrt(len(a)))
+    # the summary block is what the rows say
+    for k, a in rows.items():
+        assert np.allclose(d["summary"][k]["mean"], a.mean(0)) and np.allclose(d["summary"][k]["median"], np.median(a, 0))
+        assert d["summary"][k]["seeds_whole_gradient_above_1e-3"] == int((whole(a) > 1e-3).sum())
+    # 1. both HIP forms are at least as close to fp64 as the reference's own fp32 arithmetic: mean and median of the whole-gradient
+    #    distance, and no more seeds above north_star's 1e-3 than the reference has (+ 1)
+    for hip in (x3, f32):
+        assert whole(hip).mean() <= whole(cpu).mean() and np.median(whole(hip)) <= 1.1 * np.median(whole(cpu))
+        assert int((whole(hip) > 1e-3).sum()) <= int((whole(cpu) > 1e-3).sum()) + 1
+        assert whole(hip).max() <= whole(cpu).max()
+    # 2. the three-limb form against the native fp32-MFMA form, paired over the same seeds: the median within 1.1 x, and the mean
+    #    difference not distinguishable from zero (inside two standard errors) or, if it is, below 10 % of the native mean
+    diff = whole(x3) - whole(f32)
+    assert np.median(whole(x3)) <= 1.1 * np.median(whole(f32))
+    assert abs(diff.mean()) <= 2.0 * sem(diff) or diff.mean() <= 0.10 * whole(f32).mean(), (diff.mean(), sem(diff), whole(f32).mean())
+    # 3. per-tensor median and worst tensor: means at most 1.1 x the reference's
+    for col in (0, 2):
+        assert x3[:, col].mean() <= 1.1 * cpu[:, col].mean() and f32[:, col].mean() <= 1.1 * cpu[:, col].mean()
+    # 4. losses: every entry of every seed within 1e-3 of fp64
+    assert all(v < 1e-3 for v in d["worst_loss_entry_rel_dev_from_fp64"].values())
