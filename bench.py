@@ -36,6 +36,10 @@ import torch.distributed as dist
 H, W = 800, 1333
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = f32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 (MI355X_MICROARCH.md)
+# what the bf16 pipe SUSTAINS on random operands (tools/mfma_peak.hip, profiles/r04_mfma_peak_random.txt: 1 865-1 873 TF at 1.84 GHz;
+# constant operands hold 2.39 GHz and 2 472 TF -- power management, not issue rate).  Reported BESIDE the nominal peak, never as `peak`.
+BF16_MFMA_SUSTAINED_TFLOPS = 1867.0
+FP32_MFMA_SUSTAINED_TFLOPS = 154.2  # (random operands: the fp32 MFMA keeps its clock)
 HBM_PEAK_GBS = 8000.0
 # algorithmic work per image per step at 800x1344: teacher fwd + student fwd + student bwd
 STEP_GFLOP_PER_IMAGE = {"r50_40_40": 1663.6,       # 431.8 + 436.0 + 795.8
@@ -536,12 +540,15 @@ def main():
                     "pipe_peak_tflops": k_peak, "ms_per_step": round(g["ms"] / rsteps, 3), "launches_per_step": g["launches"] // rsteps,
                     "avg_launch_us": round(k_us, 2), "algorithmic_tflops": round(k_alg, 2), "executed_flop_fraction": round(k_exec, 4),
                     "executed_tflops": round(k_alg * k_exec, 2), "mfma_frac": round(mfma_frac, 4),
+                    "pipe_sustained_tflops_random_operands": BF16_MFMA_SUSTAINED_TFLOPS if on_bf16 else FP32_MFMA_SUSTAINED_TFLOPS,
+                    "mfma_frac_of_sustained": round(k_alg * k_exec / (BF16_MFMA_SUSTAINED_TFLOPS if on_bf16 else FP32_MFMA_SUSTAINED_TFLOPS), 4),
                     "algorithmic_bytes_per_launch": int(k_bytes), "hbm_GBps_algorithmic": round(k_bytes / (k_us * 1e-6) / 1e9, 1),
                     "hbm_frac": round(hbm_frac, 4), "bound": "mfma" if mfma_frac >= hbm_frac else "hbm",
                     "frac_of_binding_roofline": round(max(mfma_frac, hbm_frac), 4),
                     "pmc_traffic_bytes_per_launch": k_traffic, "pmc_traffic_over_algorithmic": round(k_traffic / k_bytes, 2) if k_traffic else None,
                     "pmc_mfma_busy": k_busy, "pmc_static": True, "pmc_source": k_src}
             out["roofline"]["per_kernel"] = per_kernel
+            out["roofline"]["sustained_peaks_source"] = "profiles/r04_mfma_peak_random.txt (tools/mfma_peak.hip, random operands)"
             # ---- step level, three ways, all over the un-instrumented step time of the timed region and the same peak:
             #  step_frac           the ALGORITHMIC work of the reference's step (both copies of the frozen trunk)
             #  step_frac_executed  minus the student's copy of the shared frozen trunk, which this build does not execute

@@ -79,6 +79,9 @@ _SIGNATURES = {
     "erd_wino_weights_elems": [i32, i32],
     "erd_wino_weights": [P, P, i32, i32, i32, P],
     "erd_wino_conv3x3": [P, i32, P, i32, i32, P, P, i32, P, i32, P, P],
+    "erd_wino_weights_x3_elems": [i32, i32],
+    "erd_wino_weights_x3": [P, P, i32, i32, i32, P],
+    "erd_wino_conv3x3_x3": [P, i32, P, i32, i32, P, P, i32, P, i32, P, P],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_row3_slices": [C.POINTER(WgradDesc)],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],

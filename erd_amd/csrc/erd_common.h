@@ -83,6 +83,44 @@ __device__ __forceinline__ void limbs3(float x, unsigned short& hi, unsigned sho
     lo = (unsigned short)(l & 0xffffu);
 }
 
+// ---- Winograd F(2x2,3x3) weight image in the THREE-LIMB layout (winograd.hip wino_x3_kernel; prep.hip kind 4) ----------------
+// U_xi = (G g G^T)[xi] of output channel co / input channel ci -- the arithmetic of wino_weight_kernel, value for value -- split
+// into limbs and stored as MFMA A-fragments of v_mfma_f32_32x32x16_bf16: U3[xi][limb][co / 32][ci / 16][lane = (ci % 16 / 8) * 32 +
+// co % 32][ci % 8], 1 KB per (xi, limb, cout block, slice); rows past Cout are zero.  One thread per (co < ceil32(Cout), ci).
+__device__ __forceinline__ void wino_x3_weight_item(const float* __restrict__ w, unsigned short* __restrict__ U3, int Cout, int Cin,
+                                                    int flip, int co, int ci) {
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            g[a][b] = co < Cout ? w[((int64_t)co * 9 + (flip ? 8 - (a * 3 + b) : a * 3 + b)) * Cin + ci] : 0.f;
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int nks = Cin / 16, ncb32 = (Cout + 31) / 32;
+    const int64_t per_xl = (int64_t)ncb32 * nks * 512;                       // bf16 elements per (position, limb)
+    const int64_t base = (((int64_t)(co / 32) * nks + ci / 16) * 64 + ((ci % 16) / 8) * 32 + (co % 32)) * 8 + (ci % 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u[4] = {t[i][0], 0.5f * (t[i][0] + t[i][1] + t[i][2]), 0.5f * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short hi, mid, lo;
+            limbs3(u[j], hi, mid, lo);
+            const int64_t o = (int64_t)((i * 4 + j) * 3) * per_xl + base;
+            U3[o] = hi;
+            U3[o + per_xl] = mid;
+            U3[o + 2 * per_xl] = lo;
+        }
+    }
+}
+
 // Element type of a map: float or erd::bf16s (a 16-bit storage cell).  ld4 / st4 move four consecutive values
 // (16-B / 8-B aligned), ld1 / st1 one.
 struct bf16s { unsigned short bits; };

@@ -82,6 +82,14 @@ __device__ __forceinline__ void split3_block(const erd_weight_prep_item& it, int
     d[2 * n + i] = l;
 }
 
+// kind 4: the Winograd weight image in the three-limb layout (erd_wino_weights_x3): one thread per (co < ceil32(Cout), ci)
+__device__ __forceinline__ void wino_x3_block(const erd_weight_prep_item& it, int local) {
+    const int cop = (it.Cout + 31) / 32 * 32;
+    const int64_t idx = local * 256ll + threadIdx.x;
+    if (idx >= (int64_t)cop * it.Cin) return;
+    erd::wino_x3_weight_item(it.w, reinterpret_cast<unsigned short*>(it.dst), it.Cout, it.Cin, it.flip, (int)(idx / it.Cin), (int)(idx % it.Cin));
+}
+
 __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_item* __restrict__ items, int nitems) {
     __shared__ float tile[32][33];
     __shared__ int s_item;
@@ -98,6 +106,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_
     const int local = (int)blockIdx.x - it.block0;
     if (it.kind == 2) wino_block(it, local);
     else if (it.kind == 3) split3_block(it, local);
+    else if (it.kind == 4) wino_x3_block(it, local);
     else transpose_block(it, local, tile);
 }
 
@@ -106,6 +115,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_
 extern "C" int erd_weight_prep_blocks(int kind, int Cout, int ntaps, int Cin) {
     if (kind == 2) return (int)(((int64_t)((Cout + 15) / 16 * 16) * Cin + 255) / 256);
     if (kind == 3) return (int)(((int64_t)Cout * ntaps * Cin + 255) / 256);
+    if (kind == 4) return (int)(((int64_t)((Cout + 31) / 32 * 32) * Cin + 255) / 256);
     return ((Cin + 31) / 32) * ((Cout + 31) / 32) * ntaps;
 }
 

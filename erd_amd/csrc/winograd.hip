@@ -131,6 +131,7 @@ struct WinoDesc {
     WinoSeg seg[ERD_MAX_SEG];
     WinoRegion reg[MAXREG];
     const float* U;
+    const void* U3;          // three-limb form (wino_x3_kernel): the bf16 limb image of U, erd_wino_weights_x3
     int Cin, Cout;
     const float* scale;
     const float* shift;
@@ -646,6 +647,458 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
     }
 }
 
+
+// =====================================================================================================================
+// The THREE-LIMB form of the same algorithm ("f32x3"): fp32 maps, fp32 accumulation, fp32 results, the 16 transform-domain
+// GEMMs on the bf16 matrix cores.  U = G g G^T arrives pre-split into three bf16 limb planes (erd_wino_weights_x3), V = B^T d B
+// is split by the data waves right after the transform (erd::limbs3_pair: exact sums, round-to-nearest limbs), and every
+// product u v is formed as the six limb products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 -- 6 x 32 cycles per
+// (position, 32 couts x 32 tiles x 16 channels) against 128 x 32 cycles of v_mfma_f32_16x16x4_f32 for all 16 positions of
+// 16 couts: a slice is 1 536 matrix cycles per wave instead of 4 096 (tools/wino_x3_skeleton.hip measured the matrix side
+// alone -- MFMAs + weight-fragment stream -- at 1 892 cycles per slice, profiles/r04_wino_x3_skeleton.txt).
+// What changes against wino_conv_kernel:
+//   * item = 32 tiles x 64 couts as before, but a matrix wave owns 32 couts x 32 tiles (the MFMA's shape) of HALF the
+//     positions: wave w -> cout block w >> 1, positions 8 (w & 1) .. + 7 (= rows i = 2 (w & 1), 2 (w & 1) + 1 of the 4 x 4
+//     transform grid): 8 x 16 = 128 accumulator registers.  A^T M A needs all four rows: each wave forms z[i][c] =
+//     (M A)[i][c] for its two rows, the pair swaps ONE row each through LDS (wave A sends z1 and finishes output row 0 =
+//     (z0 + z1) + z2, wave B sends z2 and finishes row 1 = (z1 - z2) - z3: the fp32 kernel's summation order) in eight
+//     rounds of 4 registers, double-buffered, handed over with LDS flags (no workgroup barrier: the data waves run on);
+//   * V lives in LDS as [position][limb][tile][16 channels] bf16 (32-byte rows: a wave's B-fragment read is 1 KB
+//     contiguous, conflict-free), 48 KB per slice, double-buffered; the data waves write 8 bytes per (position, limb);
+//   * weight fragments: U3[position][limb][cout block][slice] is 1 KB contiguous; a ring of FOUR positions (x 3 limbs),
+//     re-loaded four positions ahead.
+// Everything else -- item list, block shapes, raw staging, look-ahead, the single barrier per slice -- is the fp32 kernel's.
+constexpr int VX_B = 16 * 3 * 1024;            // bytes of one V buffer (three-limb form)
+constexpr int XCH_B = 1024;                    // bytes of one exchange chunk (4 registers x 64 lanes)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: raw0 | raw1 | V0 | V1 (2 x VX_B) | exchange [4 waves][2][XCH_B] | flags [4] | sh_ss [4][128] | sh_item [2]
+    constexpr unsigned RAWB = RAW_LDS_F4 * 16, VOFF = 2 * RAWB, VB = VX_B, XOFF = VOFF + 2 * VB;
+    volatile int* xflag = reinterpret_cast<volatile int*>(smem + XOFF + 4 * 2 * XCH_B);
+    float* sh_ss = reinterpret_cast<float*>(smem + XOFF + 4 * 2 * XCH_B + 64);
+    int* sh_item = reinterpret_cast<int*>(sh_ss + 512);
+
+    const int tid = threadIdx.x;
+    const int Cin = p.Cin;
+    const int nks = Cin / KS;
+    const int nitems = p.nitems;
+    const int ncb32 = (p.Cout + 31) / 32;
+
+    auto decode = [&](int item) {
+        WinoItem it;
+        const int nb = item / p.blocks_per_nb;
+        int b = item - nb * p.blocks_per_nb;
+        int r = 0;
+        while (r + 1 < p.nreg && b >= p.reg[r + 1].block0) ++r;
+        const WinoRegion& rg = p.reg[r];
+        b -= rg.block0;
+        const int per_img = rg.nby * rg.nbx;
+        const int n = b / per_img;
+        const int rem = b - n * per_img;
+        const int by = rem / rg.nbx, bx = rem - by * rg.nbx;
+        const int lbw = rg.lbw;
+        it.s = __builtin_amdgcn_readfirstlane(rg.seg);
+        it.n = __builtin_amdgcn_readfirstlane(n);
+        it.y0 = __builtin_amdgcn_readfirstlane(2 * (rg.ty0 + by * (32 >> lbw)));
+        it.x0 = __builtin_amdgcn_readfirstlane(2 * (rg.tx0 + (bx << lbw)));
+        it.cout0 = __builtin_amdgcn_readfirstlane(nb * BN);
+        it.lbw = __builtin_amdgcn_readfirstlane(lbw);
+        it.yl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].H, 2 * rg.ty1));
+        it.xl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].W, 2 * rg.tx1));
+        return it;
+    };
+    auto claim = [&](int k) -> int {
+        return p.sched ? (int)gridDim.x + atomicAdd(p.sched, 1) : (int)blockIdx.x + (k + 1) * (int)gridDim.x;
+    };
+
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool is_mma = wave_id >= 4;
+    const int wave = wave_id & 3;
+    const int item0 = blockIdx.x;
+    if (item0 >= nitems) return;
+    if (tid < 4) xflag[tid] = 0;                 // (published by the first workgroup barrier, long before the first exchange)
+
+    if (is_mma) {
+        // ------------------------------------------------------------------ matrix waves
+        const int li = lane & 31, h = lane >> 5;
+        const int cb = wave >> 1, ph = wave & 1;
+        const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.U3), 0, (int)((size_t)16 * 3 * ncb32 * nks * 1024), 0x00020000);
+        const unsigned u_lane = (unsigned)lane * 16u;
+        const unsigned per_xl_b = (unsigned)ncb32 * (unsigned)nks * 1024u;          // bytes per (position, limb)
+        const unsigned pos0_b = (unsigned)(ph * 8 * 3) * per_xl_b;                  // this wave's first position
+        // B-fragment address inside a V buffer: (position, limb) block of 1 KB, tile row 32 B, k half h
+        const unsigned v_lane = (unsigned)(ph * 8 * 3 * 1024 + li * 32 + h * 16);
+        const char* vbase0 = smem + VOFF;
+        char* const xmy = smem + XOFF + wave * 2 * XCH_B + lane * 16;
+        const char* const xpartner = smem + XOFF + (wave ^ 1) * 2 * XCH_B + lane * 16;
+        int xr = 0;                                                                 // exchange rounds done
+
+        WinoItem cur = decode(item0);
+        int k_item = 0;
+        unsigned u_item = (unsigned)__builtin_amdgcn_readfirstlane(((cur.cout0 >> 5) + cb) * nks * 1024);   // byte offset of (cout block, ks = 0) inside a plane
+        f32x16 acc[8];
+        u32x4 ub[4][3];                                                             // weight-fragment ring: position q lives in slot q & 3
+        bf16x8 vf[2][3];                                                            // tile fragments [position parity][limb]
+        auto load_u = [&](const int q, const unsigned soff) {                      // q: compile-time after unrolling
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                ub[q & 3][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)(q * 3 + l) * per_xl_b + soff, 0);
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_u(q, u_item);
+        __syncthreads();                                    // P   (data waves: raw slice 0 is in LDS)
+        __syncthreads();                                    // B_0 (V(0) complete)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) vf[0][l] = *reinterpret_cast<const bf16x8*>(vbase0 + v_lane + l * 1024);
+        int g = 0;
+        for (;;) {
+            const int nxt_item = __builtin_amdgcn_readfirstlane(sh_item[(k_item + 1) & 1]);
+            const bool has_next = nxt_item < nitems;
+            const WinoItem nxt = has_next ? decode(nxt_item) : cur;
+            const unsigned u_next = (unsigned)__builtin_amdgcn_readfirstlane(((nxt.cout0 >> 5) + cb) * nks * 1024);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+            for (int ks = 0; ks < nks; ++ks, ++g) {
+                const char* vc = vbase0 + v_lane + ((g & 1) ? VB : 0);
+                const char* vn = vbase0 + v_lane + ((g & 1) ? 0 : VB);
+                int lastflag = __builtin_amdgcn_readfirstlane(ks + 1 == nks ? 1 : 0);
+                asm volatile("" : "+s"(lastflag));          // (opaque: keeps the compiler from peeling the last slice)
+                const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(u_item + (unsigned)ks * 1024u));
+                const unsigned u_reload = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)(lastflag ? u_next : u_item + (unsigned)(ks + 1) * 1024u));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q == 7) {                           // B_{g+1}: V(g+1) complete; every read of V(g) has been issued
+                        __syncthreads();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const char* src = q < 7 ? vc + (q + 1) * 3 * 1024 : vn;
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) vf[(q + 1) & 1][l] = *reinterpret_cast<const bf16x8*>(src + l * 1024);
+                    __builtin_amdgcn_sched_barrier(0);      // reads first: they travel behind this position's MFMAs
+                    const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[q & 3][0]), um = __builtin_bit_cast(bf16x8, ub[q & 3][1]),
+                                 ul = __builtin_bit_cast(bf16x8, ub[q & 3][2]);
+                    const bf16x8 vh = vf[q & 1][0], vm = vf[q & 1][1], vl = vf[q & 1][2];
+                    // rows = couts (U), columns = tiles (V); smallest terms first, as everywhere in the three-limb kernels
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[q], 0, 0, 0);
+                    // the slot is free: position q + 4 of this slice, or position q - 4 of the next one
+                    if (q < 4) load_u(q + 4, u_cur); else load_u(q - 4, u_reload);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- output stage: z[i][c] = (M A)[i][c] for this wave's two rows, one row swapped with the partner wave, y = A^T z
+            {
+                const WinoSeg& sg = p.seg[cur.s];
+                const float* ss = sh_ss + (k_item & 3) * 128;
+                const int lbw = cur.lbw, bwm = (1 << lbw) - 1;
+                const int ty = li >> lbw, tx = li & bwm;
+                const int oy = cur.y0 + 2 * ty + ph;                          // this wave finishes output row a = ph of every tile
+                const bool simple = !sg.res && !sg.mask && !p.colsum;
+                const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+                    sg.out, 0, (int)((long long)sg.N * sg.out_nstride * 4), 0x00020000);
+                const float lo = p.relu ? 0.f : -__builtin_inff();
+                float4 cs[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) cs[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                // z[il][c] = (M A)[i][c] of this wave's rows i = 2 ph + il: the accumulators die here, row by row
+                f32x16 z[2][2];
+                z[0][0] = (acc[0] + acc[1]) + acc[2];
+                z[0][1] = (acc[1] - acc[2]) - acc[3];
+                z[1][0] = (acc[4] + acc[5]) + acc[6];
+                z[1][1] = (acc[5] - acc[6]) - acc[7];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x16 za = z[0][c], zb = z[1][c];
+                    f32x16 recv;
+#pragma unroll
+                    for (int qr = 0; qr < 4; ++qr) {                          // A sends z1, B sends z2: four registers per round
+                        char* mine = xmy + (xr & 1) * XCH_B;
+                        const float4 s4 = ph == 0 ? make_float4(zb[4 * qr], zb[4 * qr + 1], zb[4 * qr + 2], zb[4 * qr + 3])
+                                                  : make_float4(za[4 * qr], za[4 * qr + 1], za[4 * qr + 2], za[4 * qr + 3]);
+                        *reinterpret_cast<float4*>(mine) = s4;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) xflag[wave] = xr + 1;
+                        while (xflag[wave ^ 1] < xr + 1) __builtin_amdgcn_s_sleep(1);
+                        const float4 r0 = *reinterpret_cast<const float4*>(xpartner + (xr & 1) * XCH_B);
+                        recv[4 * qr + 0] = r0.x; recv[4 * qr + 1] = r0.y; recv[4 * qr + 2] = r0.z; recv[4 * qr + 3] = r0.w;
+                        ++xr;
+                    }
+                    // wave A: y[0][c] = (z0 + z1) + z2 ; wave B: y[1][c] = (z1 - z2) - z3   (the fp32 kernel's order)
+                    const f32x16 yv = ph == 0 ? (za + zb) + recv : (recv - za) - zb;
+                    const int ox = cur.x0 + 2 * tx + c;
+                    const bool pix_ok = oy < cur.yl && ox < cur.xl;
+                    const int64_t opix = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {                          // registers 4 gq .. 4 gq + 3: couts 8 gq + 4 h + {0..3} of the block
+                        const int cl = 32 * cb + 8 * gq + 4 * h;              // 0..63 inside the item's cout block
+                        const int co0 = cur.cout0 + cl;
+                        const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                        const float4 sh = *reinterpret_cast<const float4*>(ss + 64 + cl);
+                        float4 v = make_float4(yv[4 * gq] * sc.x + sh.x, yv[4 * gq + 1] * sc.y + sh.y, yv[4 * gq + 2] * sc.z + sh.z,
+                                               yv[4 * gq + 3] * sc.w + sh.w);
+                        if (simple && (p.Cout & 3) == 0) {
+                            const bool ok = pix_ok && co0 < p.Cout;
+                            u32x4 o;
+                            o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
+                            o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
+                        } else if (pix_ok && co0 < p.Cout) {
+                            const int64_t o = opix + co0;
+                            if ((p.Cout & 3) == 0) {
+                                if (sg.res) v = f4add(v, *reinterpret_cast<const float4*>(sg.res + o));
+                                if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                                if (sg.mask) {
+                                    const float4 mk = *reinterpret_cast<const float4*>(sg.mask + o);
+                                    v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
+                                                    mk.w > 0.f ? v.w : 0.f);
+                                }
+                                *reinterpret_cast<float4*>(sg.out + o) = v;
+                            } else {
+                                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    if (co0 + r < p.Cout) {
+                                        float e = vv[r];
+                                        if (sg.res) e += sg.res[o + r];
+                                        if (p.relu) e = fmaxf(e, 0.f);
+                                        if (sg.mask) e = sg.mask[o + r] > 0.f ? e : 0.f;
+                                        sg.out[o + r] = e;
+                                        vv[r] = e;
+                                    } else vv[r] = 0.f;
+                                }
+                                v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                            }
+                            cs[gq] = f4add(cs[gq], v);
+                        }
+                    }
+                }
+                if (p.colsum) {                                               // (Cout % 4 == 0 is required with colsum)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) {
+                            cs[gq].x += __shfl_xor(cs[gq].x, o, 64); cs[gq].y += __shfl_xor(cs[gq].y, o, 64);
+                            cs[gq].z += __shfl_xor(cs[gq].z, o, 64); cs[gq].w += __shfl_xor(cs[gq].w, o, 64);
+                        }
+                        const int co0 = cur.cout0 + 32 * cb + 8 * gq + 4 * h;
+                        if (li == 0 && co0 < p.Cout) {
+                            float* cp = p.colsum + (p.colsum_copies > 1 ? (blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) + co0;
+                            atomicAdd(cp + 0, cs[gq].x); atomicAdd(cp + 1, cs[gq].y); atomicAdd(cp + 2, cs[gq].z); atomicAdd(cp + 3, cs[gq].w);
+                        }
+                    }
+                }
+            }
+            if (!has_next) {
+                if (wave == 0 && lane == 0 && p.sched) {     // the last workgroup to leave re-arms the counters
+                    if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
+                }
+                break;
+            }
+            cur = nxt;
+            u_item = u_next;
+            ++k_item;
+        }
+    } else {
+        // ------------------------------------------------------------------ data waves (wino_conv_kernel's, with the limb split
+        // behind the transform and 8-byte stores into the [position][limb][tile][16 channels] planes)
+        __builtin_amdgcn_s_setprio(ERD_WINO_DATA_PRIO);
+        const int dt = tid & 255;
+        const int t_chunk = dt & 3, t_tile = (dt >> 2) & 31, t_half = __builtin_amdgcn_readfirstlane(dt >> 7);
+        WinoItem la = decode(item0);
+        int la_ks = 0, k_la = 0;
+        unsigned la_soff = 0;
+        bool la_valid = true;
+        int slices_total = nks;
+        unsigned roff[NCH];
+        float4 rv[NCH], rvb[NCH];
+        __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0].in), 0, 0, 0x00020000);
+        float pend_sc = 1.f, pend_sh = 0.f;
+        int pend_claim = 0, pend_k = -1;
+        unsigned rd0 = 0, rd1 = 0, rd2 = 0;
+        unsigned nrd0 = 0, nrd1 = 0, nrd2 = 0;
+        int tr_left = 0;
+        WinoItem nx_it = la;
+        bool nx_valid = false;
+        unsigned nx_roff[NCH], nx_rd0 = 0, nx_rd1 = 0, nx_rd2 = 0;
+        __amdgpu_buffer_rsrc_t nx_rs = rs_in;
+        auto item_geometry = [&](const WinoItem& it, unsigned (&ro)[NCH], unsigned& g0, unsigned& g1, unsigned& g2,
+                                 __amdgpu_buffer_rsrc_t& rs) {
+            const WinoSeg& sg = p.seg[it.s];
+            rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+            const int lbw = it.lbw, bw = 1 << lbw, bh = 32 >> lbw;
+            const int pc_n = 2 * bw + 2, npix = (2 * bh + 2) * pc_n;
+            const int recip = (65536 + pc_n - 1) / pc_n;
+            const unsigned base_n = (unsigned)(it.n * sg.in_nstride);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int idx = dt + 256 * i;
+                const int chunk = idx & 3, pix = idx >> 2;
+                const int pr = (pix * recip) >> 16, pc = pix - pr * pc_n;
+                const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
+                ro[i] = OOBV;
+                if (pix < npix && (unsigned)iy < (unsigned)sg.H && (unsigned)ix < (unsigned)sg.W)
+                    ro[i] = (base_n + (unsigned)((iy * sg.W + ix) * Cin + chunk * 4)) * 4u;
+            }
+            const int t_ty = t_tile >> lbw, t_tx = t_tile & (bw - 1);
+            g0 = (unsigned)((((2 * t_ty + t_half) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
+            g1 = g0 + (unsigned)(pc_n * RCS * 16);
+            g2 = g1 + (unsigned)(pc_n * RCS * 16);
+        };
+        auto request_item_data = [&]() {
+            if (dt < 64) {
+                const int co = la.cout0 + dt;
+                pend_sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
+                pend_sh = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
+            }
+            if (dt == 64) pend_claim = claim(k_la);
+            pend_k = k_la;
+        };
+        auto flush_pending = [&]() {
+            if (pend_k >= 0) {
+                if (dt < 64) {
+                    float* ss = sh_ss + (pend_k & 3) * 128;
+                    ss[dt] = pend_sc;
+                    ss[64 + dt] = pend_sh;
+                }
+                if (dt == 64) sh_item[(pend_k + 1) & 1] = pend_claim;
+                pend_k = -1;
+            }
+        };
+        auto issue_next = [&](float4* dst) {
+            if (la_valid) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
+                la_soff += KS * 4;
+                ++la_ks;
+                if (la_ks == 3) {
+                    const int nx = __builtin_amdgcn_readfirstlane(sh_item[(k_la + 1) & 1]);
+                    nx_valid = nx < nitems;
+                    if (nx_valid) nx_it = decode(nx);
+                }
+                if (la_ks == 4 && nx_valid) item_geometry(nx_it, nx_roff, nx_rd0, nx_rd1, nx_rd2, nx_rs);
+                if (la_ks == nks) {
+                    if (nx_valid) {
+                        la = nx_it;
+                        rs_in = nx_rs;
+#pragma unroll
+                        for (int i = 0; i < NCH; ++i) roff[i] = nx_roff[i];
+                        nrd0 = nx_rd0; nrd1 = nx_rd1; nrd2 = nx_rd2;
+                        la_ks = 0;
+                        la_soff = 0;
+                        ++k_la;
+                        slices_total += nks;
+                        request_item_data();
+                    } else la_valid = false;
+                }
+            }
+        };
+        char* const sm = smem;
+        const unsigned st_base = (unsigned)(((dt >> 2) * RCS + (dt & 3)) * 16);
+        // this thread's 8 bytes inside a (position, limb) block: tile row 32 B, channels 4 t_chunk .. + 3
+        const unsigned wr_base = VOFF + (unsigned)(t_tile * 32 + t_chunk * 8);
+        auto store_raw = [&](const float4* src, auto par_tag) {
+            constexpr unsigned PAR = decltype(par_tag)::value;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) *reinterpret_cast<float4*>(sm + PAR * RAWB + st_base + i * (64 * RCS * 16)) = src[i];
+        };
+        auto put = [&](char* dst, const float4 v) {        // four channels of one position -> three limb words of 8 bytes
+            uint2 hi, mid, lo;
+            erd::limbs3_pair(v.x, v.y, hi.x, mid.x, lo.x);
+            erd::limbs3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + 1024) = mid;
+            *reinterpret_cast<uint2*>(dst + 2048) = lo;
+        };
+        auto transform = [&](auto rpar_tag, auto vpar_tag, auto half_tag) {
+            constexpr unsigned RPAR = decltype(rpar_tag)::value, VPAR = decltype(vpar_tag)::value;
+            constexpr int HALF = decltype(half_tag)::value;
+            const char* r0 = sm + RPAR * RAWB + rd0;
+            const char* r1 = sm + RPAR * RAWB + rd1;
+            const char* r2 = sm + RPAR * RAWB + rd2;
+            float4 rr[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 d0 = *reinterpret_cast<const float4*>(r0 + c * (RCS * 16));
+                const float4 d1 = *reinterpret_cast<const float4*>(r1 + c * (RCS * 16));
+                const float4 d2 = *reinterpret_cast<const float4*>(r2 + c * (RCS * 16));
+                if (HALF == 0) { rr[0][c] = f4sub(d0, d2); rr[1][c] = f4add(d1, d2); }
+                else           { rr[0][c] = f4sub(d1, d0); rr[1][c] = f4sub(d0, d2); }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {                  // positions (2 HALF + a) * 4 + {0, 1, 2, 3}: 3 KB apart
+                char* v = sm + wr_base + VPAR * VB + ((2 * HALF + a) * 4) * 3 * 1024;
+                put(v + 0 * 3072, f4sub(rr[a][0], rr[a][2]));
+                put(v + 1 * 3072, f4add(rr[a][1], rr[a][2]));
+                put(v + 2 * 3072, f4sub(rr[a][2], rr[a][1]));
+                put(v + 3 * 3072, f4sub(rr[a][1], rr[a][3]));
+            }
+            if (--tr_left == 0) {
+                rd0 = nrd0;
+                rd1 = nrd1;
+                rd2 = nrd2;
+                tr_left = nks;
+            }
+        };
+        using P0 = std::integral_constant<unsigned, 0>;
+        using P1 = std::integral_constant<unsigned, 1>;
+        auto run = [&](auto half_tag) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) { rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rvb[i] = rv[i]; }
+            item_geometry(la, roff, nrd0, nrd1, nrd2, rs_in);
+            request_item_data();
+            rd0 = nrd0;
+            rd1 = nrd1;
+            rd2 = nrd2;
+            tr_left = nks;
+            flush_pending();
+            issue_next(rv);
+            issue_next(rvb);
+            store_raw(rv, P0{});
+            __syncthreads();                                  // P
+            transform(P0{}, P0{}, half_tag);
+            store_raw(rvb, P1{});
+            flush_pending();
+            issue_next(rv);
+            __syncthreads();                                  // B_0
+            auto iter = [&](auto par_tag, auto npar_tag) {
+                store_raw(rv, par_tag);
+                flush_pending();
+                issue_next(rv);
+                transform(npar_tag, npar_tag, half_tag);
+                __syncthreads();                              // B_{g+1}
+            };
+            for (int g = 0;;) {
+                if (g >= slices_total) break;
+                iter(P0{}, P1{});
+                if (++g >= slices_total) break;
+                iter(P1{}, P0{});
+                ++g;
+            }
+        };
+        if (t_half == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ U3, int Cout,
+                                                              int Cin, int flip) {
+    const int cop = (Cout + 31) / 32 * 32;
+    const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
+    if (idx >= (int64_t)cop * Cin) return;
+    erd::wino_x3_weight_item(w, U3, Cout, Cin, flip, (int)(idx / Cin), (int)(idx % Cin));
+}
+
 }  // namespace
 
 extern "C" int erd_wino_weights(const float* w_ohwi, float* U, int Cout, int Cin, int flip, erd_stream_t stream) {
@@ -665,14 +1118,16 @@ extern "C" int erd_wino_trace(unsigned long long* out) {       // debug builds o
 
 extern "C" size_t erd_wino_weights_elems(int Cout, int Cin) { return (size_t)16 * ((Cout + 15) / 16 * 16) * Cin; }
 
-extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout,
-                                const float* scale, const float* shift, int relu, float* colsum, int colsum_copies,
-                                int* sched, erd_stream_t stream) {
-    ERD_REQUIRE(segs && U && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
+namespace {
+// the launch both forms share: descriptor (segments, block regions, item count) and the persistent grid
+int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* U3, int Cin, int Cout, const float* scale,
+                const float* shift, int relu, float* colsum, int colsum_copies, int* sched, hipStream_t stream) {
+    ERD_REQUIRE(segs && (U || U3) && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
     ERD_REQUIRE(Cin % KS == 0 && Cin >= 4 * KS && Cout > 0, "wino: Cin=%d must be a multiple of %d and at least %d", Cin, KS, 4 * KS);
     WinoDesc d;
     d.nseg = nseg;
     d.U = U;
+    d.U3 = U3;
     d.Cin = Cin;
     d.Cout = Cout;
     d.scale = scale;
@@ -732,13 +1187,6 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     d.nreg = nreg;
     d.blocks_per_nb = blocks;
     const int ncb = (Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (RAW_LDS_F4 + V_F4) * sizeof(float4) + 2048 + 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_done = true;
-    }
     if (blocks == 0) return 0;
     d.nitems = blocks * ncb;
     int ncu = 0;
@@ -755,6 +1203,48 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
     if (persist != 1) d.sched = nullptr;
-    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, d);
+    if (U3) {
+        const size_t lds = (size_t)2 * RAW_LDS_F4 * sizeof(float4) + 2 * VX_B + 4 * 2 * XCH_B + 64 + 2048 + 16;
+        static bool attr3_done = false;
+        if (!attr3_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr3_done = true;
+        }
+        hipLaunchKernelGGL(wino_x3_kernel, dim3((unsigned)grid), dim3(512), lds, stream, d);
+        return erd::check_launch("wino_conv3x3_x3");
+    }
+    const size_t lds = (size_t)2 * (RAW_LDS_F4 + V_F4) * sizeof(float4) + 2048 + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)grid), dim3(512), lds, stream, d);
     return erd::check_launch("wino_conv3x3");
+}
+}  // namespace
+
+extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin, int Cout,
+                                const float* scale, const float* shift, int relu, float* colsum, int colsum_copies,
+                                int* sched, erd_stream_t stream) {
+    ERD_REQUIRE(U, "wino: null U");
+    return wino_launch(segs, nseg, U, nullptr, Cin, Cout, scale, shift, relu, colsum, colsum_copies, sched, (hipStream_t)stream);
+}
+
+extern "C" size_t erd_wino_weights_x3_elems(int Cout, int Cin) { return (size_t)16 * 3 * ((Cout + 31) / 32 * 32) * Cin; }
+
+extern "C" int erd_wino_weights_x3(const float* w_ohwi, void* U3, int Cout, int Cin, int flip, erd_stream_t stream) {
+    ERD_REQUIRE(w_ohwi && U3 && Cout > 0 && Cin > 0 && Cin % KS == 0, "wino_weights_x3: Cin=%d must be a multiple of %d", Cin, KS);
+    const int64_t n = (int64_t)((Cout + 31) / 32 * 32) * Cin;
+    hipLaunchKernelGGL(wino_weight_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ohwi,
+                       reinterpret_cast<unsigned short*>(U3), Cout, Cin, flip);
+    return erd::check_launch("wino_weights_x3");
+}
+
+extern "C" int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout,
+                                   const float* scale, const float* shift, int relu, float* colsum, int colsum_copies,
+                                   int* sched, erd_stream_t stream) {
+    ERD_REQUIRE(U3, "wino_x3: null U3");
+    return wino_launch(segs, nseg, nullptr, U3, Cin, Cout, scale, shift, relu, colsum, colsum_copies, sched, (hipStream_t)stream);
 }

@@ -117,6 +117,9 @@ class BucketedGradSync:
         self._works: List = []
         self._remaining: List[int] = []
         self.late_buckets = 0            # buckets whose all-reduce had to be issued by wait() (diagnostic)
+        self.missing: List[str] = []     # ... and the parameters that had not reported a gradient by then (last occurrence)
+        self._seen: List[bool] = []
+        self.repeats = set()             # parameters that reported more than once in a step (diagnostic: the contract is once)
         self._warned_late = False
         self._next = 0
         for i, p in enumerate(flat.params):
@@ -126,6 +129,7 @@ class BucketedGradSync:
 
     def arm(self) -> None:
         self._remaining = [len(m) for (_, _, m) in self.flat.buckets]
+        self._seen = [False] * len(self.flat.params)
         self._works = []
         self._next = 0                   # collectives are issued strictly in bucket order: the same order on every rank
 
@@ -144,6 +148,10 @@ class BucketedGradSync:
         def hook(_p):
             if not self._remaining:
                 return
+            if self._seen[i]:            # (one notification per parameter and step: a second one must not drive the countdown
+                self.repeats.add(self.flat.names[i])      # below zero -- the in-order issue loop waits for exactly zero)
+                return
+            self._seen[i] = True
             b = self.flat.bucket_of[i]
             self._remaining[b] -= 1
             # issue every complete bucket at the head of the queue.  A bucket that completes before an earlier one (a
@@ -164,11 +172,13 @@ class BucketedGradSync:
             self._next += 1
         if late:
             self.late_buckets += late
+            self.missing = [self.flat.names[i] for i, seen in enumerate(self._seen) if not seen]
             if not self._warned_late:
                 self._warned_late = True
                 import warnings
                 warnings.warn(f"BucketedGradSync: {late} of {len(self._remaining)} gradient buckets were not complete when backward "
-                              "ended (a parameter without a gradient this step?); their all-reduce was issued late, in bucket order")
+                              "ended (a parameter without a gradient this step?); their all-reduce was issued late, in bucket order.  "
+                              f"Parameters that did not report a gradient: {self.missing[:8]}{' ...' if len(self.missing) > 8 else ''}")
         for w in self._works:
             w.wait()
         self._works = []

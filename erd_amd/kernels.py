@@ -466,39 +466,54 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
 WINOGRAD = _os.environ.get("ERD_WINO", "1") != "0"     # F(2x2,3x3) for the fp32 3x3 stride-1 convolutions (winograd.hip)
 
 
-def wino_weights(w_ohwi: Tensor, flip: bool = False) -> Tensor:
+WINO_X3 = _os.environ.get("ERD_WINO_X3", "1") != "0"      # "f32x3": the Winograd launches on the bf16 matrix cores too (A/B aid: 0)
+
+
+def wino_x3() -> bool:
+    """do the Winograd launches run in the three-limb form (erd_wino_conv3x3_x3)?"""
+    return WINO_X3 and COMPUTE == "f32x3"
+
+
+def wino_weights(w_ohwi: Tensor, flip: bool = False, x3: Optional[bool] = None) -> Tensor:
     """U = G g G^T of a [Cout,3,3,Cin] weight in the layout erd_wino_conv3x3 streams (flip: taps reversed, for the
-    input-gradient form on transposed weights)"""
+    input-gradient form on transposed weights); x3 (default: wino_x3()): the bf16 limb image erd_wino_conv3x3_x3 streams"""
     Cout, kh, kw, Cin = w_ohwi.shape
     assert kh == 3 and kw == 3 and w_ohwi.is_contiguous() and w_ohwi.dtype == torch.float32
+    x3 = wino_x3() if x3 is None else x3
     # forward form: the source is the parameter; gradient form: a prepared transposed weight
     owner = _prep_owner(w_ohwi) if not flip else getattr(w_ohwi, "_erd_prep_owner", None)
     PREP = _prep_of(owner)
     if PREP is None:
         owner = None
-    key = ("UT" if flip else "U", id(owner))
+    key = (("UT" if flip else "U") + ("3" if x3 else ""), id(owner))
     if owner is not None:
         r = PREP.lookup(key)
         if r is not None and r.matches(owner, w_ohwi, None):
             return r.out
-    U = torch.empty(int(_lib.load().erd_wino_weights_elems(Cout, Cin)), dtype=torch.float32, device=w_ohwi.device)
-    call("erd_wino_weights", _p(w_ohwi), _p(U), Cout, Cin, 1 if flip else 0, _stream())
+    if x3:
+        U = torch.empty(int(_lib.load().erd_wino_weights_x3_elems(Cout, Cin)), dtype=torch.bfloat16, device=w_ohwi.device)
+        call("erd_wino_weights_x3", _p(w_ohwi), _p(U), Cout, Cin, 1 if flip else 0, _stream())
+    else:
+        U = torch.empty(int(_lib.load().erd_wino_weights_elems(Cout, Cin)), dtype=torch.float32, device=w_ohwi.device)
+        call("erd_wino_weights", _p(w_ohwi), _p(U), Cout, Cin, 1 if flip else 0, _stream())
     if owner is not None and not torch.cuda.is_current_stream_capturing():
-        PREP.register(key, 2, w_ohwi, None, torch.empty_like(U), Cout, 9, Cin, 1 if flip else 0, owner, 1 if flip else 0)
+        PREP.register(key, 4 if x3 else 2, w_ohwi, None, torch.empty_like(U), Cout, 9, Cin, 1 if flip else 0, owner, 1 if flip else 0)
     return U
 
 
 def _wino_weights_cached(w: Tensor) -> Tensor:
-    """frozen weights: transformed once (cached on the owning parameter, validated by pointer + version);
+    """frozen weights: transformed once (cached on the owning parameter, validated by pointer + version + form);
     trainable ones per use (a 5 us launch)."""
     base = getattr(w, "_erd_owner", None)
     if base is None or base.requires_grad:
         return wino_weights(w)
-    ver = (w.data_ptr(), base._version, tuple(w.shape))
-    hit = getattr(base, "_erd_wino", None)
+    x3 = wino_x3()
+    ver = (w.data_ptr(), base._version, tuple(w.shape), x3)
+    attr = "_erd_wino3" if x3 else "_erd_wino"
+    hit = getattr(base, attr, None)
     if hit is None or hit[0] != ver:
-        hit = (ver, wino_weights(w))
-        base._erd_wino = hit
+        hit = (ver, wino_weights(w, x3=x3))
+        setattr(base, attr, hit)
     return hit[1]
 
 
@@ -568,8 +583,9 @@ def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: 
         _fill_seg(segs[i], x, o, x.shape[1], x.shape[2], None if res is None else res[i], None,
                   None if mask is None else mask[i])
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * 9 * Cin
-    nbytes = 4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U.numel()) if _TIMING is not None else 0.0
-    _timed_call(kname, flop, "erd_wino_conv3x3", segs, len(xs), _p(U), Cin, Cout, _p(scale), _p(shift),
+    nbytes = (4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs)) + U.numel() * U.element_size()) if _TIMING is not None else 0.0
+    # (the form is the weight image's: a bf16 image is the three-limb one)
+    _timed_call(kname, flop, "erd_wino_conv3x3_x3" if U.dtype == torch.bfloat16 else "erd_wino_conv3x3", segs, len(xs), _p(U), Cin, Cout, _p(scale), _p(shift),
                 1 if relu else 0, _p(colsum), (colsum.numel() // Cout if colsum is not None else 0),
                 _p(_wino_sched(U.device)), _stream(), nbytes=nbytes,
                 tag=f"px{sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs)} {Cin}->{Cout} k3s1" if TIMING_DETAIL else "")
@@ -617,6 +633,7 @@ class ParamPrep:
         out._erd_prep_owner = owner
         if key[0] == "T":                       # what was built from the previous transposed buffer is orphaned
             self.recipes.pop(("UT", key[1]), None)
+            self.recipes.pop(("UT3", key[1]), None)
             self.recipes.pop(("XT", key[1]), None)
         self.recipes[key] = r
         self._tables = None
@@ -637,6 +654,7 @@ class ParamPrep:
                 del self.recipes[key]
                 if key[0] == "T":
                     self.recipes.pop(("UT", key[1]), None)
+                    self.recipes.pop(("UT3", key[1]), None)
                     self.recipes.pop(("XT", key[1]), None)
                 self._tables = None
                 self._stale()

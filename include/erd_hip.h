@@ -143,6 +143,16 @@ int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float* U, int Cin
                                    persistent grid; NULL = static split */,
                      erd_stream_t stream);
 
+/* The THREE-LIMB form of the same algorithm (ABI v4; "f32x3"): fp32 maps, accumulation and results, the 16 transform-domain GEMMs on
+ * the bf16 matrix cores (six limb products per fp32 product, v_mfma_f32_32x32x16_bf16).  erd_wino_weights_x3 builds U = G g G^T with
+ * erd_wino_weights' arithmetic and stores its three bf16 limbs as MFMA fragments ([16 positions][3 limbs][ceil(Cout/32)][Cin/16]
+ * [64 lanes][8]: erd_wino_weights_x3_elems bf16 values); erd_wino_conv3x3_x3 takes that image, everything else as
+ * erd_wino_conv3x3 (same item list, epilogue, scheduling counters). */
+size_t erd_wino_weights_x3_elems(int Cout, int Cin);
+int erd_wino_weights_x3(const float* w_ohwi, void* U3, int Cout, int Cin, int flip, erd_stream_t stream);
+int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout, const float* scale,
+                        const float* shift, int relu, float* colsum, int colsum_copies, int* sched, erd_stream_t stream);
+
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
  * Up to ERD_MAX_SEG feature maps that share the weights (the head's five levels) are summed in ONE
@@ -200,8 +210,8 @@ int erd_weight_transpose_x3(const float* w, const float* rowscale, void* dst, in
                             int Cin, int flip, erd_stream_t stream);
 
 /* Many weight transforms in ONE launch: erd_weight_transpose (kind 0), erd_weight_transpose_bf16 (kind 1),
- * erd_wino_weights (kind 2: w is [Cout][3][3][Cin], ntaps = 9, rowscale unused) or erd_split3 (kind 3: the Cout * ntaps * Cin
- * values at w, rowscale / flip unused) per item, same arithmetic.  `items_dev` is a
+ * erd_wino_weights (kind 2: w is [Cout][3][3][Cin], ntaps = 9, rowscale unused), erd_split3 (kind 3: the Cout * ntaps * Cin
+ * values at w, rowscale / flip unused) or erd_wino_weights_x3 (kind 4, as kind 2) per item, same arithmetic.  `items_dev` is a
  * DEVICE array sorted by block0; item i owns blocks [block0, block0 + erd_weight_prep_blocks(kind, Cout, ntaps, Cin)) of the
  * launch, total_blocks is their sum.  Items of one launch must not depend on each other (a Winograd image of a transposed
  * weight goes into a second launch).  The trainer prepares everything the step derives from the parameters alone this

@@ -90,7 +90,7 @@ def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path, H, W, bucket_
         assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])
     res = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(WORLD)]
     for r, d in enumerate(res):
-        assert d["backend"] == "gloo" and d["device"] == 0 and d["late_buckets"] == 0, (r, d["backend"], d["device"], d["late_buckets"])
+        assert d["backend"] == "gloo" and d["device"] == 0 and d["late_buckets"] == 0, (r, d["backend"], d["device"], d["late_buckets"], d["missing"][:12], d["repeats"][:12])
         assert d["lrs"] == pytest.approx(lrs, rel=1e-12)
         assert d["buckets"] >= (4 if bucket_mb == 32 else 20)
     # ---- C2 / C3 ---------------------------------------------------------------------------------------------------------------

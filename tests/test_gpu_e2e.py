@@ -533,6 +533,9 @@ def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
             if r.kind == 2:
                 ref = torch.empty_like(r.out)
                 K.call("erd_wino_weights", K._p(r.src), K._p(ref), r.Cout, r.Cin, r.flip, K._stream())
+            elif r.kind == 4:                     # the Winograd weight image in the three-limb layout ("f32x3")
+                ref = torch.empty_like(r.out)
+                K.call("erd_wino_weights_x3", K._p(r.src), K._p(ref), r.Cout, r.Cin, r.flip, K._stream())
             elif r.kind == 3:                     # the three bf16 limb planes of a weight ("f32x3")
                 ref = torch.empty_like(r.out)
                 K.call("erd_split3", K._p(r.src), K._p(ref), r.src.numel(), K._stream())
@@ -543,8 +546,10 @@ def test_prepared_weight_buffers_equal_the_inline_transforms(mode):
                        r.Cout, r.ntaps, r.Cin, r.flip, K._stream())
             assert torch.equal(ref, r.out), key
         assert kinds.get("T", 0) >= 40, kinds                         # every trainable convolution's transposed weights
-        if mode in ("f32", "f32x3"):
+        if mode == "f32":
             assert kinds.get("U", 0) >= 15 and kinds.get("UT", 0) >= 15, kinds
+        if mode == "f32x3":                                           # (the Winograd launches run in the three-limb form too)
+            assert kinds.get("U3", 0) >= 15 and kinds.get("UT3", 0) >= 15, kinds
         if mode == "f32x3":
             assert kinds.get("X", 0) >= 30 and kinds.get("XT", 0) >= 25, kinds    # the direct launches' limb planes, both forms
         # ... and they are what the wrappers hand out

@@ -63,7 +63,7 @@ def main():
         tr.flush()
         torch.cuda.synchronize()
         params = {n: p.detach().cpu().clone() for n, p in zip(tr.flat.names, tr.flat.params)}
-        torch.save(dict(logs=logs, grad0=grad0, params=params, reduce_mean=seen, late_buckets=tr.sync.late_buckets,
+        torch.save(dict(logs=logs, grad0=grad0, params=params, reduce_mean=seen, late_buckets=tr.sync.late_buckets, missing=list(tr.sync.missing), repeats=sorted(tr.sync.repeats),
                         lrs=[tr.lr_at(i) for i in range(steps)], buckets=len(tr.flat.buckets),
                         backend=dist.get_backend(), device=torch.cuda.current_device()), os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
