@@ -445,8 +445,9 @@ def main():
                  ("r50_40_40", "f32", True): "BASELINE configs[4], per-GPU leg, fp32", ("r50_40_40", "bf16", True): "BASELINE configs[4], per-GPU leg, bf16"}.get(
                      (args.arch, prec, args.mixed_res), "a combination BASELINE.json does not name")
         arithmetic = {"f32x3": "fp32 maps / accumulation / results; the products of the direct implicit-GEMM and weight-gradient launches are formed "
-                               "on the bf16 matrix cores from exact three-limb splits of both fp32 multiplicands (6 of 9 limb products, dropped "
-                               "part < 2^-23 of a product); Winograd F(2x2,3x3) launches on the fp32 matrix cores",
+                               "on the bf16 matrix cores from exact three-limb splits of both fp32 multiplicands (6 of 9 limb products, round-to-nearest limbs: dropped "
+                               "part zero-mean and < 2^-23 of a product); so are the transform-domain products of the Winograd F(2x2,3x3) launches" +
+                               ("" if K.wino_x3() else " -- EXCEPT here: ERD_WINO_X3=0 keeps the Winograd launches on the fp32 matrix cores"),
                       "f32": "fp32 throughout, every GEMM-shaped launch on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                       "bf16": "bf16 matrix cores, bf16-stored maps, fp32 accumulate / statistics / losses"}[args.compute]
         res = "mixed resolution " + "/".join(f"{h}x{w}" for h, w in MIXED_SHAPES) + " (round-robin, each padded to /32)" if args.mixed_res \
@@ -482,8 +483,13 @@ def main():
             peak_tf = BF16_MFMA_PEAK_TFLOPS if args.compute == "bf16" else FP32_MFMA_PEAK_TFLOPS   # every GEMM class follows --compute
             # ---- the dominant KERNEL SYMBOL (rocprof's unit: the Winograd kernel's forward and input-gradient launches are
             # one symbol) and its roofline on the flops it EXECUTES
+            wino_on_bf16 = K.wino_x3()       # "f32x3": the Winograd launches run as wino_x3_kernel (six bf16 limb products per transform-domain product)
+            symbols = dict(SYMBOLS)
+            if wino_on_bf16:
+                symbols["wino_x3_kernel"] = symbols.pop("wino_conv_kernel")
+            wino_sym = "wino_x3_kernel" if wino_on_bf16 else "wino_conv_kernel"
             groups = {}
-            for sym, classes in SYMBOLS.items():
+            for sym, classes in symbols.items():
                 rs = [ktime[c] for c in classes if c in ktime]
                 if rs:
                     groups[sym] = dict(ms=sum(r["ms"] for r in rs), flop=sum(r["flop"] for r in rs), launches=sum(r["launches"] for r in rs),
@@ -493,8 +499,8 @@ def main():
             # form of the direct launches 6 bf16 MFMA flops per fp32 flop on the bf16 pipe
             x3 = args.compute == "f32x3"
             X3_SYMS = ("conv_igemm_kernel", "conv_wgrad_row3_kernel", "conv_wgrad_kernel")      # launch classes that run in the three-limb form
-            execf = WINO_EXECUTED if sym == "wino_conv_kernel" else (6.0 if (x3 and sym in X3_SYMS) else 1.0)
-            if x3 and sym in X3_SYMS:
+            execf = WINO_EXECUTED * (6.0 if wino_on_bf16 else 1.0) if sym == wino_sym else (6.0 if (x3 and sym in X3_SYMS) else 1.0)
+            if (x3 and sym in X3_SYMS) or (sym == wino_sym and wino_on_bf16):
                 peak_tf = BF16_MFMA_PEAK_TFLOPS
             alg_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
             # PMC counters cannot be read from inside this process: `traffic` / `mfma_busy_pmc` are STATIC values from the
@@ -503,10 +509,12 @@ def main():
             pmc_sym = {"conv_wgrad_row3_kernel": "conv_wgrad_row3_x3_kernel<2, 1", "conv_wgrad_kernel": "conv_wgrad_row3_x3_kernel<2, 2"}.get(sym, sym) \
                 if x3 else sym
             traffic, traffic_src = pmc_traffic_per_launch(pmc_sym, args.compute)
-            out["roofline"] = {"bound": "mfma", "kernel": sym, "classes": [c for c in SYMBOLS[sym] if c in ktime],
+            out["roofline"] = {"bound": "mfma", "kernel": sym, "classes": [c for c in symbols[sym] if c in ktime],
                                "achieved": round(alg_tf * execf, 2), "peak": peak_tf, "unit": "TFLOP/s",
                                "frac": round(alg_tf * execf / peak_tf, 4),
                                "basis": "flops the kernel executes on the matrix cores" + (
+                                   " (Winograd F(2x2,3x3): 16/36 of the direct-convolution count, x 6 bf16 limb products per product, against the bf16 MFMA peak)"
+                                   if (sym == wino_sym and wino_on_bf16) else
                                    " (Winograd F(2x2,3x3): 16/36 of the direct-convolution count)" if execf < 1 else (
                                        " (six bf16 limb products per fp32 product, against the bf16 MFMA peak)" if execf > 1 else " (= the direct-convolution count)")),
                                "algorithmic_tflops": round(alg_tf, 2), "executed_flop_fraction": round(execf, 4),
@@ -523,8 +531,8 @@ def main():
             # numbers of this run + the committed PMC passes (static, labelled); everything needed to recompute a fraction is in the row
             per_kernel = {}
             for ksym, g in groups.items():
-                on_bf16 = args.compute == "bf16" or (x3 and ksym in X3_SYMS)
-                k_exec = WINO_EXECUTED if ksym == "wino_conv_kernel" else (6.0 if (x3 and ksym in X3_SYMS) else 1.0)
+                on_bf16 = args.compute == "bf16" or (x3 and ksym in X3_SYMS) or (ksym == wino_sym and wino_on_bf16)
+                k_exec = WINO_EXECUTED * (6.0 if wino_on_bf16 else 1.0) if ksym == wino_sym else (6.0 if (x3 and ksym in X3_SYMS) else 1.0)
                 k_peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
                 k_alg = g["flop"] / (g["ms"] * 1e-3) / 1e12
                 k_us = 1e3 * g["ms"] / g["launches"]
@@ -563,7 +571,11 @@ def main():
             wino_alg = per_step(SYMBOLS["wino_conv_kernel"])
             igemm_alg = sum(per_step(SYMBOLS[k_]) for k_ in X3_SYMS) if x3 else 0.0      # (every three-limb class, not only the implicit GEMM)
             exec_gflop_step = args.batch * (g_img - skipped) - wino_alg * (1.0 - WINO_EXECUTED)
-            pipe_s = ((exec_gflop_step - igemm_alg) / step_peak + igemm_alg * 6.0 / BF16_MFMA_PEAK_TFLOPS) * 1e-3
+            wino_exec = wino_alg * WINO_EXECUTED                                          # Winograd-executed GFLOP per step
+            if wino_on_bf16:     # ... which run as six limb products on the bf16 pipe
+                pipe_s = ((exec_gflop_step - igemm_alg - wino_exec) / step_peak + (igemm_alg + wino_exec) * 6.0 / BF16_MFMA_PEAK_TFLOPS) * 1e-3
+            else:
+                pipe_s = ((exec_gflop_step - igemm_alg) / step_peak + igemm_alg * 6.0 / BF16_MFMA_PEAK_TFLOPS) * 1e-3
             out["roofline"]["step_gflop_per_image"] = round(g_img, 1)
             out["roofline"]["step_tflops"] = round(args.batch * g_img / step_s / 1e3, 2)
             out["roofline"]["step_frac"] = round(out["roofline"]["step_tflops"] / step_peak, 4)
@@ -571,7 +583,8 @@ def main():
             out["roofline"]["mfma_executed_frac"] = round(pipe_s / step_s, 4)
             out["roofline"]["mfma_executed_gflop_per_step"] = round(exec_gflop_step, 1)
             if x3:
-                out["roofline"]["three_limb_gflop_per_step"] = round(igemm_alg, 1)
+                out["roofline"]["three_limb_gflop_per_step"] = round(igemm_alg + (wino_exec if wino_on_bf16 else 0.0), 1)
+                out["roofline"]["winograd_on_bf16_pipe"] = bool(wino_on_bf16)
             out["kernels"] = {k: {"ms_per_step": round(r["ms"] / rsteps, 3),
                                   "tflops": round(r["flop"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flop"] else None,
                                   "launches_per_step": r["launches"] // rsteps} for k, r in ktime.items()}

@@ -669,6 +669,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
 //     re-loaded four positions ahead.
 // Everything else -- item list, block shapes, raw staging, look-ahead, the single barrier per slice -- is the fp32 kernel's.
 constexpr int VX_B = 16 * 3 * 1024;            // bytes of one V buffer (three-limb form)
+#ifndef ERD_WX3_RD
+#define ERD_WX3_RD 4                          // weight-fragment ring depth in positions (4: half a slice ahead; 8: a whole slice)
+#endif
 constexpr int XCH_B = 1024;                    // bytes of one exchange chunk (4 registers x 64 lanes)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -739,17 +742,19 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
 
         WinoItem cur = decode(item0);
         int k_item = 0;
+        unsigned long long t_bar = 0, t_out = 0, t_xch = 0; (void)t_bar; (void)t_out; (void)t_xch;
+        ERD_T0(t_begin);
         unsigned u_item = (unsigned)__builtin_amdgcn_readfirstlane(((cur.cout0 >> 5) + cb) * nks * 1024);   // byte offset of (cout block, ks = 0) inside a plane
         f32x16 acc[8];
-        u32x4 ub[4][3];                                                             // weight-fragment ring: position q lives in slot q & 3
+        u32x4 ub[ERD_WX3_RD][3];                                                             // weight-fragment ring: position q lives in slot q mod ERD_WX3_RD
         bf16x8 vf[2][3];                                                            // tile fragments [position parity][limb]
         auto load_u = [&](const int q, const unsigned soff) {                      // q: compile-time after unrolling
 #pragma unroll
             for (int l = 0; l < 3; ++l)
-                ub[q & 3][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)(q * 3 + l) * per_xl_b + soff, 0);
+                ub[q & (ERD_WX3_RD - 1)][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)(q * 3 + l) * per_xl_b + soff, 0);
         };
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_u(q, u_item);
+        for (int q = 0; q < ERD_WX3_RD; ++q) load_u(q, u_item);
         __syncthreads();                                    // P   (data waves: raw slice 0 is in LDS)
         __syncthreads();                                    // B_0 (V(0) complete)
 #pragma unroll
@@ -775,29 +780,39 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (q == 7) {                           // B_{g+1}: V(g+1) complete; every read of V(g) has been issued
+                        ERD_T0(tb);
                         __syncthreads();
+                        ERD_TACC(t_bar, tb);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     const char* src = q < 7 ? vc + (q + 1) * 3 * 1024 : vn;
 #pragma unroll
                     for (int l = 0; l < 3; ++l) vf[(q + 1) & 1][l] = *reinterpret_cast<const bf16x8*>(src + l * 1024);
                     __builtin_amdgcn_sched_barrier(0);      // reads first: they travel behind this position's MFMAs
-                    const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[q & 3][0]), um = __builtin_bit_cast(bf16x8, ub[q & 3][1]),
-                                 ul = __builtin_bit_cast(bf16x8, ub[q & 3][2]);
+                    const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[q & (ERD_WX3_RD - 1)][0]), um = __builtin_bit_cast(bf16x8, ub[q & (ERD_WX3_RD - 1)][1]),
+                                 ul = __builtin_bit_cast(bf16x8, ub[q & (ERD_WX3_RD - 1)][2]);
                     const bf16x8 vh = vf[q & 1][0], vm = vf[q & 1][1], vl = vf[q & 1][2];
                     // rows = couts (U), columns = tiles (V); smallest terms first, as everywhere in the three-limb kernels
+#ifdef ERD_WX3_NOMFMA       // timing probe: everything but the matrix instructions (results are wrong)
+                    acc[q][0] += __builtin_bit_cast(float4, ul).x * __builtin_bit_cast(float4, vh).x + __builtin_bit_cast(float4, um).x * __builtin_bit_cast(float4, vm).x +
+                                 __builtin_bit_cast(float4, uh).x * __builtin_bit_cast(float4, vl).x;
+#else
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[q], 0, 0, 0);
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[q], 0, 0, 0);
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[q], 0, 0, 0);
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[q], 0, 0, 0);
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[q], 0, 0, 0);
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[q], 0, 0, 0);
+#endif
                     // the slot is free: position q + 4 of this slice, or position q - 4 of the next one
-                    if (q < 4) load_u(q + 4, u_cur); else load_u(q - 4, u_reload);
+#ifndef ERD_WX3_NOLOAD      // (timing probe: the ring keeps the first slice's fragments)
+                    if (q + ERD_WX3_RD < 8) load_u(q + ERD_WX3_RD, u_cur); else load_u(q + ERD_WX3_RD - 8, u_reload);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- output stage: z[i][c] = (M A)[i][c] for this wave's two rows, one row swapped with the partner wave, y = A^T z
+            ERD_T0(to);
             {
                 const WinoSeg& sg = p.seg[cur.s];
                 const float* ss = sh_ss + (k_item & 3) * 128;
@@ -829,7 +844,9 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
                         *reinterpret_cast<float4*>(mine) = s4;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         if (lane == 0) xflag[wave] = xr + 1;
+                        ERD_T0(tx);
                         while (xflag[wave ^ 1] < xr + 1) __builtin_amdgcn_s_sleep(1);
+                        ERD_TACC(t_xch, tx);
                         const float4 r0 = *reinterpret_cast<const float4*>(xpartner + (xr & 1) * XCH_B);
                         recv[4 * qr + 0] = r0.x; recv[4 * qr + 1] = r0.y; recv[4 * qr + 2] = r0.z; recv[4 * qr + 3] = r0.w;
                         ++xr;
@@ -899,7 +916,16 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
                     }
                 }
             }
+            ERD_TACC(t_out, to);
             if (!has_next) {
+#ifdef ERD_WINO_TRACE
+                if (wave == 0 && lane == 0 && blockIdx.x < 256) {
+                    g_wino_trace[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
+                    g_wino_trace[blockIdx.x * 8 + 1] = t_bar;
+                    g_wino_trace[blockIdx.x * 8 + 2] = t_out;
+                    g_wino_trace[blockIdx.x * 8 + 3] = t_xch;             // (x3: the exchange polls inside the output stage, not the item count)
+                }
+#endif
                 if (wave == 0 && lane == 0 && p.sched) {     // the last workgroup to leave re-arms the counters
                     if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
                 }
@@ -916,6 +942,8 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
         const int dt = tid & 255;
         const int t_chunk = dt & 3, t_tile = (dt >> 2) & 31, t_half = __builtin_amdgcn_readfirstlane(dt >> 7);
         WinoItem la = decode(item0);
+        unsigned long long t_bar = 0, t_ent = 0, t_wait = 0; (void)t_bar; (void)t_ent; (void)t_wait;
+        ERD_T0(t_begin);
         int la_ks = 0, k_la = 0;
         unsigned la_soff = 0;
         bool la_valid = true;
@@ -1014,24 +1042,47 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
         };
         auto put = [&](char* dst, const float4 v) {        // four channels of one position -> three limb words of 8 bytes
             uint2 hi, mid, lo;
+#ifdef ERD_WX3_NOSPLIT      // timing probe (tools/build_probe.sh): what the limb split costs the data waves (results are wrong)
+            hi.x = __builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u);
+            hi.y = __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u);
+            mid = hi; lo = hi;
+#else
             erd::limbs3_pair(v.x, v.y, hi.x, mid.x, lo.x);
             erd::limbs3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+#endif
             *reinterpret_cast<uint2*>(dst) = hi;
             *reinterpret_cast<uint2*>(dst + 1024) = mid;
             *reinterpret_cast<uint2*>(dst + 2048) = lo;
         };
-        auto transform = [&](auto rpar_tag, auto vpar_tag, auto half_tag) {
-            constexpr unsigned RPAR = decltype(rpar_tag)::value, VPAR = decltype(vpar_tag)::value;
-            constexpr int HALF = decltype(half_tag)::value;
+        // the transform in two halves so that its 12 LDS reads can be issued BEFORE the raw store / next loads of the same
+        // iteration (they touch the other raw buffer) and travel under them: (1) the patch rows of this thread's (tile, 4 channels)
+        float4 pd[3][4];
+        auto transform_read = [&](auto rpar_tag) {
+            constexpr unsigned RPAR = decltype(rpar_tag)::value;
             const char* r0 = sm + RPAR * RAWB + rd0;
             const char* r1 = sm + RPAR * RAWB + rd1;
             const char* r2 = sm + RPAR * RAWB + rd2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                pd[0][c] = *reinterpret_cast<const float4*>(r0 + c * (RCS * 16));
+                pd[1][c] = *reinterpret_cast<const float4*>(r1 + c * (RCS * 16));
+                pd[2][c] = *reinterpret_cast<const float4*>(r2 + c * (RCS * 16));
+            }
+            if (--tr_left == 0) {                             // the next slice belongs to the item the pointer entered last
+                rd0 = nrd0;
+                rd1 = nrd1;
+                rd2 = nrd2;
+                tr_left = nks;
+            }
+        };
+        // (2) rows (2 HALF, 2 HALF + 1) of B^T d B, split into limbs, into V buffer VPAR
+        auto transform_write = [&](auto vpar_tag, auto half_tag) {
+            constexpr unsigned VPAR = decltype(vpar_tag)::value;
+            constexpr int HALF = decltype(half_tag)::value;
             float4 rr[2][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 d0 = *reinterpret_cast<const float4*>(r0 + c * (RCS * 16));
-                const float4 d1 = *reinterpret_cast<const float4*>(r1 + c * (RCS * 16));
-                const float4 d2 = *reinterpret_cast<const float4*>(r2 + c * (RCS * 16));
+                const float4 d0 = pd[0][c], d1 = pd[1][c], d2 = pd[2][c];
                 if (HALF == 0) { rr[0][c] = f4sub(d0, d2); rr[1][c] = f4add(d1, d2); }
                 else           { rr[0][c] = f4sub(d1, d0); rr[1][c] = f4sub(d0, d2); }
             }
@@ -1042,12 +1093,6 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
                 put(v + 1 * 3072, f4add(rr[a][1], rr[a][2]));
                 put(v + 2 * 3072, f4sub(rr[a][2], rr[a][1]));
                 put(v + 3 * 3072, f4sub(rr[a][1], rr[a][3]));
-            }
-            if (--tr_left == 0) {
-                rd0 = nrd0;
-                rd1 = nrd1;
-                rd2 = nrd2;
-                tr_left = nks;
             }
         };
         using P0 = std::integral_constant<unsigned, 0>;
@@ -1066,17 +1111,29 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
             issue_next(rvb);
             store_raw(rv, P0{});
             __syncthreads();                                  // P
-            transform(P0{}, P0{}, half_tag);
+            transform_read(P0{});
+            transform_write(P0{}, half_tag);
             store_raw(rvb, P1{});
             flush_pending();
             issue_next(rv);
             __syncthreads();                                  // B_0
             auto iter = [&](auto par_tag, auto npar_tag) {
+                ERD_T0(ts);
+                transform_read(npar_tag);                     // raw(g+1): requested first, consumed after the store / issue below
+                __builtin_amdgcn_sched_barrier(0);
                 store_raw(rv, par_tag);
                 flush_pending();
                 issue_next(rv);
-                transform(npar_tag, npar_tag, half_tag);
+                ERD_TACC(t_ent, ts);
+                ERD_T0(tt);
+                transform_write(npar_tag, half_tag);
+#ifdef ERD_WINO_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                ERD_TACC(t_wait, tt);
+                ERD_T0(tb);
                 __syncthreads();                              // B_{g+1}
+                ERD_TACC(t_bar, tb);
             };
             for (int g = 0;;) {
                 if (g >= slices_total) break;
@@ -1088,6 +1145,14 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
         };
         if (t_half == 0) run(std::integral_constant<int, 0>{});
         else run(std::integral_constant<int, 1>{});
+#ifdef ERD_WINO_TRACE
+        if (wave == 0 && lane == 0 && blockIdx.x < 256) {
+            g_wino_trace[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime() - t_begin;
+            g_wino_trace[blockIdx.x * 8 + 5] = t_bar;
+            g_wino_trace[blockIdx.x * 8 + 6] = t_ent;
+            g_wino_trace[blockIdx.x * 8 + 7] = t_wait;
+        }
+#endif
     }
 }
 

@@ -22,5 +22,7 @@ for name, Cin, Cout, sizes in [("head tower", 256, 256, sizes_of(800, 1344)), ("
     rc = lib.erd_wino_trace(buf)
     t = np.array(buf[:], dtype=np.float64).reshape(256, 8)
     m = t.mean(0)
-    print(f"{name}: MMA wave: total {m[0]:.0f} cyc, barrier wait {m[1]:.0f} ({m[1]/m[0]:.1%}), output stage {m[2]:.0f} ({m[2]/m[0]:.1%}), items {m[3]:.1f} | "
+    x3 = U.dtype == torch.bfloat16      # (three-limb kernel: slot 3 holds the cycles spent polling the partner wave's exchange flag)
+    print(f"{name} ({'three-limb' if x3 else 'fp32'}): MMA wave: total {m[0]:.0f} cyc, barrier wait {m[1]:.0f} ({m[1]/m[0]:.1%}), output stage {m[2]:.0f} ({m[2]/m[0]:.1%}), "
+          f"{'exchange polls' if x3 else 'items'} {m[3]:.1f} | "
           f"data wave: total {m[4]:.0f}, barrier wait {m[5]:.0f} ({m[5]/m[4]:.1%}), store+issue {m[6]:.0f} ({m[6]/m[4]:.1%}), transform {m[7]:.0f} ({m[7]/m[4]:.1%})")
