@@ -109,18 +109,20 @@ def test_full_size_gradients_anchored_to_fp64(nets):
     flip moves every gradient tensor upstream by ~1e-3 and a small-norm one (a BN bias gradient: a sum over a map with heavy
     cancellation) by up to 1e-2.  Which implementation owns a flip on a given seed is chance, and the distribution is
     heavy-tailed -- twelve seeds cannot tell chance from a 20 % shift.  The statistics that CAN are in
-    profiles/r04_parity_seeds.json (tools/parity_seeds.py: 48 seeds, 7-54, same evaluation; tests/test_parity_seeds_profile.py
-    asserts what this docstring quotes from it).  Whole-gradient distance to fp64 over the 48 seeds:
+    profiles/r04_parity_seeds.json (tools/parity_seeds.py: 144 seeds, 7-150, same evaluation; tests/test_parity_seeds_profile.py
+    asserts what this docstring quotes from it).  Whole-gradient distance to fp64 over the 144 seeds:
                                    mean +- s.e.m.        median     seeds > 1e-3   worst seed
-        cpu fp32 (the reference)   9.6e-4 +- 1.7e-4      5.8e-4     10             6.3e-3
-        hip "f32" (fp32 MFMA)      6.1e-4 +- 0.7e-4      4.9e-4      6             2.8e-3
-        hip "f32x3" (default)      7.1e-4 +- 0.9e-4      4.4e-4     10             2.9e-3
-        (round 3's truncating limbs 8.6e-4 +- 1.3e-4     6.3e-4     11             4.6e-3: the round-to-nearest split is the closer)
-    Both HIP forms are closer to fp64 than the reference's own arithmetic; between the two the paired difference over the 48
-    seeds is +1.0e-4 +- 0.7e-4 (1.3 standard errors; the median favours the three-limb form): not distinguishable.  On random
-    12-seed subsets of those 48 the ratio of the two forms' means ranges from 0.6 to 2.4 (90th percentile 1.48), and the
-    three-limb form has more than one seed above 1e-3 beyond the reference's count on 11 % of the subsets -- so the assertions
-    here, on the PINNED seeds 7-18, are (values measured on these seeds in brackets):
+        cpu fp32 (the reference)   9.2e-4 +- 1.4e-4      5.7e-4     27             1.8e-2
+        hip "f32" (fp32 MFMA)      6.5e-4 +- 0.4e-4      5.1e-4     26             2.8e-3
+        hip "f32x3" (default)      7.3e-4 +- 0.7e-4      5.1e-4     26             5.3e-3
+        (seeds 7-54 also with round 3's truncating limbs: 8.6e-4 against 7.1e-4 for the round-to-nearest split on the same seeds,
+         and with all NINE limb products: 8.7e-4 -- the more exact form reads further: profiles/r04_nine_products.txt)
+    Both HIP forms are closer to fp64 than the reference's own arithmetic; between the two the paired difference over the 144
+    seeds is +0.8e-4 +- 0.5e-4 (1.5 standard errors; the medians are equal): not distinguishable.  On random 12-seed subsets of
+    the first 48 seeds the ratio of the two forms' means ranges from 0.6 to 2.4 (90th percentile 1.48), and the three-limb form
+    has more than one seed above 1e-3 beyond the reference's count on 11 % of the subsets -- so the assertions here, on the
+    PINNED seeds 7-18, are (values measured on these seeds with the direct launches' limb split alone in brackets; the Winograd
+    launches have since joined the three-limb form, which redraws the lottery of which ReLU flips on which seed):
       A. every seed, both forms: losses within 1e-3 of the fp32 reference and of fp64.
          "f32": the whole gradient within 1e-3 of fp64 on EVERY seed -- the original bound [worst 8.9e-4].
          "f32x3": its own, named bound: the number of seeds above 1e-3 at most the reference's own count + 1 [1 vs 1], no seed

@@ -1,4 +1,5 @@
-// Issue rate of the VALU instructions the limb split is made of (gfx950): cycles per wave-instruction, one wave per SIMD.
+// Issue rate of the VALU instructions the limb split is made of (gfx950): cycles per wave-instruction with 1 / 2 / 4 waves per SIMD
+// (1024 workgroups of 64 / 128 / 256 threads = four workgroups per CU; thread 0 of each workgroup times its own wave).
 //   hipcc --offload-arch=gfx950 -O3 -w tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -6,7 +7,7 @@ typedef __bf16 b2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int KIND>
-__global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, int iters) {
+__global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, int iters) {
     float a[8], b[8];
     unsigned u[8];
     f2 p[8];
@@ -35,12 +36,17 @@ void run(const char* name) {
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 4); hipMalloc(&cyc, 8 * 1024);
     const int iters = 4096;
-    hipLaunchKernelGGL(k<KIND>, dim3(1024), dim3(64), 0, 0, out, cyc, iters);
-    hipDeviceSynchronize();
-    unsigned long long h[1024];
-    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
-    double m = 0; for (int i = 0; i < 1024; ++i) m += h[i];
-    printf("%-22s %6.2f shader cycles per wave-instruction (one wave per SIMD, 8 independent chains)\n", name, m / 1024 / (iters * 8.0));
+    printf("%-22s", name);
+    for (int waves = 1; waves <= 4; waves *= 2) {       // waves per SIMD: workgroups of 64 x waves threads, four per CU
+        hipLaunchKernelGGL(k<KIND>, dim3(1024), dim3(64 * waves), 0, 0, out, cyc, iters);
+        hipDeviceSynchronize();
+        unsigned long long h[1024];
+        hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+        double m = 0; for (int i = 0; i < 1024; ++i) m += h[i];
+        const double per = m / 1024 / (iters * 8.0);
+        printf("  %d wave%s/SIMD: %5.2f cycles per instruction of a wave (%4.2f per SIMD)", waves, waves > 1 ? "s" : " ", per, per / waves);
+    }
+    printf("\n");
 }
 int main() {
     run<2>("v_sub_f32"); run<3>("v_pk_add_f32"); run<0>("v_cvt_pk_bf16_f32"); run<1>("v_perm_b32"); run<4>("v_lshlrev_b32"); run<5>("v_and_b32");
