@@ -1156,432 +1156,6 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
     }
 }
 
-// =====================================================================================================================
-// The three-limb form with EIGHT HYBRID waves (the default): every wave moves data AND multiplies.
-// Why: tools/valu_rate.hip -- a lone wave on a SIMD issues one VALU instruction every ~8 cycles, not every 4; the four data
-// waves of wino_x3_kernel (one per SIMD, ~290 instructions per slice for transform + limb split) are the critical path at
-// ~3 200 busy cycles per slice while its matrix waves wait a third of the time (profiles/r04_wino_x3_trace.txt).  With the
-// matrix work at 1 536 cycles per wave and slice the balance is two waves per SIMD that EACH do half of both jobs:
-//   * wave w: cout block cb = w >> 2 (32 couts), transform row i = w & 3 (positions 4 i .. 4 i + 3): 4 x 16 = 64 accumulator
-//     registers, a weight-fragment ring of 4 positions x 3 limbs that is a FULL slice deep (the four-position ring of the
-//     role-split kernel was half a slice);
-//   * data: thread t handles (tile (t >> 2) & 31, channels 4 (t & 3) .., transform row t >> 7): two patch rows from the raw
-//     slice (8 LDS reads), row pass, column pass, limb split, 12 eight-byte stores -- a quarter of it placed behind each
-//     position's six MFMAs, so the VALU work runs while the matrix pipe executes them;
-//   * raw staging: 2 x 16 bytes per thread and slice, 208 pixel slots (the largest patch, 6 x 34, needs 204);
-//   * output: z[i][c] = (M A)[i][c] is local to a wave; y[a][c] = (A^T z)[a][c] needs three rows: wave i finishes (a, c) =
-//     (i >> 1, i & 1) from its own z and two others', published in chunks of four registers through LDS (double-buffered, one
-//     flag per wave, a four-wave rendezvous per round: write, raise the flag, wait for the other three, read);
-//   * one workgroup barrier per slice, as before; item claims, staged item entry, scale / shift slices: wino_conv_kernel's.
-// Summation order of y: the fp32 kernel's ((z0 + z1) + z2, (z1 - z2) - z3).
-constexpr int HPIX = 208;
-
-__global__ __launch_bounds__(512, 2) void wino_x3h_kernel(const WinoDesc p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: raw0 | raw1 (2 x [HPIX][RCS] float4) | V0 | V1 (2 x VX_B) | exchange [8 waves][2][XCH_B] | flags [8] | sh_ss [4][128] | sh_item [2]
-    constexpr unsigned RAWB = HPIX * RCS * 16, VOFF = 2 * RAWB, VB = VX_B, XOFF = VOFF + 2 * VB;
-    volatile int* xflag = reinterpret_cast<volatile int*>(smem + XOFF + 8 * 2 * XCH_B);
-    float* sh_ss = reinterpret_cast<float*>(smem + XOFF + 8 * 2 * XCH_B + 64);
-    int* sh_item = reinterpret_cast<int*>(sh_ss + 512);
-    char* const sm = smem;
-
-    const int tid = threadIdx.x;
-    const int Cin = p.Cin;
-    const int nks = Cin / KS;
-    const int nitems = p.nitems;
-    const int ncb32 = (p.Cout + 31) / 32;
-
-    auto decode = [&](int item) {
-        WinoItem it;
-        const int nb = item / p.blocks_per_nb;
-        int b = item - nb * p.blocks_per_nb;
-        int r = 0;
-        while (r + 1 < p.nreg && b >= p.reg[r + 1].block0) ++r;
-        const WinoRegion& rg = p.reg[r];
-        b -= rg.block0;
-        const int per_img = rg.nby * rg.nbx;
-        const int n = b / per_img;
-        const int rem = b - n * per_img;
-        const int by = rem / rg.nbx, bx = rem - by * rg.nbx;
-        const int lbw = rg.lbw;
-        it.s = __builtin_amdgcn_readfirstlane(rg.seg);
-        it.n = __builtin_amdgcn_readfirstlane(n);
-        it.y0 = __builtin_amdgcn_readfirstlane(2 * (rg.ty0 + by * (32 >> lbw)));
-        it.x0 = __builtin_amdgcn_readfirstlane(2 * (rg.tx0 + (bx << lbw)));
-        it.cout0 = __builtin_amdgcn_readfirstlane(nb * BN);
-        it.lbw = __builtin_amdgcn_readfirstlane(lbw);
-        it.yl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].H, 2 * rg.ty1));
-        it.xl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].W, 2 * rg.tx1));
-        return it;
-    };
-    auto claim = [&](int k) -> int {
-        return p.sched ? (int)gridDim.x + atomicAdd(p.sched, 1) : (int)blockIdx.x + (k + 1) * (int)gridDim.x;
-    };
-
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int item0 = blockIdx.x;
-    if (item0 >= nitems) return;
-    if (tid < 8) xflag[tid] = 0;
-
-    // ---- roles -----------------------------------------------------------------------------------------------------------
-    const int li = lane & 31, h = lane >> 5;
-    const int cb = wave >> 2, ri = wave & 3;                         // matrix work: cout block, transform row
-    const int t_chunk = tid & 3, t_tile = (tid >> 2) & 31;          // data work: (tile, 4 channels) ...
-    const int t_row = __builtin_amdgcn_readfirstlane(tid >> 7);     // ... and transform row (uniform per wave)
-    // row pass of B^T d B: R = d[A] + sgn d[B] with (A, B, sgn) = (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -)
-    const int rowA = t_row == 0 ? 0 : (t_row == 2 ? 2 : 1), rowB = t_row == 2 ? 1 : (t_row == 3 ? 3 : 2);
-    const float sgn = t_row == 1 ? 1.f : -1.f;
-
-    // ---- matrix side state ------------------------------------------------------------------------------------------------
-    const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.U3), 0, (int)((size_t)16 * 3 * ncb32 * nks * 1024), 0x00020000);
-    const unsigned u_lane = (unsigned)lane * 16u;
-    const unsigned per_xl_b = (unsigned)ncb32 * (unsigned)nks * 1024u;
-    const unsigned pos0_b = (unsigned)(ri * 4 * 3) * per_xl_b;
-    const unsigned v_lane = (unsigned)(ri * 4 * 3 * 1024 + li * 32 + h * 16);
-    char* const xmy = smem + XOFF + wave * 2 * XCH_B + lane * 16;
-    int xr = 0;
-    WinoItem cur = decode(item0);
-    int k_item = 0;
-    unsigned u_item = (unsigned)__builtin_amdgcn_readfirstlane(((cur.cout0 >> 5) + cb) * nks * 1024);
-    f32x16 acc[4];
-    u32x4 ub[4][3];
-    bf16x8 vf[2][3];
-    auto load_u = [&](const int j, const unsigned soff) {
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-            ub[j][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)(j * 3 + l) * per_xl_b + soff, 0);
-    };
-
-    // ---- data side state (wino_conv_kernel's data waves, on 512 threads) --------------------------------------------------
-    WinoItem la = cur;                                   // the item of the look-ahead pointer (3 slices ahead of the matrix slice)
-    int la_ks = 0, k_la = 0;
-    unsigned la_soff = 0;
-    bool la_valid = true;
-    unsigned roff[2];
-    float4 rv[2], rvb[2];
-    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0].in), 0, 0, 0x00020000);
-    float pend_sc = 1.f, pend_sh = 0.f;
-    int pend_claim = 0, pend_k = -1;
-    unsigned rdA = 0, rdB = 0, nrdA = 0, nrdB = 0;
-    int tr_left = 0;
-    WinoItem nx_it = la;
-    bool nx_valid = false;
-    unsigned nx_roff[2], nx_rdA = 0, nx_rdB = 0;
-    __amdgpu_buffer_rsrc_t nx_rs = rs_in;
-    auto item_geometry = [&](const WinoItem& it, unsigned (&ro)[2], unsigned& gA, unsigned& gB, __amdgpu_buffer_rsrc_t& rs) {
-        const WinoSeg& sg = p.seg[it.s];
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
-        const int lbw = it.lbw, bw = 1 << lbw, bh = 32 >> lbw;
-        const int pc_n = 2 * bw + 2, npix = (2 * bh + 2) * pc_n;
-        const int recip = (65536 + pc_n - 1) / pc_n;
-        const unsigned base_n = (unsigned)(it.n * sg.in_nstride);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 512 * i;
-            const int chunk = idx & 3, pix = idx >> 2;
-            const int pr = (pix * recip) >> 16, pc = pix - pr * pc_n;
-            const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
-            ro[i] = OOBV;
-            if (pix < npix && (unsigned)iy < (unsigned)sg.H && (unsigned)ix < (unsigned)sg.W)
-                ro[i] = (base_n + (unsigned)((iy * sg.W + ix) * Cin + chunk * 4)) * 4u;
-        }
-        const int t_ty = t_tile >> lbw, t_tx = t_tile & (bw - 1);
-        gA = (unsigned)((((2 * t_ty + rowA) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
-        gB = (unsigned)((((2 * t_ty + rowB) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
-    };
-    auto request_item_data = [&]() {
-        if (tid < 64) {
-            const int co = la.cout0 + tid;
-            pend_sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
-            pend_sh = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
-        }
-        if (tid == 64) pend_claim = claim(k_la);
-        pend_k = k_la;
-    };
-    auto flush_pending = [&]() {
-        if (pend_k >= 0) {
-            if (tid < 64) {
-                float* ss = sh_ss + (pend_k & 3) * 128;
-                ss[tid] = pend_sc;
-                ss[64 + tid] = pend_sh;
-            }
-            if (tid == 64) sh_item[(pend_k + 1) & 1] = pend_claim;
-            pend_k = -1;
-        }
-    };
-    auto issue_next = [&](float4* dst) {
-        if (la_valid) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
-            la_soff += KS * 4;
-            ++la_ks;
-            if (la_ks == 3) {                             // stage 1: which item comes next
-                const int nx = __builtin_amdgcn_readfirstlane(sh_item[(k_la + 1) & 1]);
-                nx_valid = nx < nitems;
-                if (nx_valid) nx_it = decode(nx);
-            }
-            if (la_ks == 4 && nx_valid) item_geometry(nx_it, nx_roff, nx_rdA, nx_rdB, nx_rs);    // stage 2
-            if (la_ks == nks) {                           // the pointer leaves item k_la
-                if (nx_valid) {
-                    la = nx_it;
-                    rs_in = nx_rs;
-                    roff[0] = nx_roff[0]; roff[1] = nx_roff[1];
-                    nrdA = nx_rdA; nrdB = nx_rdB;
-                    la_ks = 0;
-                    la_soff = 0;
-                    ++k_la;
-                    request_item_data();
-                } else la_valid = false;
-            }
-        }
-    };
-    const unsigned st_base = (unsigned)(((tid >> 2) * RCS + (tid & 3)) * 16);      // pixel tid >> 2 (+ 128 for the second chunk)
-    const bool st1_ok = (tid >> 2) + 128 < HPIX;
-    auto store_raw = [&](const float4* src, const unsigned par) {
-        *reinterpret_cast<float4*>(sm + par * RAWB + st_base) = src[0];
-        if (st1_ok) *reinterpret_cast<float4*>(sm + par * RAWB + st_base + 128 * RCS * 16) = src[1];
-    };
-    float4 pd[2][4];
-    auto transform_read = [&](const unsigned rpar) {
-        const char* rA = sm + rpar * RAWB + rdA;
-        const char* rB = sm + rpar * RAWB + rdB;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            pd[0][c] = *reinterpret_cast<const float4*>(rA + c * (RCS * 16));
-            pd[1][c] = *reinterpret_cast<const float4*>(rB + c * (RCS * 16));
-        }
-        if (--tr_left == 0) {
-            rdA = nrdA;
-            rdB = nrdB;
-            tr_left = nks;
-        }
-    };
-    const unsigned wr_base = VOFF + (unsigned)(t_row * 4 * 3 * 1024 + t_tile * 32 + t_chunk * 8);
-    auto put = [&](char* dst, const float4 v) {
-        uint2 hi, mid, lo;
-        erd::limbs3_pair(v.x, v.y, hi.x, mid.x, lo.x);
-        erd::limbs3_pair(v.z, v.w, hi.y, mid.y, lo.y);
-        *reinterpret_cast<uint2*>(dst) = hi;
-        *reinterpret_cast<uint2*>(dst + 1024) = mid;
-        *reinterpret_cast<uint2*>(dst + 2048) = lo;
-    };
-    float4 R[4];
-    auto row_pass = [&]() {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            R[c] = make_float4(fmaf(sgn, pd[1][c].x, pd[0][c].x), fmaf(sgn, pd[1][c].y, pd[0][c].y), fmaf(sgn, pd[1][c].z, pd[0][c].z),
-                               fmaf(sgn, pd[1][c].w, pd[0][c].w));
-    };
-    auto col_put = [&](const int j, const unsigned vpar) {          // position 4 t_row + j of V buffer vpar
-        char* v = sm + wr_base + vpar * VB + j * 3072;
-        if (j == 0) put(v, f4sub(R[0], R[2]));
-        if (j == 1) put(v, f4add(R[1], R[2]));
-        if (j == 2) put(v, f4sub(R[2], R[1]));
-        if (j == 3) put(v, f4sub(R[1], R[3]));
-    };
-
-    // ---- prologue ---------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rvb[i] = rv[i]; }
-    item_geometry(la, roff, nrdA, nrdB, rs_in);
-    request_item_data();
-    rdA = nrdA;
-    rdB = nrdB;
-    tr_left = nks;
-    flush_pending();
-    issue_next(rv);                                       // raw(0)
-    issue_next(rvb);                                      // raw(1)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) load_u(j, u_item);
-    store_raw(rv, 0);
-    __syncthreads();                                      // raw(0) is in LDS
-    transform_read(0);
-    row_pass();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) col_put(j, 0);
-    store_raw(rvb, 1);
-    flush_pending();
-    issue_next(rv);                                       // raw(2)
-    __syncthreads();                                      // V(0) complete, raw(1) in LDS
-
-    // ---- the slice stream: iteration g multiplies slice g, transforms raw(g+1) -> V(g+1), stores raw(g+2), requests raw(g+3) ----
-    int g = 0;
-    for (;;) {
-        const int nxt_item = __builtin_amdgcn_readfirstlane(sh_item[(k_item + 1) & 1]);
-        const bool has_next = nxt_item < nitems;
-        const WinoItem nxt = has_next ? decode(nxt_item) : cur;
-        const unsigned u_next = (unsigned)__builtin_amdgcn_readfirstlane(((nxt.cout0 >> 5) + cb) * nks * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        for (int ks = 0; ks < nks; ++ks, ++g) {
-            const unsigned par = (unsigned)(g & 1), npar = par ^ 1u;
-            const char* vc = sm + VOFF + v_lane + par * VB;
-            int lastflag = __builtin_amdgcn_readfirstlane(ks + 1 == nks ? 1 : 0);
-            asm volatile("" : "+s"(lastflag));              // (opaque: keeps the compiler from peeling the last slice)
-            const unsigned u_reload = (unsigned)__builtin_amdgcn_readfirstlane(
-                (int)(lastflag ? u_next : u_item + (unsigned)(ks + 1) * 1024u));
-#pragma unroll
-            for (int l = 0; l < 3; ++l) vf[0][l] = *reinterpret_cast<const bf16x8*>(vc + l * 1024);
-            transform_read(npar);                           // raw(g+1)
-            __builtin_amdgcn_sched_barrier(0);
-            store_raw(rv, par);                             // raw(g+2) over raw(g)
-            flush_pending();
-            issue_next(rv);                                 // raw(g+3)
-            row_pass();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < 3) {
-#pragma unroll
-                    for (int l = 0; l < 3; ++l) vf[(j + 1) & 1][l] = *reinterpret_cast<const bf16x8*>(vc + (j + 1) * 3072 + l * 1024);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[j][0]), um = __builtin_bit_cast(bf16x8, ub[j][1]),
-                             ul = __builtin_bit_cast(bf16x8, ub[j][2]);
-                const bf16x8 vh = vf[j & 1][0], vm = vf[j & 1][1], vl = vf[j & 1][2];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[j], 0, 0, 0);
-                load_u(j, u_reload);                        // the same position of the next slice: a whole slice ahead
-                col_put(j, npar);                           // a quarter of the transform IN the shadow of this position's MFMAs:
-                // issue is in order, and the six MFMAs of a position are one dependent chain (32 cycles each) -- left alone the
-                // compiler clusters them and the wave issues nothing in between.  Pin the pattern: one MFMA, four VALU
-                // instructions of the limb split (4 x ~8 cycles of issue = the MFMA's latency), ...; then the stores and loads.
-#ifndef ERD_WX3H_NOPIN
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // VALU
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();                                // V(g+1) complete, V(g) and raw(g+1) consumed, raw(g+2) stored
-        }
-        // ---- output stage -------------------------------------------------------------------------------------------------
-        {
-            const WinoSeg& sg = p.seg[cur.s];
-            const float* ss = sh_ss + (k_item & 3) * 128;
-            const int lbw = cur.lbw, bwm = (1 << lbw) - 1;
-            const int ty = li >> lbw, tx = li & bwm;
-            const int fa = ri >> 1, fc = ri & 1;                           // this wave finishes y[fa][fc]
-            f32x16 z[2];
-            z[0] = (acc[0] + acc[1]) + acc[2];
-            z[1] = (acc[1] - acc[2]) - acc[3];
-            // sources of y[fa][fc]: rows (0, 1, 2) for fa = 0, rows (1, 2, 3) for fa = 1 -- own row included
-            const int base_w = cb * 4;
-            // the two rows that are not this wave's, ascending: ri 0 -> (1, 2), 1 -> (0, 2), 2 -> (1, 3), 3 -> (1, 2)
-            const int oa = ri == 1 ? 0 : 1, ob = ri == 2 ? 3 : 2;
-            const char* xa = smem + XOFF + (base_w + oa) * 2 * XCH_B + lane * 16;
-            const char* xb = smem + XOFF + (base_w + ob) * 2 * XCH_B + lane * 16;
-            f32x16 yv;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                for (int qr = 0; qr < 4; ++qr) {
-                    const float4 mine4 = make_float4(z[c][4 * qr], z[c][4 * qr + 1], z[c][4 * qr + 2], z[c][4 * qr + 3]);
-                    *reinterpret_cast<float4*>(xmy + (xr & 1) * XCH_B) = mine4;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) xflag[wave] = xr + 1;
-                    // rendezvous of the cout block's four waves: everybody has published round xr (and thereby finished reading round xr - 1)
-                    while (xflag[base_w] < xr + 1 || xflag[base_w + 1] < xr + 1 || xflag[base_w + 2] < xr + 1 || xflag[base_w + 3] < xr + 1)
-                        __builtin_amdgcn_s_sleep(1);
-                    if (c == fc) {
-                        const float4 s1 = *reinterpret_cast<const float4*>(xa + (xr & 1) * XCH_B);
-                        const float4 s2 = *reinterpret_cast<const float4*>(xb + (xr & 1) * XCH_B);
-                        // y[0][c] = (z0 + z1) + z2 ; y[1][c] = (z1 - z2) - z3 with (own, s1, s2) put back in row order
-                        float4 y4;
-                        if (ri == 0) y4 = f4add(f4add(mine4, s1), s2);          // own = z0, s1 = z1, s2 = z2
-                        else if (ri == 1) y4 = f4add(f4add(s1, mine4), s2);     // s1 = z0, own = z1, s2 = z2
-                        else if (ri == 2) y4 = f4sub(f4sub(s1, mine4), s2);     // s1 = z1, own = z2, s2 = z3
-                        else y4 = f4sub(f4sub(s1, s2), mine4);                  // s1 = z1, s2 = z2, own = z3
-                        yv[4 * qr] = y4.x; yv[4 * qr + 1] = y4.y; yv[4 * qr + 2] = y4.z; yv[4 * qr + 3] = y4.w;
-                    }
-                    ++xr;
-                }
-            }
-            const int oy = cur.y0 + 2 * ty + fa, ox = cur.x0 + 2 * tx + fc;
-            const bool simple = !sg.res && !sg.mask && !p.colsum;
-            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-                sg.out, 0, (int)((long long)sg.N * sg.out_nstride * 4), 0x00020000);
-            const float lo = p.relu ? 0.f : -__builtin_inff();
-            const bool pix_ok = oy < cur.yl && ox < cur.xl;
-            const int64_t opix = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int cl = 32 * cb + 8 * gq + 4 * h;
-                const int co0 = cur.cout0 + cl;
-                const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
-                const float4 sh = *reinterpret_cast<const float4*>(ss + 64 + cl);
-                float4 v = make_float4(yv[4 * gq] * sc.x + sh.x, yv[4 * gq + 1] * sc.y + sh.y, yv[4 * gq + 2] * sc.z + sh.z,
-                                       yv[4 * gq + 3] * sc.w + sh.w);
-                if (simple && (p.Cout & 3) == 0) {
-                    const bool ok = pix_ok && co0 < p.Cout;
-                    u32x4 o;
-                    o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
-                    o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
-                } else {
-                    float4 csv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (pix_ok && co0 < p.Cout) {
-                        const int64_t o = opix + co0;
-                        if ((p.Cout & 3) == 0) {
-                            if (sg.res) v = f4add(v, *reinterpret_cast<const float4*>(sg.res + o));
-                            if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                            if (sg.mask) {
-                                const float4 mk = *reinterpret_cast<const float4*>(sg.mask + o);
-                                v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
-                                                mk.w > 0.f ? v.w : 0.f);
-                            }
-                            *reinterpret_cast<float4*>(sg.out + o) = v;
-                        } else {
-                            float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (co0 + r < p.Cout) {
-                                    float e = vv[r];
-                                    if (sg.res) e += sg.res[o + r];
-                                    if (p.relu) e = fmaxf(e, 0.f);
-                                    if (sg.mask) e = sg.mask[o + r] > 0.f ? e : 0.f;
-                                    sg.out[o + r] = e;
-                                    vv[r] = e;
-                                } else vv[r] = 0.f;
-                            }
-                            v = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                        }
-                        csv = v;
-                    }
-                    if (p.colsum) {                                   // (Cout % 4 == 0 is required with colsum)
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) {
-                            csv.x += __shfl_xor(csv.x, o, 64); csv.y += __shfl_xor(csv.y, o, 64);
-                            csv.z += __shfl_xor(csv.z, o, 64); csv.w += __shfl_xor(csv.w, o, 64);
-                        }
-                        if (li == 0 && co0 < p.Cout) {
-                            float* cp = p.colsum + (p.colsum_copies > 1 ? (blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) + co0;
-                            atomicAdd(cp + 0, csv.x); atomicAdd(cp + 1, csv.y); atomicAdd(cp + 2, csv.z); atomicAdd(cp + 3, csv.w);
-                        }
-                    }
-                }
-            }
-        }
-        if (!has_next) {
-            if (tid == 0 && p.sched) {                       // the last workgroup to leave re-arms the counters
-                if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
-            }
-            break;
-        }
-        cur = nxt;
-        u_item = u_next;
-        ++k_item;
-    }
-}
-
 __global__ __launch_bounds__(256) void wino_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ U3, int Cout,
                                                               int Cin, int flip) {
     const int cop = (Cout + 31) / 32 * 32;
@@ -1694,17 +1268,6 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
     if (persist != 1) d.sched = nullptr;
-    static const int hybrid = getenv("ERD_WINO_X3H") ? atoi(getenv("ERD_WINO_X3H")) : 0;      // 0: the role-split three-limb kernel (A/B aid)
-    if (U3 && hybrid) {
-        const size_t lds = (size_t)2 * HPIX * RCS * 16 + 2 * VX_B + 8 * 2 * XCH_B + 64 + 2048 + 16;
-        static bool attrh_done = false;
-        if (!attrh_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_x3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attrh_done = true;
-        }
-        hipLaunchKernelGGL(wino_x3h_kernel, dim3((unsigned)grid), dim3(512), lds, stream, d);
-        return erd::check_launch("wino_conv3x3_x3h");
-    }
     if (U3) {
         const size_t lds = (size_t)2 * RAW_LDS_F4 * sizeof(float4) + 2 * VX_B + 4 * 2 * XCH_B + 64 + 2048 + 16;
         static bool attr3_done = false;
