@@ -663,8 +663,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(const WinoDesc p) {
 //     (M A)[i][c] for its two rows, the pair swaps ONE row each through LDS (wave A sends z1 and finishes output row 0 =
 //     (z0 + z1) + z2, wave B sends z2 and finishes row 1 = (z1 - z2) - z3: the fp32 kernel's summation order) in eight
 //     rounds of 4 registers, double-buffered, handed over with LDS flags (no workgroup barrier: the data waves run on);
-//   * V lives in LDS as [position][limb][tile][16 channels] bf16 (32-byte rows: a wave's B-fragment read is 1 KB
-//     contiguous, conflict-free), 48 KB per slice, double-buffered; the data waves write 8 bytes per (position, limb);
+//   * V lives in LDS as [position][limb][k half][tile][8 channels] bf16 (a wave's B-fragment read is 1 KB, every 16-lane
+//     service group 256 contiguous bytes: conflict-free), 48 KB per slice, double-buffered; the data waves write 8 bytes per
+//     (position, limb);
 //   * weight fragments: U3[position][limb][cout block][slice] is 1 KB contiguous; a ring of FOUR positions (x 3 limbs),
 //     re-loaded four positions ahead.
 // Everything else -- item list, block shapes, raw staging, look-ahead, the single barrier per slice -- is the fp32 kernel's.
@@ -734,7 +735,8 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
         const unsigned per_xl_b = (unsigned)ncb32 * (unsigned)nks * 1024u;          // bytes per (position, limb)
         const unsigned pos0_b = (unsigned)(ph * 8 * 3) * per_xl_b;                  // this wave's first position
         // B-fragment address inside a V buffer: (position, limb) block of 1 KB, tile row 32 B, k half h
-        const unsigned v_lane = (unsigned)(ph * 8 * 3 * 1024 + li * 32 + h * 16);
+        // (layout of a (position, limb) block: [k half h][tile][8 channels = 16 B], the tiles of half 1 XOR 8 -- see the data waves)
+        const unsigned v_lane = (unsigned)(ph * 8 * 3 * 1024 + h * 512 + ((li ^ (h * 8)) * 16));
         const char* vbase0 = smem + VOFF;
         char* const xmy = smem + XOFF + wave * 2 * XCH_B + lane * 16;
         const char* const xpartner = smem + XOFF + (wave ^ 1) * 2 * XCH_B + lane * 16;
@@ -1034,7 +1036,11 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
         char* const sm = smem;
         const unsigned st_base = (unsigned)(((dt >> 2) * RCS + (dt & 3)) * 16);
         // this thread's 8 bytes inside a (position, limb) block: tile row 32 B, channels 4 t_chunk .. + 3
-        const unsigned wr_base = VOFF + (unsigned)(t_tile * 32 + t_chunk * 8);
+        // V block of a (position, limb): 1 KB = [k half h = channel / 8][tile 32][16 B].  A matrix wave's B-fragment read (lane = tile,
+        // h) then covers 256 CONTIGUOUS bytes per 16-lane service group -- with 32-byte tile rows ([tile][16 channels]) the sixteen
+        // 16-byte pieces of a group were spread over 512 bytes and every bank was hit twice.  The tiles of half 1 are XORed with 8
+        // so that the 8-byte stores of a data wave's 16-lane group (4 tiles x 4 channel quads: both halves) land on different banks.
+        const unsigned wr_base = VOFF + (unsigned)((t_chunk >> 1) * 512 + ((t_tile ^ ((t_chunk >> 1) * 8)) * 16) + (t_chunk & 1) * 8);
         auto store_raw = [&](const float4* src, auto par_tag) {
             constexpr unsigned PAR = decltype(par_tag)::value;
 #pragma unroll

@@ -651,10 +651,14 @@ class FPNOutputs(Function):
         l3, l4, l5, cat, *ws = ctx.saved_tensors
         sizes = ctx.sizes
         lats = [l3, l4, l5]
-        # P5 / P6 slices accumulate the extra-level input gradients IN PLACE: the incoming tensor is the fan-in sum autograd has just
-        # built for this node alone (`cat` has no other consumer holding its gradient), so no private copy is taken (92 MB per step)
+        # The P5 / P6 slices accumulate the extra-level input gradients.  The incoming tensor belongs to the caller (a user-supplied
+        # grad_outputs, a retained gradient, a hook's capture: an autograd.Function must not modify its gradient inputs -- ADVICE
+        # r3), so those two slices are accumulated into PRIVATE copies (5.4 MB at the benchmark's size; round 3 skipped the
+        # copy altogether, round 2 cloned all 92 MB)
         dcat = dcat.contiguous()
-        dv = K.level_views(dcat, sizes)
+        dv = list(K.level_views(dcat, sizes))
+        dv[3] = dv[3].clone()
+        dv[2] = dv[2].clone()
         pv = K.level_views(cat, sizes)
         grads_w: List[Optional[Tensor]] = [None] * 5
         grads_b: List[Optional[Tensor]] = [None] * 5
@@ -662,7 +666,7 @@ class FPNOutputs(Function):
         def wgrad(i, xin, dz, stride):
             wk = ohwi(ws[i])
             if ctx.needs_input_grad[3 + i]:
-                grads_w[i] = _wgrad_plain(ws[i], [xin], [dz], 3, stride, 1, keep=(xin, dcat))
+                grads_w[i] = _wgrad_plain(ws[i], [xin], [dz], 3, stride, 1, keep=(xin, dcat, dz))
             if ctx.needs_input_grad[8 + i]:
                 sink = _sink(ctx.bias_params[i])
                 if sink is not None:          # column sums straight into the bias' flat gradient slot (zero at this point)

@@ -393,6 +393,20 @@ def _desc_cache() -> dict:
     return c
 
 
+THIN = _os.environ.get("ERD_THIN", "1") != "0"
+
+
+def _igemm_class(d, form: str) -> str:
+    """timing class of an erd_conv_igemm launch = the kernel SYMBOL it runs on (bench.py's roofline rows are per symbol, and must
+    agree with rocprofv3's): three-limb 1x1 launches with Cin in {64, 128} and Cout % 32 == 0 go to conv_thin_x3_kernel
+    (csrc/conv_thin.hip, erd::conv_thin_x3_ok -- the same test; only consulted while timing is on)"""
+    if _TIMING is None:
+        return "conv_igemm_" + form
+    thin = (THIN and d.w_x3 and not d.w_bf16 and d.ntaps == 1 and d.Cin in (64, 128) and d.Cout % 32 == 0 and d.wrow % 8 == 0 and
+            all(d.seg[i].ntaps == 0 for i in range(d.nseg)) and _lib.load().erd_conv_thin_enable(-1))
+    return ("conv_thin_" if thin else "conv_igemm_") + form
+
+
 def _geom(ts) -> tuple:
     # (all strides: the NHWC-density check of _check_map runs when the descriptor is built, so a differently laid out
     # tensor of the same shape must not hit an entry that was checked for another layout)
@@ -459,7 +473,7 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
     else:
         d.w_x3 = 0
     _attach_sk_ws(d, w.device)
-    _timed_call("conv_igemm_fwd", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
+    _timed_call(_igemm_class(d, "fwd"), flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
                 tag=tag if TIMING_DETAIL else "")
 
 
@@ -763,7 +777,7 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
             d.w_bf16 = wtb.data_ptr()
         d.w_x3 = 0 if wtx is None else wtx.data_ptr()
         _attach_sk_ws(d, wt.device)
-        _timed_call("conv_igemm_dgrad", flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
+        _timed_call(_igemm_class(d, "dgrad"), flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
                     tag=tag if TIMING_DETAIL else "")
 
 

@@ -91,7 +91,10 @@ def test_fpn_functions():
         l[i - 1] = Fn.UpsampleAdd.apply(l[i - 1], l[i])
     cat = Fn.FPNOutputs.apply(l[0], l[1], l[2], *fwg, *fbg)
     assert relerr(cat.detach().cpu(), ref_cat.detach()) < 2e-5
-    cat.backward(dcat.cuda())
+    g_in = dcat.cuda()
+    g_keep = g_in.clone()
+    cat.backward(g_in)
+    assert torch.equal(g_in, g_keep)        # the caller's gradient tensor is not modified (the P5 / P6 slices accumulate into copies)
     for i in range(3):
         assert relerr(csg[i].grad.permute(0, 3, 1, 2).cpu(), cs[i].grad) < 5e-5, i
         assert relerr(lwg[i].grad.cpu(), lw[i].grad) < 5e-5, i

@@ -21,7 +21,7 @@ python bench.py --compute bf16 --no-cpu-baseline > $O/bf16_bench.log 2>&1; line 
 python bench.py --arch r101_70_10 --no-cpu-baseline > $O/r101_bench.log 2>&1; line $O/r101_bench.log > $O/r101_bench.json
 python bench.py --mixed-res --no-cpu-baseline --steps 20 > $O/mixed_bench.log 2>&1; line $O/mixed_bench.log > $O/mixed_bench.json
 python bench.py --mixed-res --compute bf16 --no-cpu-baseline --steps 20 > $O/bf16_mixed_bench.log 2>&1; line $O/bf16_mixed_bench.log > $O/bf16_mixed_bench.json
-python tools/step_breakdown.py > $O/step_breakdown.txt 2>>$O/errors.log
+python tools/step_breakdown.py 3 f32x3 > $O/step_breakdown.txt 2>>$O/errors.log
 hipcc --offload-arch=gfx950 -O3 -w tools/mfma_peak.hip -o /tmp/mfma_peak_$T 2>>$O/errors.log && /tmp/mfma_peak_$T > $O/mfma_peak.txt 2>&1
 prof serial --serial --steps 6 --warmup 2 --no-cpu-baseline
 prof bf16_serial --serial --steps 6 --warmup 2 --no-cpu-baseline --compute bf16

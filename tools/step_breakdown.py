@@ -36,13 +36,15 @@ tr.flush()
 rec = K.timing_end()
 rows = sorted(rec.values(), key=lambda r: -r["ms"])
 tot = sum(r["ms"] for r in rows) / steps
-X3_CLASSES = ("conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad_row3", "conv_wgrad")
+X3_CLASSES = ("conv_igemm_fwd", "conv_igemm_dgrad", "conv_thin_fwd", "conv_thin_dgrad", "conv_wgrad_row3", "conv_wgrad")
 
 
 def pipe_of(kernel: str):
     """(executed flop per algorithmic flop, peak of the pipe in flop/s, label) of a timing class"""
     cls = kernel.split(" ")[0]
     if cls.startswith("conv_wino"):
+        if K.wino_x3():       # three-limb Winograd: 16/36 of the direct count, six bf16 limb products each
+            return bench.WINO_EXECUTED * 6.0, bench.BF16_MFMA_PEAK_TFLOPS * 1e12, "wx3"
         return bench.WINO_EXECUTED, bench.FP32_MFMA_PEAK_TFLOPS * 1e12, "f32"
     if mode == "bf16":
         return 1.0, bench.BF16_MFMA_PEAK_TFLOPS * 1e12, "bf16"
