@@ -91,6 +91,8 @@ def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path, H, W, bucket_
     res = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(WORLD)]
     for r, d in enumerate(res):
         assert d["backend"] == "gloo" and d["device"] == 0 and d["late_buckets"] == 0, (r, d["backend"], d["device"], d["late_buckets"], d["missing"][:12], d["repeats"][:12])
+        print("rank %d: %d buckets, parameters that reported a gradient more than once in a step (deduplicated by the sync): %s"
+              % (r, d["buckets"], d["repeats"][:6]))
         assert d["lrs"] == pytest.approx(lrs, rel=1e-12)
         assert d["buckets"] >= (4 if bucket_mb == 32 else 20)
     # ---- C2 / C3 ---------------------------------------------------------------------------------------------------------------
