@@ -619,6 +619,83 @@ def test_bf16_full_size_step_against_the_fp32_path():
           % (abs(l16["loss"] - l32["loss"]) / abs(l32["loss"]), cos, ratio, ["%.3f" % j for j in jac]))
 
 
+def test_bf16_full_size_step_against_the_oracle_bf16_mode():
+    """The same bf16 step against the ORACLE in its bf16 mode (`O.bf16_multiplicands()`: both multiplicands of every 1x1 / 3x3
+    convolution rounded to bf16, fp32 accumulation -- what the reference's AMP switch does to the convolutions, tools/train.py:85-97)
+    at BASELINE size, not against this package's own fp32 path ("a bound a bug would trip").  Both sides round at
+    the same places (the HIP path additionally stores maps as bf16, i.e. its residual adds and GroupNorm inputs see rounded values
+    too), so they must agree with each other MUCH better than either agrees with fp32: the oracle's bf16 mode is itself only
+    cos ~0.99 from the oracle's fp32 gradients.  Asserted relative to that measured noise floor."""
+    from erd_amd import kernels as K, parse_losses
+    tsd, ssd = f7_state_dicts()
+    names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
+    imgs, boxes, labels = O.synthetic_batch(1, 800, 1333, 40, seed=7)
+    x, metas = O.preprocess(imgs)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+
+    def oracle(bf16):
+        sd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in ssd.items()}
+        if bf16:
+            with O.bf16_multiplicands():
+                losses, aux = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80, return_aux=True)
+                O.parse_losses(losses).backward()
+        else:
+            losses, aux = O.erd_step_loss(tsd, sd, x, boxes, labels, metas, 40, 80, return_aux=True)
+            O.parse_losses(losses).backward()
+        row = {k: float(sum(v.detach().mean() for v in vs)) for k, vs in losses.items()}
+        row["loss"] = float(O.parse_losses(losses).detach())
+        return row, {k: sd[k].grad.double() for k in names}, [set(aux["ers_cls"][0].tolist()), set(aux["ers_bbox"][0].tolist())]
+
+    try:
+        l_o16, g_o16, s_o16 = oracle(True)
+        l_o32, g_o32, s_o32 = oracle(False)
+    finally:
+        torch.set_num_threads(threads)
+    K.set_compute("bf16")
+    try:
+        model = build_erd(tsd, ssd)
+        losses = model(x.cuda(), make_samples(boxes, labels, metas), mode="loss")
+        total, lv = parse_losses(losses)
+        total.backward()
+        t = model.teacher_pass(x.cuda())
+        cnt = t.ers["counts"].cpu()
+        s_h16 = [set(t.ers[n][0, :int(cnt[0, c])].cpu().tolist()) for n, c in (("idx_cls", 0), ("idx_bbox", 1))]
+        p = dict(model.named_parameters())
+        g_h16 = {k: p[k].grad.detach().cpu().double() for k in names}
+        l_h16 = {k: float(v) for k, v in lv.items()}
+    finally:
+        K.set_compute(K.DEFAULT_COMPUTE)
+
+    def cos(ga, gb):
+        dot = na = nb = 0.0
+        worst = 1.0
+        for k in names:
+            a, b = ga[k], gb[k]
+            if float(b.norm()) < 1e-12:
+                continue
+            if b.numel() >= 4096:
+                worst = min(worst, float((a * b).sum() / (a.norm() * b.norm())))
+            dot += float((a * b).sum()); na += float(a.pow(2).sum()); nb += float(b.pow(2).sum())
+        return dot / (na * nb) ** 0.5, (na / nb) ** 0.5, worst
+
+    c_ho, r_ho, w_ho = cos(g_h16, g_o16)          # HIP bf16 against the oracle's bf16 mode
+    c_oo, r_oo, w_oo = cos(g_o16, g_o32)          # the oracle's bf16 mode against the oracle's fp32: the rounding noise itself
+    jac_ho = [len(a & b) / max(len(a | b), 1) for a, b in zip(s_h16, s_o16)]
+    jac_oo = [len(a & b) / max(len(a | b), 1) for a, b in zip(s_o16, s_o32)]
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-7)
+    print("bf16 at 800x1333, HIP vs oracle-bf16 | oracle-bf16 vs oracle-fp32: gradient cosine %.5f | %.5f, norm ratio %.4f | %.4f, worst big tensor "
+          "%.4f | %.4f, total loss rel %.2e | %.2e, worst loss entry %.2e | %.2e, ERS Jaccard %s | %s"
+          % (c_ho, c_oo, r_ho, r_oo, w_ho, w_oo, rel(l_h16["loss"], l_o16["loss"]), rel(l_o16["loss"], l_o32["loss"]),
+             max(rel(l_h16[k], v) for k, v in l_o16.items()), max(rel(l_o16[k], v) for k, v in l_o32.items()),
+             ["%.3f" % j for j in jac_ho], ["%.3f" % j for j in jac_oo]))
+    # the HIP bf16 step is closer to the oracle's bf16 mode than that mode is to fp32 -- in direction, norm and losses
+    assert c_ho >= 0.985 and (1.0 - c_ho) <= 1.25 * (1.0 - c_oo) + 1e-4, (c_ho, c_oo)
+    assert abs(r_ho - 1.0) <= max(0.02, 1.5 * abs(r_oo - 1.0)), (r_ho, r_oo)
+    assert rel(l_h16["loss"], l_o16["loss"]) <= max(2e-3, 2.0 * rel(l_o16["loss"], l_o32["loss"])), (l_h16["loss"], l_o16["loss"])
+    assert min(jac_ho) >= min(0.88, min(jac_oo) - 0.03), (jac_ho, jac_oo)
+
+
 def test_shared_frozen_trunk_feeds_both_networks(monkeypatch):
     """Student stem + layer1 are frozen and warm-started from the teacher checkpoint (gfl_increment_erd.py:83-93,
     resnet.py:613-629): when the two copies are bit-identical the trunk is computed once per step and fed to both
