@@ -136,7 +136,7 @@ _SIGNATURES = {
     "erd_atss_result": [P, P, i64, P, P, P, P],
 }
 
-EXPORTS = ["erd_abi_version", "erd_last_error"] + sorted(_SIGNATURES)
+EXPORTS = ["erd_abi_version", "erd_probe_build", "erd_last_error"] + sorted(_SIGNATURES)
 
 _lib = None
 
@@ -163,6 +163,10 @@ def load():
         fn.restype = C.c_size_t if name.endswith(("_ws_bytes", "_elems")) else C.c_int
     if lib.erd_abi_version() != 4:
         raise ErdHipError("liberd_hip.so ABI version mismatch")
+    lib.erd_probe_build.restype = C.c_int
+    if lib.erd_probe_build() and not os.environ.get("ERD_HIP_LIB"):
+        raise ErdHipError(f"{LIB_PATH} is a PROBE build (a kernel was compiled with a timing / accuracy / trace macro of "
+                          "csrc/erd_probes.h): rebuild with `make -C erd_amd/csrc`, or select it explicitly with ERD_HIP_LIB")
     _lib = lib
     return lib
 

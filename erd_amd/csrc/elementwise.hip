@@ -14,6 +14,9 @@ void set_error(const char* fmt, ...) {
 }  // namespace erd
 
 extern "C" int erd_abi_version(void) { return ERD_ABI_VERSION; }
+// 1 when any translation unit of this library was compiled with a probe of erd_probes.h (a timing / accuracy / trace variant)
+extern "C" __attribute__((weak)) int erd_probe_build_marker;
+extern "C" int erd_probe_build(void) { return &erd_probe_build_marker != nullptr ? erd_probe_build_marker : 0; }
 extern "C" const char* erd_last_error(void) { return erd::g_err; }
 
 namespace {

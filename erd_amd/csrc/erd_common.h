@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/erd_hip.h"
+#include "erd_probes.h"
 
 namespace erd {
 

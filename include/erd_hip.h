@@ -44,6 +44,9 @@ typedef void* erd_stream_t; /* hipStream_t */
 enum { ERD_F32 = 0, ERD_BF16 = 1 };
 
 int erd_abi_version(void);
+/* 0 for the product build; 1 when the library contains a timing / accuracy / trace probe variant of a kernel (csrc/erd_probes.h):
+ * such builds exist for same-box A/B measurements only and must never be the library a training run loads */
+int erd_probe_build(void);
 const char* erd_last_error(void);
 
 /* ---- convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) --------------------
