@@ -277,8 +277,8 @@ def main():
     ap.add_argument("--compute", choices=["f32x3", "f32", "bf16"], default="f32x3",
                     help="f32x3 (default; BASELINE configs[1], the headline): fp32 maps, fp32 accumulation, fp32 results; the direct "
                          "implicit-GEMM launches form each fp32 product on the bf16 matrix cores from exact three-limb splits of both "
-                         "multiplicands (what is dropped is below 2^-23 of the product; gfx950's fp32 MFMA runs at 1/16 of the bf16 rate), so do "
-                         "the weight-gradient launches; Winograd launches run on the fp32 matrix cores.  f32: every launch on the fp32 matrix cores "
+                         "multiplicands (round-to-nearest limbs: what is dropped is zero-mean and below 2^-23 of the product; gfx950's fp32 MFMA runs at 1/16 of the bf16 rate), so do "
+                         "the weight-gradient launches and the transform-domain products of the Winograd launches.  f32: every launch on the fp32 matrix cores "
                          "(the A/B sibling).  bf16: BASELINE configs[2] -- the 1x1 / 3x3 convolutions on the bf16 matrix cores with fp32 "
                          "accumulation, feature maps and their gradients STORED as bf16; head outputs, statistics, losses, parameters "
                          "and parameter gradients stay fp32")

@@ -197,8 +197,9 @@ def make_levels(sizes: Sequence[Tuple[int, int]]) -> Levels:
 # accumulation, epilogues and storage) or "f32x3": fp32 maps / accumulation / results as in "f32", but the direct
 # implicit-GEMM launches form every product on the bf16 matrix cores from exact three-limb splits of both fp32
 # multiplicands (erd_conv_desc::w_x3; gfx950's fp32 MFMA runs at 1/16 of the bf16 rate), and so do the weight-gradient
-# launches (erd_wgrad_desc::limbs3: both operands are split in the kernel's transposing loader).  The Winograd launches are
-# the "f32" ones.  Process-wide switch: set_compute(...) / ERD_COMPUTE=...
+# launches (erd_wgrad_desc::limbs3: both operands are split in the kernel's transposing loader) and the Winograd launches
+# (erd_wino_conv3x3_x3: U = G g G^T pre-split, V = B^T d B split behind the transform; WINO_X3).  Process-wide switch:
+# set_compute(...) / ERD_COMPUTE=...
 # ---------------------------------------------------------------------------------------------
 DEFAULT_COMPUTE = _os.environ.get("ERD_COMPUTE", "f32x3")      # the fp32 configuration of BASELINE configs[1]; "f32": native fp32 MFMA
 COMPUTE = DEFAULT_COMPUTE
