@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
             }
             __syncthreads();
             const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+                erd::uniform_ptr(const_cast<float*>(sg.in)), 0, erd::uniform_int((int)((long long)sg.N * sg.in_nstride * 4)), 0x00020000);
             const int ibase = rows[wave * 32 + li].in_off;
             // lane (li, h) holds channels 16 s + 8 h .. + 7 of pixel row li for every step s: two 16-byte loads per step
             u4v xa[KS], xb[KS];

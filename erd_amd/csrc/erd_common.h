@@ -14,6 +14,9 @@ void set_error(const char* fmt, ...);
 // conv_thin.hip: the activation-stationary three-limb kernel for 1x1 convolutions with Cin <= 128 (erd_conv_igemm dispatches to it)
 bool conv_thin_x3_ok(const erd_conv_desc* d);
 int conv_thin_x3(const erd_conv_desc* d, hipStream_t st);
+// conv_frag.hip: the fragment-streaming three-limb kernel for 1x1 convolutions with Cin >= 256 (erd_conv_desc::w_x3f)
+bool conv_frag_x3_ok(const erd_conv_desc* d);
+int conv_frag_x3(const erd_conv_desc* d, hipStream_t st);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -62,6 +65,17 @@ __device__ __forceinline__ float4 unpack4_bf16(uint2 u) {
     return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
 }
 __device__ __forceinline__ uint2 pack4_bf16(float4 v) { return make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w)); }
+
+// a pointer / integer that IS wave-uniform but that the compiler cannot prove uniform (a segment picked by a data-dependent loop):
+// through v_readfirstlane, so that buffer resources built from it live in SGPRs (a resource in VGPRs turns every buffer
+// load into a waterfall loop)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- three-limb split ("f32x3"): an fp32 value as the EXACT sum of three bf16 values, each rounded to nearest even:
 //   hi = rne(x), mid = rne(x - hi), lo = x - hi - mid      (x - hi has <= 16 significant bits, x - hi - mid <= 8: both exact)
