@@ -252,7 +252,6 @@ def self_launch(args, argv) -> int:
 SYMBOLS = {"wino_conv_kernel": ("conv_wino_fwd", "conv_wino_dgrad"),
            "conv_igemm_kernel": ("conv_igemm_fwd", "conv_igemm_dgrad"),
            "conv_thin_x3_kernel": ("conv_thin_fwd", "conv_thin_dgrad"),
-           "conv_frag_x3_kernel": ("conv_frag_fwd", "conv_frag_dgrad"),
            "conv_wgrad_row3_kernel": ("conv_wgrad_row3",),
            "conv_wgrad_kernel": ("conv_wgrad",)}
 WINO_EXECUTED = 16.0 / 36.0       # F(2x2,3x3) runs 16 of the 36 multiplications a direct 3x3 convolution counts per 2x2 outputs
@@ -500,7 +499,7 @@ def main():
             # executed flops per algorithmic flop, and the matrix pipe they run on: Winograd 16/36 on the fp32 pipe; the three-limb
             # form of the direct launches 6 bf16 MFMA flops per fp32 flop on the bf16 pipe
             x3 = args.compute == "f32x3"
-            X3_SYMS = ("conv_igemm_kernel", "conv_thin_x3_kernel", "conv_frag_x3_kernel", "conv_wgrad_row3_kernel", "conv_wgrad_kernel")      # launch classes that run in the three-limb form
+            X3_SYMS = ("conv_igemm_kernel", "conv_thin_x3_kernel", "conv_wgrad_row3_kernel", "conv_wgrad_kernel")      # launch classes that run in the three-limb form
             execf = WINO_EXECUTED * (6.0 if wino_on_bf16 else 1.0) if sym == wino_sym else (6.0 if (x3 and sym in X3_SYMS) else 1.0)
             if (x3 and sym in X3_SYMS) or (sym == wino_sym and wino_on_bf16):
                 peak_tf = BF16_MFMA_PEAK_TFLOPS

@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("in_stride", i32), ("out_stride", i32), ("oy", i32), ("ox", i32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", i32), ("colsum", C.c_void_p),
                 ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("w_bf16", C.c_void_p), ("colsum_copies", i32),
-                ("in_bf16", i32), ("out_bf16", i32), ("w_x3", C.c_void_p), ("w_x3f", C.c_void_p)]
+                ("in_bf16", i32), ("out_bf16", i32), ("w_x3", C.c_void_p)]
 
 
 class WgradSeg(C.Structure):
@@ -75,9 +75,6 @@ _SIGNATURES = {
     "erd_to_bf16": [P, P, i64, P],
     "erd_split3": [P, P, i64, P],
     "erd_conv_thin_enable": [i32],
-    "erd_conv_frag_enable": [i32],
-    "erd_weight_frag_x3_elems": [i32, i32],
-    "erd_weight_frag_x3": [P, P, i32, i32, i32, P],
     "erd_weight_transpose_x3": [P, P, P, i32, i32, i32, i32, P],
     "erd_wino_weights_elems": [i32, i32],
     "erd_wino_weights": [P, P, i32, i32, i32, P],

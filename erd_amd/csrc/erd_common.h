@@ -14,9 +14,6 @@ void set_error(const char* fmt, ...);
 // conv_thin.hip: the activation-stationary three-limb kernel for 1x1 convolutions with Cin <= 128 (erd_conv_igemm dispatches to it)
 bool conv_thin_x3_ok(const erd_conv_desc* d);
 int conv_thin_x3(const erd_conv_desc* d, hipStream_t st);
-// conv_frag.hip: the fragment-streaming three-limb kernel for 1x1 convolutions with Cin >= 256 (erd_conv_desc::w_x3f)
-bool conv_frag_x3_ok(const erd_conv_desc* d);
-int conv_frag_x3(const erd_conv_desc* d, hipStream_t st);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

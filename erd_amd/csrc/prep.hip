@@ -82,23 +82,6 @@ __device__ __forceinline__ void split3_block(const erd_weight_prep_item& it, int
     d[2 * n + i] = l;
 }
 
-// kind 5: the limb planes of a [Cout][Cin] weight pre-tiled as MFMA B-fragments (erd_weight_frag_x3): one thread per value
-__device__ __forceinline__ void frag_x3_block(const erd_weight_prep_item& it, int local) {
-    const int K = it.Cin;
-    const int64_t idx = local * 256ll + threadIdx.x;
-    if (idx >= (int64_t)it.Cout * K) return;
-    const int co = (int)(idx / K), k = (int)(idx % K);
-    unsigned short hi, mid, lo;
-    erd::limbs3(it.w[idx], hi, mid, lo);
-    const int nks = K / 16;
-    const int64_t per_plane = (int64_t)(it.Cout / 32) * nks * 512;
-    const int64_t o = (((int64_t)(co / 32) * nks + k / 16) * 64 + ((k % 16) / 8) * 32 + (co % 32)) * 8 + (k % 8);
-    unsigned short* d = reinterpret_cast<unsigned short*>(it.dst);
-    d[o] = hi;
-    d[per_plane + o] = mid;
-    d[2 * per_plane + o] = lo;
-}
-
 // kind 4: the Winograd weight image in the three-limb layout (erd_wino_weights_x3): one thread per (co < ceil32(Cout), ci)
 __device__ __forceinline__ void wino_x3_block(const erd_weight_prep_item& it, int local) {
     const int cop = (it.Cout + 31) / 32 * 32;
@@ -124,7 +107,6 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const erd_weight_prep_
     if (it.kind == 2) wino_block(it, local);
     else if (it.kind == 3) split3_block(it, local);
     else if (it.kind == 4) wino_x3_block(it, local);
-    else if (it.kind == 5) frag_x3_block(it, local);
     else transpose_block(it, local, tile);
 }
 
@@ -134,7 +116,6 @@ extern "C" int erd_weight_prep_blocks(int kind, int Cout, int ntaps, int Cin) {
     if (kind == 2) return (int)(((int64_t)((Cout + 15) / 16 * 16) * Cin + 255) / 256);
     if (kind == 3) return (int)(((int64_t)Cout * ntaps * Cin + 255) / 256);
     if (kind == 4) return (int)(((int64_t)((Cout + 31) / 32 * 32) * Cin + 255) / 256);
-    if (kind == 5) return (int)(((int64_t)Cout * Cin + 255) / 256);
     return ((Cin + 31) / 32) * ((Cout + 31) / 32) * ntaps;
 }
 

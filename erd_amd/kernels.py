@@ -299,50 +299,6 @@ def _weights_x3(w: Tensor, grad_form: bool = False) -> Tensor:
     return out
 
 
-FRAG = _os.environ.get("ERD_FRAG", "1") != "0"
-
-
-def frag_ok(Cout: int, k: int, Cin: int) -> bool:
-    """does a three-limb 1x1 launch run on the fragment-streaming kernel (csrc/conv_frag.hip, erd::conv_frag_x3_ok)?"""
-    return FRAG and COMPUTE == "f32x3" and k == 1 and Cin % 32 == 0 and Cin >= 256 and Cout % 128 == 0
-
-
-def weight_frag_x3(w2d: Tensor) -> Tensor:
-    """the three limb planes of a contiguous [Cout, K] fp32 weight pre-tiled as MFMA B-fragments (erd_conv_desc::w_x3f)"""
-    Cout, Kd = w2d.shape
-    assert w2d.is_contiguous() and w2d.dtype == torch.float32
-    out = torch.empty(int(_lib.load().erd_weight_frag_x3_elems(Cout, Kd)), dtype=torch.bfloat16, device=w2d.device)
-    call("erd_weight_frag_x3", _p(w2d), _p(out), Cout, Kd, Kd, _stream())
-    return out
-
-
-def _weights_x3f(w: Tensor, grad_form: bool = False) -> Tensor:
-    """fragment-tiled limb planes of a 1x1 weight view for erd_conv_desc::w_x3f: `w` is [Cout, 1, 1, Cin] (forward: the OHWI view of a
-    parameter; gradient form: a transposed weight from weight_transpose()).  Frozen weights are tiled once (cached on the parameter),
-    trainable ones are served from the trainer's per-step preparation (ParamPrep kind 5) or tiled per use."""
-    owner = getattr(w, "_erd_prep_owner", None) if grad_form else _prep_owner(w)
-    prep = _prep_of(owner)
-    key = ("FT" if grad_form else "F", id(owner))
-    if prep is not None:
-        r = prep.lookup(key)
-        if r is not None and r.matches(owner, w, None):
-            return r.out
-    w2d = w.detach().view(w.shape[0], w.shape[3])
-    if not grad_form:
-        base = getattr(w, "_erd_owner", None)
-        if base is not None and not base.requires_grad and not w.requires_grad:
-            ver = (w.data_ptr(), base._version, tuple(w.shape))
-            hit = getattr(base, "_erd_x3f", None)
-            if hit is None or hit[0] != ver:
-                hit = (ver, weight_frag_x3(w2d))
-                base._erd_x3f = hit
-            return hit[1]
-    out = weight_frag_x3(w2d)
-    if prep is not None and not torch.cuda.is_current_stream_capturing():
-        prep.register(key, 5, w, None, torch.empty_like(out), w.shape[0], 1, w.shape[3], 0, owner, 1 if grad_form else 0)
-    return out
-
-
 # ---------------------------------------------------------------------------------------------
 # convolution (forward form, input-gradient form, weight gradient)
 # ---------------------------------------------------------------------------------------------
@@ -449,11 +405,7 @@ def _igemm_class(d, form: str) -> str:
         return "conv_igemm_" + form
     thin = (THIN and d.w_x3 and not d.w_bf16 and d.ntaps == 1 and d.Cin in (64, 128) and d.Cout % 32 == 0 and d.wrow % 8 == 0 and
             all(d.seg[i].ntaps == 0 for i in range(d.nseg)) and _lib.load().erd_conv_thin_enable(-1))
-    if thin:
-        return "conv_thin_" + form
-    frag = (FRAG and d.w_x3f and d.ntaps == 1 and d.Cin % 32 == 0 and d.Cin >= 256 and d.Cout % 128 == 0 and
-            all(d.seg[i].ntaps == 0 for i in range(d.nseg)) and _lib.load().erd_conv_frag_enable(-1))
-    return ("conv_frag_" if frag else "conv_igemm_") + form
+    return ("conv_thin_" if thin else "conv_igemm_") + form
 
 
 def _geom(ts) -> tuple:
@@ -517,15 +469,10 @@ def conv_forward(xs: Sequence[Tensor], w: Tensor, outs: Sequence[Tensor], k: int
         wb = _weights_bf16(w)          # (kept alive by this frame until the launch is queued; stream-ordered free)
         d.w_bf16 = wb.data_ptr()
     elif COMPUTE == "f32x3" and Cin % 4 == 0:
-        if frag_ok(Cout, k, Cin):          # 1x1, Cin >= 256: the fragment-streaming kernel reads the pre-tiled planes only
-            wf = _weights_x3f(w)
-            d.w_x3f, d.w_x3 = wf.data_ptr(), wf.data_ptr()      # (w_x3 non-null selects the three-limb dispatch; this launch never reads it)
-        else:
-            wx = _weights_x3(w)
-            d.w_x3, d.w_x3f = wx.data_ptr(), 0
+        wx = _weights_x3(w)
+        d.w_x3 = wx.data_ptr()
     else:
         d.w_x3 = 0
-        d.w_x3f = 0
     _attach_sk_ws(d, w.device)
     _timed_call(_igemm_class(d, "fwd"), flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
                 tag=tag if TIMING_DETAIL else "")
@@ -703,7 +650,6 @@ class ParamPrep:
             self.recipes.pop(("UT", key[1]), None)
             self.recipes.pop(("UT3", key[1]), None)
             self.recipes.pop(("XT", key[1]), None)
-            self.recipes.pop(("FT", key[1]), None)
         self.recipes[key] = r
         self._tables = None
 
@@ -725,7 +671,6 @@ class ParamPrep:
                     self.recipes.pop(("UT", key[1]), None)
                     self.recipes.pop(("UT3", key[1]), None)
                     self.recipes.pop(("XT", key[1]), None)
-                    self.recipes.pop(("FT", key[1]), None)
                 self._tables = None
                 self._stale()
         if self._tables is None:
@@ -802,17 +747,12 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         return
     wtb = None
     wtx = None
-    wtf = None
     if COMPUTE == "bf16":
         wtb = wt if wt.dtype == torch.bfloat16 else to_bf16(wt)
     elif wt.dtype != torch.float32:
         raise ValueError("conv_dgrad: bf16 weights in f32 compute mode")
     elif COMPUTE == "f32x3" and Cout % 4 == 0:
-        if frag_ok(Cin, k, Cout):          # (the input gradient is a GEMM K = Cout -> N = Cin of the forward convolution)
-            wtf = _weights_x3f(wt, grad_form=True)
-            wtx = wtf                      # (w_x3 non-null selects the three-limb dispatch; the fragment kernel never reads it)
-        else:
-            wtx = _weights_x3(wt, grad_form=True)
+        wtx = _weights_x3(wt, grad_form=True)
     if stride == 2 and k == 3 and len(dzs) == 1 and MERGE_PARITY:
         _dgrad_s2_merged(dzs[0], wt, wtb, dxs[0], pad, Cin, Cout, accumulate, res, relu_mask, colsum, wtx=wtx)
         return
@@ -837,7 +777,6 @@ def conv_dgrad(dzs: Sequence[Tensor], wt: Tensor, dxs: Sequence[Tensor], k: int,
         if wtb is not None:
             d.w_bf16 = wtb.data_ptr()
         d.w_x3 = 0 if wtx is None else wtx.data_ptr()
-        d.w_x3f = 0 if wtf is None else wtf.data_ptr()
         _attach_sk_ws(d, wt.device)
         _timed_call(_igemm_class(d, "dgrad"), flop, "erd_conv_igemm", C.byref(d), _stream(), nbytes=nbytes if _TIMING is not None else 0.0,
                     tag=tag if TIMING_DETAIL else "")

@@ -109,12 +109,6 @@ typedef struct {
      * weight >= 2^-16 (the activation is split the same way in registers): the dropped terms are zero-mean and below 2^-23 |a*w|,
      * fp32's own rounding of that product (the round-3 library split by truncation: dropped terms up to 2^-21 |a*w|, all of the product's sign).  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate; six bf16 MFMAs cost 3/8 of one fp32 MFMA. */
     const void* w_x3;
-    /* optional (ABI v4, "f32x3"): the same three limb planes PRE-TILED as MFMA B-fragments, [3][Cout / 32][K / 16][64 lanes][8]
-     * (erd_weight_frag_x3; K = wrow = Cin: 1x1 convolutions only).  When set and the launch is a 1x1 convolution with Cin % 32 == 0,
-     * Cin >= 256 and Cout % 128 == 0, erd_conv_igemm runs the fragment-streaming kernel (csrc/conv_frag.hip: weight fragments go
-     * global -> registers with no LDS in between, 2 x 2 waves); same MFMA sequence per accumulator as the w_x3 kernel without a
-     * stream-K split.  Other launches ignore it. */
-    const void* w_x3f;
 } erd_conv_desc;
 
 /* replaces: F.conv2d dispatches at resnet.py:268-283, res_layer.py:57-63, fpn.py:196,215-220,
@@ -128,12 +122,6 @@ size_t erd_conv_igemm_ws_bytes(int max_tiles);
  * dispatch for the process (A/B runs and the bit-identity test), on < 0 only queries; returns the previous setting.
  * Default: on (environment ERD_THIN=0: off). */
 int erd_conv_thin_enable(int on);
-/* the fragment-streaming kernel of erd_conv_desc::w_x3f: the same process-wide switch (default on; ERD_FRAG=0: off) */
-int erd_conv_frag_enable(int on);
-/* dst[plane][co / 32][k / 16][lane = (k % 16 / 8) * 32 + co % 32][k % 8] = limb `plane` of w[co * wrow + k]: the layout
- * erd_conv_desc::w_x3f wants (Cout % 32 == 0, K % 16 == 0; erd_weight_frag_x3_elems = 3 * Cout * K bf16 values) */
-size_t erd_weight_frag_x3_elems(int Cout, int K);
-int erd_weight_frag_x3(const float* w, void* dst, int Cout, int K, int wrow, erd_stream_t stream);
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements */
 int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
 /* the three bf16 limbs of every value, each rounded to nearest even: dst[0][i] + dst[1][i] + dst[2][i] == src[i] exactly; dst = [3][n] bf16
@@ -226,8 +214,7 @@ int erd_weight_transpose_x3(const float* w, const float* rowscale, void* dst, in
 
 /* Many weight transforms in ONE launch: erd_weight_transpose (kind 0), erd_weight_transpose_bf16 (kind 1),
  * erd_wino_weights (kind 2: w is [Cout][3][3][Cin], ntaps = 9, rowscale unused), erd_split3 (kind 3: the Cout * ntaps * Cin
- * values at w, rowscale / flip unused), erd_wino_weights_x3 (kind 4, as kind 2) or erd_weight_frag_x3 (kind 5: w is [Cout][Cin],
- * ntaps = 1, wrow = Cin) per item, same arithmetic.  `items_dev` is a
+ * values at w, rowscale / flip unused) or erd_wino_weights_x3 (kind 4, as kind 2) per item, same arithmetic.  `items_dev` is a
  * DEVICE array sorted by block0; item i owns blocks [block0, block0 + erd_weight_prep_blocks(kind, Cout, ntaps, Cin)) of the
  * launch, total_blocks is their sum.  Items of one launch must not depend on each other (a Winograd image of a transposed
  * weight goes into a second launch).  The trainer prepares everything the step derives from the parameters alone this

@@ -10,7 +10,7 @@ extra=""
 case $base in losses|leaf_ops|predict) extra="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f -o /tmp/${base}_probe_$n.o
 objs=""
-for o in conv_mfma conv_thin conv_frag elementwise losses predict winograd leaf_ops prep; do
+for o in conv_mfma conv_thin elementwise losses predict winograd leaf_ops prep; do
   if [ $o = $base ]; then objs="$objs /tmp/${base}_probe_$n.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../lib/abl/liberd_hip_$n.so

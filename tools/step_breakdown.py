@@ -36,7 +36,7 @@ tr.flush()
 rec = K.timing_end()
 rows = sorted(rec.values(), key=lambda r: -r["ms"])
 tot = sum(r["ms"] for r in rows) / steps
-X3_CLASSES = ("conv_igemm_fwd", "conv_igemm_dgrad", "conv_thin_fwd", "conv_thin_dgrad", "conv_frag_fwd", "conv_frag_dgrad", "conv_wgrad_row3", "conv_wgrad")
+X3_CLASSES = ("conv_igemm_fwd", "conv_igemm_dgrad", "conv_thin_fwd", "conv_thin_dgrad", "conv_wgrad_row3", "conv_wgrad")
 
 
 def pipe_of(kernel: str):
