@@ -44,7 +44,9 @@ def _storage_view(flat: Tensor, off: int, p: Tensor) -> Tensor:
 
 
 class FlatParams:
-    def __init__(self, named_params: Sequence, device, bucket_bytes: int = 32 << 20, tail_bytes: int = 4 << 20):
+    def __init__(self, named_params: Sequence, device, bucket_bytes: int = 32 << 20, tail_bytes: int = 4 << 20, group_key=None):
+        """`group_key(name)`: parameters with the same key are never split between two buckets (ERDTrainer: one key per
+        ResNet block / per neck / per head -- the unit whose backward launches are issued together, see BucketedGradSync)."""
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         offs, total = [], 0
@@ -62,27 +64,38 @@ class FlatParams:
             p.grad = _storage_view(self.grad, off, p)
             p._erd_sink = True        # backward kernels may write this slot directly (functional._sink)
         self.data_bf16: Optional[Tensor] = None      # bf16 shadow of `data` (bf16 matrix-core mode), see refresh_shadow
-        # buckets over the flat range, in layout order (= backward order)
+        # units: runs of parameters that stay together (one parameter each without a group key), in layout order (= backward order)
+        ends = offs[1:] + [total]
+        units: List[list] = []
+        prev = object()
+        for i, name in enumerate(self.names):
+            key = group_key(name) if group_key is not None else i
+            if units and key == prev:
+                units[-1].append(i)
+            else:
+                units.append([i])
+            prev = key
+        # buckets over the flat range: whole units until `bucket_bytes` are reached
         self.buckets: List[tuple] = []
-        start, members = 0, []
-        for i, (p, off) in enumerate(zip(self.params, offs)):
-            members.append(i)
-            end = off + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-            if (end - start) * 4 >= bucket_bytes or i == len(self.params) - 1:
-                self.buckets.append((start, end, members))
-                start, members = end, []
-        # the LAST bucket's all-reduce is the only one nothing of the backward pass is left to hide: with the teacher of step
-        # t+1 running next to backward(t) it sits between backward(t) and forward(t+1) on the main stream.  Keep it short:
-        # the tail of the layout (the parameters whose gradients land last: the first trainable block) becomes its own
-        # bucket of at most `tail_bytes` (a 1.5 MB all-reduce instead of up to `bucket_bytes`)
-        if len(self.params) > 1 and self.buckets:
-            s0, e0, mem = self.buckets[-1]
-            cut = len(mem)
-            while cut > 1 and (e0 - offs[mem[cut - 1]]) * 4 <= tail_bytes:
+        cur: List[list] = []
+        for u in units:
+            cur.append(u)
+            if (ends[u[-1]] - offs[cur[0][0]]) * 4 >= bucket_bytes or u is units[-1]:
+                self.buckets.append(cur)
+                cur = []
+        # the LAST bucket's all-reduce and update are the ones nothing of the backward pass is left to hide: with the teacher
+        # of step t+1 running next to backward(t) they sit between backward(t) and forward(t+1).  Keep them short: the tail
+        # of the layout (the parameters whose gradients land last: the first trainable block(s)) becomes its own bucket of
+        # at most `tail_bytes` (GFL-R50: layer2's first three blocks, 3.6 MB, instead of 19 MB)
+        size = lambda us: (ends[us[-1][-1]] - offs[us[0][0]]) * 4
+        if self.buckets and len(self.buckets[-1]) > 1:
+            us = self.buckets[-1]
+            cut = len(us)
+            while cut > 1 and size(us[cut - 1:]) <= tail_bytes:
                 cut -= 1
-            if cut < len(mem) and (e0 - offs[mem[cut]]) * 4 <= tail_bytes and (e0 - s0) * 4 > tail_bytes:
-                mid = offs[mem[cut]]
-                self.buckets[-1:] = [(s0, mid, mem[:cut]), (mid, e0, mem[cut:])]
+            if cut < len(us) and size(us[cut:]) <= tail_bytes < size(us):
+                self.buckets[-1:] = [us[:cut], us[cut:]]
+        self.buckets = [(offs[us[0][0]], ends[us[-1][-1]], [i for u in us for i in u]) for us in self.buckets]
         self.bucket_of = {}
         for b, (_, _, mem) in enumerate(self.buckets):
             for i in mem:
@@ -91,37 +104,59 @@ class FlatParams:
     def zero_grad(self) -> None:
         self.grad.zero_()
 
-    def refresh_shadow(self) -> None:
-        """bf16 matrix-core mode: ONE conversion launch over the flat parameter buffer after each update instead of one
-        per convolution; every 4-d parameter gets a bf16 twin view (same shape and strides) that the conv wrappers pick
-        up as long as the parameter's version counter has not moved since."""
+    def refresh_shadow(self, bucket: Optional[int] = None) -> None:
+        """bf16 matrix-core mode: ONE conversion launch over the flat parameter buffer (or one bucket of it) after each update
+        instead of one per convolution; every 4-d parameter gets a bf16 twin view (same shape and strides) that the conv
+        wrappers pick up as long as the parameter's version counter has not moved since."""
         if K.COMPUTE != "bf16":
             return
         if self.data_bf16 is None:
             self.data_bf16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.data.device)
-        K.to_bf16_into(self.data, self.data_bf16)
-        for p, off in zip(self.params, self.offsets):
+            if bucket is not None:       # (first use from a per-bucket update: the other buckets follow within the same step)
+                K.to_bf16_into(self.data, self.data_bf16)
+        if bucket is None:
+            K.to_bf16_into(self.data, self.data_bf16)
+            members = range(len(self.params))
+        else:
+            s, e, members = self.buckets[bucket]
+            K.to_bf16_into(self.data[s:e], self.data_bf16[s:e])
+        for i in members:
+            p = self.params[i]
             if p.dim() == 4:
-                p._erd_shadow = (_storage_view(self.data_bf16, off, p), p._version)
+                p._erd_shadow = (_storage_view(self.data_bf16, self.offsets[i], p), p._version)
 
 
 class BucketedGradSync:
     """Data-parallel gradient SUM over ranks on the flat gradient buffer: one async all-reduce per bucket, issued
     from a post-accumulate-grad hook when the bucket's last gradient has landed (so it overlaps the rest of the
     backward).  Device-agnostic (RCCL on GPUs, gloo in the CPU tests); the 1/world scaling is folded into the SGD
-    kernel's `grad_scale`."""
+    kernel's `grad_scale`.
 
-    def __init__(self, flat: FlatParams, streams: Sequence = ()):
+    With `on_bucket` the sync also drives a per-bucket UPDATE: `on_bucket(b)` runs once bucket b's summed gradient is final
+    (ERDTrainer: SGD on the bucket's slice, its BN folds, its prepared weight buffers), so that at the step boundary only the
+    small tail bucket is left.  The update rewrites what the bucket's own backward launches still read (weights, folded BN
+    scales, transposed weights), and a parameter reports as soon as ITS gradient kernel is queued -- the input-gradient launch
+    of the same convolution may follow.  So a complete bucket is released by the first report that comes from ANOTHER bucket
+    (buckets hold whole blocks -- FlatParams(group_key=...) -- and a block's launches are issued together, hence all queued by
+    then), or by wait().  With `stream` (a side HIP stream) collective and update are queued there, behind everything the
+    producing streams hold at that moment; the producing streams are never made to wait.  `reduce=False`: a single rank --
+    the hooks only drive the update."""
+
+    def __init__(self, flat: FlatParams, streams: Sequence = (), reduce: bool = True, on_bucket=None, stream=None):
         self.flat = flat
         self.streams = list(streams)     # HIP streams that may hold gradient-producing kernels of one backward pass
+        self.reduce = reduce
+        self.on_bucket = on_bucket
+        self.stream = stream
         self._works: List = []
         self._remaining: List[int] = []
-        self.late_buckets = 0            # buckets whose all-reduce had to be issued by wait() (diagnostic)
+        self.late_buckets = 0            # buckets that were not complete when backward ended (diagnostic)
         self.missing: List[str] = []     # ... and the parameters that had not reported a gradient by then (last occurrence)
         self._seen: List[bool] = []
         self.repeats = set()             # parameters that reported more than once in a step (diagnostic: the contract is once)
         self._warned_late = False
         self._next = 0
+        self.issued_in_backward = 0      # buckets released by a hook (not by wait()) in the last step (diagnostic)
         for i, p in enumerate(flat.params):
             hook = self._make_hook(i)
             p.register_post_accumulate_grad_hook(hook)
@@ -132,17 +167,40 @@ class BucketedGradSync:
         self._seen = [False] * len(self.flat.params)
         self._works = []
         self._next = 0                   # collectives are issued strictly in bucket order: the same order on every rank
+        self.issued_in_backward = 0
+
+    def disarm(self) -> None:
+        """the coming backward is not this sync's business (a captured whole-step graph): hooks do nothing until arm()"""
+        self._remaining = []
 
     def _issue(self, b: int) -> None:
         s, e, _ = self.flat.buckets[b]
-        # a bucket's gradients may come from kernels on different streams (the two head towers run their backward on
-        # two, the backbone's weight gradients trail on a third): the collective is ordered behind ALL of them
+        g = self.flat.grad[s:e]
+        if self.stream is not None:
+            # behind every kernel the producing streams hold now (a bucket's gradients come from kernels on several streams:
+            # the two head towers run their backward on two, the backbone's weight gradients trail on a third)
+            for st in self.streams:
+                self.stream.wait_stream(st)
+            with torch.cuda.stream(self.stream):
+                if self.reduce:
+                    w = all_reduce_sum_(g, async_op=True)
+                    if w is not None:
+                        w.wait()         # (RCCL: orders this stream behind the collective; the host does not block)
+                if self.on_bucket is not None:
+                    self.on_bucket(b)
+            return
         if self.streams:
             cs = torch.cuda.current_stream(self.flat.grad.device)
             for st in self.streams:
                 if st != cs:
                     cs.wait_stream(st)
-        self._works.append(all_reduce_sum_(self.flat.grad[s:e], async_op=True))
+        w = all_reduce_sum_(g, async_op=True) if self.reduce else None
+        if self.on_bucket is not None:
+            if w is not None:
+                w.wait()
+            self.on_bucket(b)
+        elif w is not None:
+            self._works.append(w)
 
     def _make_hook(self, i: int):
         def hook(_p):
@@ -156,17 +214,21 @@ class BucketedGradSync:
             self._remaining[b] -= 1
             # issue every complete bucket at the head of the queue.  A bucket that completes before an earlier one (a
             # parameter without a gradient on THIS rank only) waits for it, so that all ranks enqueue the collectives of
-            # one communicator in the same order whatever their local completion order is
-            while self._next < len(self._remaining) and self._remaining[self._next] == 0:
+            # one communicator in the same order whatever their local completion order is.  With a per-bucket update the
+            # bucket this report belongs to stays queued (see the class docstring)
+            hold = b if self.on_bucket is not None else -1
+            while self._next < len(self._remaining) and self._remaining[self._next] == 0 and self._next != hold:
                 self._issue(self._next)
                 self._next += 1
+                self.issued_in_backward += 1
         return hook
 
-    def wait(self) -> None:
+    def issue_rest(self) -> None:
+        """backward has ended (every producing launch is queued): release what is left, in bucket order"""
         # a bucket whose countdown never reached zero (a parameter without a gradient this step, or a broken
         # "one notification per parameter" contract) would leave rank-local gradients in the flat buffer and let the
-        # ranks diverge silently: the rest of the queue is issued here, in bucket order, behind every producing stream
-        late = len(self._remaining) - self._next if self._remaining else 0
+        # ranks diverge silently: it is issued here all the same
+        late = sum(1 for r in self._remaining[self._next:] if r != 0) if self._remaining else 0
         while self._remaining and self._next < len(self._remaining):
             self._issue(self._next)
             self._next += 1
@@ -179,10 +241,15 @@ class BucketedGradSync:
                 warnings.warn(f"BucketedGradSync: {late} of {len(self._remaining)} gradient buckets were not complete when backward "
                               "ended (a parameter without a gradient this step?); their all-reduce was issued late, in bucket order.  "
                               f"Parameters that did not report a gradient: {self.missing[:8]}{' ...' if len(self.missing) > 8 else ''}")
+        self._remaining = []
+
+    def wait(self) -> None:
+        self.issue_rest()
         for w in self._works:
             w.wait()
         self._works = []
-        self._remaining = []
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.stream)
 
 
 class TeacherGraphs:
@@ -246,7 +313,7 @@ class ERDTrainer:
         self.device = dev
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith("ori_model.")]
         named.reverse()                      # backward order: head first, layer2 last
-        self.flat = FlatParams(named, dev, bucket_mb << 20)
+        self.flat = FlatParams(named, dev, bucket_mb << 20, group_key=self._block_of)
         self.flat.refresh_shadow()
         self.base_lr = lr * (self.world * batch_size_per_gpu / base_batch_size
                              if (auto_scale_lr and batch_size_per_gpu) else 1.0)   # auto_scale_lr (config :116)
@@ -266,12 +333,24 @@ class ERDTrainer:
             p._erd_prep = self.prep          # (kernels._prep_of): several trainers in one process do not see each other's
         if self.prep is not None:
             self.prep.on_stale = self._drop_step_graphs
-        self.sync = None
-        if self.distributed:
-            self.sync = BucketedGradSync(self.flat, streams=[torch.cuda.current_stream(dev), Fn.aux_stream(dev),
-                                                             Fn.trail_stream(dev)])
         self.is_erd = isinstance(model, GFLIncrementERD)
         self.overlap_teacher = overlap_teacher and self.is_erd
+        # the update per gradient bucket, next to the rest of the backward pass (BucketedGradSync): SGD on the bucket's slice
+        # of the flat buffers, then its BN folds and its prepared weight buffers, on a side stream; what is left at the step
+        # boundary is the tail bucket (<= 4 MB).  At one rank too: the ~0.5 ms of update launches leave the critical path
+        self.bucket_update = (os.environ.get("ERD_BUCKET_UPDATE", "1") != "0" and not step_graph and self.prefold is not None
+                              and self.prep is not None)
+        self.sync = None
+        if self.distributed or self.bucket_update:
+            producers = [torch.cuda.current_stream(dev), Fn.aux_stream(dev), Fn.trail_stream(dev)]
+            if self.bucket_update:
+                bucket_of = {id(p): self.flat.bucket_of[i] for i, p in enumerate(self.flat.params)}
+                self.prefold.set_groups(lambda p: bucket_of.get(id(p)))
+                self.prep.group_of = lambda p: bucket_of.get(id(p))
+                self.sync = BucketedGradSync(self.flat, streams=producers, reduce=self.distributed, on_bucket=self._update_bucket,
+                                             stream=torch.cuda.Stream(device=dev))
+            else:
+                self.sync = BucketedGradSync(self.flat, streams=producers)
         self.side = torch.cuda.Stream(device=dev) if self.overlap_teacher else None
         # whole-step hipGraph (one per input shape): everything between two SGD updates -- teacher, ERS, NMS, targets,
         # student forward, losses, backward on all streams -- is recorded once and replayed as ONE launch; the step is
@@ -298,9 +377,35 @@ class ERDTrainer:
             f = self.warmup_start + (1.0 - self.warmup_start) * it / max(self.warmup_iters - 1, 1)
         return self.base_lr * f * epoch_factor
 
+    @staticmethod
+    def _block_of(name: str) -> str:
+        """the unit of the backward pass a parameter belongs to (FlatParams(group_key=...)): a ResNet block (one
+        functional._bottleneck_backward call: resnet.py:263-302), the neck, the head.  Buckets hold whole units"""
+        parts = name.split(".")
+        return ".".join(parts[:3]) if parts[0] == "backbone" and len(parts) > 3 else parts[0]
+
+    def _update_bucket(self, b: int) -> None:
+        """BucketedGradSync.on_bucket: the summed gradient of bucket b is final and every launch that reads the bucket's
+        weights / folded scales / prepared buffers is queued ahead of the current (update) stream"""
+        s, e, _ = self.flat.buckets[b]
+        K.sgd_momentum_(self.flat.data[s:e], self.flat.grad[s:e], self.flat.momentum[s:e], self._pending_lr, self.momentum,
+                        self.weight_decay, 1.0 / self.world, self._first)
+        self.flat.refresh_shadow(b)
+        self.prefold.run_group(b)
+        if self.prefold.valid[0]:
+            self.prep.run_group(b)
+        else:
+            self.prep.invalidate()
+
     def _apply_pending(self) -> None:
-        """wait for the bucket all-reduces of the previous backward, then ONE fused SGD launch."""
+        """wait for the bucket all-reduces of the previous backward, then ONE fused SGD launch -- or, with the per-bucket
+        update, release the buckets that are left (the tail) and join the update stream."""
         if not self._pending:
+            return
+        if self.bucket_update:
+            self.sync.wait()
+            self._first = False
+            self._pending = False
             return
         if self.sync is not None:
             self.sync.wait()
@@ -515,6 +620,7 @@ class ERDTrainer:
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side), torch.no_grad():
                 self._teacher_ahead = (next_batch[0], self._teacher(next_batch[0], next_batch[1], self.iter + 1))
+        self._pending_lr = self.last_lr = self.lr_at(self.iter, self.epoch_factor)      # (per-bucket updates start inside backward)
         if self.sync is not None:
             self.sync.arm()
         total.backward()
@@ -523,7 +629,8 @@ class ERDTrainer:
         self._mark("trail_joined")
         K.zero_arena_end()
         self._pending = True
-        self._pending_lr = self.last_lr = self.lr_at(self.iter, self.epoch_factor)
+        if self.bucket_update:
+            self.sync.issue_rest()        # the tail bucket: queued now, joined by the next step (or flush())
         self.iter += 1
         if not self.overlap_teacher:
             self._apply_pending()

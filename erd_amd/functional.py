@@ -238,16 +238,46 @@ class BnPrefold:
     def run(self) -> None:
         if not self.bns:
             return
-        ptrs = tuple((m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr()) for m in self.bns)
-        if self._ptrs is not None and ptrs != self._ptrs:
+        self._run(self.bns, self.views, self.table, self.max_n, None)
+
+    def set_groups(self, group_of) -> None:
+        """`group_of(gamma parameter) -> int`: run(group) folds only that group's BNs (ERDTrainer: per gradient bucket)"""
+        from ._lib import BnFoldItem
+        import ctypes as C
+        size = C.sizeof(BnFoldItem)
+        self.groups, self.gtables, self._gptrs = {}, {}, {}
+        if not self.bns:
+            return
+        for j, m in enumerate(self.bns):
+            g = group_of(m.weight)
+            self.groups.setdefault(group_of(m.bias) if g is None else g, []).append(j)
+        host = self.table.cpu()
+        for g, js in self.groups.items():
+            sub = torch.cat([host[j * size:(j + 1) * size] for j in js]).to(self.table.device)
+            self.gtables[g] = (sub, [self.bns[j] for j in js], [self.views[j] for j in js], max(self.bns[j].weight.numel() for j in js))
+
+    def run_group(self, g: int) -> None:
+        ent = self.gtables.get(g)
+        if ent is None:
+            return
+        table, bns, views, max_n = ent
+        self._run(bns, views, table, max_n, g)
+
+    def _run(self, bns, views, table, max_n, g) -> None:
+        ptrs = tuple((m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr()) for m in bns)
+        seen = self._ptrs if g is None else self._gptrs.get(g)
+        if seen is not None and ptrs != seen:
             self.valid[0] = False          # re-homed parameters: the device table is stale -> fall back to per-call folds
             return
-        self._ptrs = ptrs
-        K.call("erd_bn_fold_batch", K._p(self.table), len(self.bns), self.max_n, K._stream())
-        for m, (sc, sh) in zip(self.bns, self.views):
-            g, b = m.weight, m.bias
-            g._erd_prefold = ((g.data_ptr(), b.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(), g._version, b._version,
-                               m.running_mean._version, m.running_var._version, m.eps), self.valid, sc, sh)
+        if g is None:
+            self._ptrs = ptrs
+        else:
+            self._gptrs[g] = ptrs
+        K.call("erd_bn_fold_batch", K._p(table), len(bns), max_n, K._stream())
+        for m, (sc, sh) in zip(bns, views):
+            g_, b = m.weight, m.bias
+            g_._erd_prefold = ((g_.data_ptr(), b.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(), g_._version, b._version,
+                                m.running_mean._version, m.running_var._version, m.eps), self.valid, sc, sh)
         self.valid[0] = True
 
 

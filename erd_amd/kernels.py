@@ -628,6 +628,8 @@ class ParamPrep:
         self.recipes: Dict[tuple, _PrepRecipe] = {}
         self.stamp = 0
         self._tables = None
+        self._gtables: Dict[int, list] = {}
+        self.group_of = None             # callable owner parameter -> group (run_group)
         self.on_stale = None             # callable: prepared buffers stopped vouching for the parameters (captured step graphs
                                          # read them by address: the trainer drops those graphs)
 
@@ -652,10 +654,60 @@ class ParamPrep:
             self.recipes.pop(("XT", key[1]), None)
         self.recipes[key] = r
         self._tables = None
+        self._gtables = {}
 
     def invalidate(self) -> None:
         self.stamp += 1
         self._stale()
+
+    def _drop_stale(self, items) -> None:
+        for key, r in items:      # re-homed storage / edited parameters: the recipe is stale
+            if r.src.data_ptr() != r.src_ptr or (r.rowscale is not None and r.rowscale.data_ptr() != r.rs_ptr) or \
+                    r.owner._version != r.version:
+                self.recipes.pop(key, None)
+                if key[0] == "T":
+                    self.recipes.pop(("UT", key[1]), None)
+                    self.recipes.pop(("UT3", key[1]), None)
+                    self.recipes.pop(("XT", key[1]), None)
+                self._tables = None
+                self._gtables = {}
+                self._stale()
+
+    def _build_tables(self, recipes) -> list:
+        from ._lib import WeightPrepItem
+        lib = _lib.load()
+        tables = []
+        for level in (0, 1):
+            rs = [r for r in recipes if r.level == level]
+            if not rs:
+                continue
+            items = (WeightPrepItem * len(rs))()
+            blk = 0
+            for it, r in zip(items, rs):
+                it.w, it.rowscale, it.dst = r.src_ptr, r.rs_ptr, r.out.data_ptr()
+                it.Cout, it.ntaps, it.Cin, it.flip, it.kind, it.block0 = r.Cout, r.ntaps, r.Cin, r.flip, r.kind, blk
+                blk += int(lib.erd_weight_prep_blocks(r.kind, r.Cout, r.ntaps, r.Cin))
+            table = torch.frombuffer(bytearray(bytes(memoryview(items))), dtype=torch.uint8).to(self.device)
+            tables.append((table, len(rs), blk, rs))
+        return tables
+
+    def run_group(self, g: int) -> None:
+        """run() for the recipes of ONE group of parameters (`group_of(owner) == g`; ERDTrainer: a gradient bucket), on the
+        current stream, right after that group's optimizer update and BN fold.  The other groups' buffers keep vouching for
+        their parameters (no stamp change): a trainer that updates per group must run every group once per step."""
+        if self.group_of is None:
+            raise RuntimeError("ParamPrep.run_group: no group_of")
+        if self.stamp == 0:
+            self.stamp = 1
+        mine = [(k, r) for k, r in self.recipes.items() if self.group_of(r.owner) == g]
+        self._drop_stale(mine)
+        tables = self._gtables.get(g)
+        if tables is None:
+            tables = self._gtables[g] = self._build_tables([r for r in self.recipes.values() if self.group_of(r.owner) == g])
+        for table, n, blocks, rs in tables:
+            call("erd_weight_prep_batch", _p(table), n, blocks, _stream())
+            for r in rs:
+                r.stamp = self.stamp
 
     def run(self) -> None:
         """rebuild every registered buffer from the current parameters (call right after the optimizer update, on the
@@ -663,32 +715,9 @@ class ParamPrep:
         self.stamp += 1
         if not self.recipes:
             return
-        for key, r in list(self.recipes.items()):      # re-homed storage / edited parameters: the recipe is stale
-            if r.src.data_ptr() != r.src_ptr or (r.rowscale is not None and r.rowscale.data_ptr() != r.rs_ptr) or \
-                    r.owner._version != r.version:
-                del self.recipes[key]
-                if key[0] == "T":
-                    self.recipes.pop(("UT", key[1]), None)
-                    self.recipes.pop(("UT3", key[1]), None)
-                    self.recipes.pop(("XT", key[1]), None)
-                self._tables = None
-                self._stale()
+        self._drop_stale(list(self.recipes.items()))
         if self._tables is None:
-            from ._lib import WeightPrepItem
-            lib = _lib.load()
-            self._tables = []
-            for level in (0, 1):
-                rs = [r for r in self.recipes.values() if r.level == level]
-                if not rs:
-                    continue
-                items = (WeightPrepItem * len(rs))()
-                blk = 0
-                for it, r in zip(items, rs):
-                    it.w, it.rowscale, it.dst = r.src_ptr, r.rs_ptr, r.out.data_ptr()
-                    it.Cout, it.ntaps, it.Cin, it.flip, it.kind, it.block0 = r.Cout, r.ntaps, r.Cin, r.flip, r.kind, blk
-                    blk += int(lib.erd_weight_prep_blocks(r.kind, r.Cout, r.ntaps, r.Cin))
-                table = torch.frombuffer(bytearray(bytes(memoryview(items))), dtype=torch.uint8).to(self.device)
-                self._tables.append((table, len(rs), blk, rs))
+            self._tables = self._build_tables(list(self.recipes.values()))
         for table, n, blocks, rs in self._tables:
             call("erd_weight_prep_batch", _p(table), n, blocks, _stream())
             for r in rs:

@@ -94,7 +94,7 @@ def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path, H, W, bucket_
         print("rank %d: %d buckets, parameters that reported a gradient more than once in a step (deduplicated by the sync): %s"
               % (r, d["buckets"], d["repeats"][:6]))
         assert d["lrs"] == pytest.approx(lrs, rel=1e-12)
-        assert d["buckets"] >= (4 if bucket_mb == 32 else 20)
+        assert d["buckets"] >= (4 if bucket_mb == 32 else 12)      # whole blocks per bucket
     # ---- C2 / C3 ---------------------------------------------------------------------------------------------------------------
     for it in range(STEPS):
         local, fac = ref_factors[it]

@@ -475,6 +475,48 @@ def test_teacher_look_ahead_waits_for_the_producer_of_the_next_batch():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+def test_per_bucket_update_equals_the_one_launch_update(mode):
+    """ERDTrainer updates per gradient bucket while the rest of the backward pass runs (engine.BucketedGradSync on_bucket: SGD on the
+    bucket's slice, its BN folds, its prepared weights, on a side stream; only the tail bucket is left at the step boundary).  After
+    every step the flat parameters and momenta are BIT-equal to ONE erd_sgd_momentum launch over the whole buffers applied to the
+    state before the step and the gradient the step left in the flat buffer; all buckets but the tail were released inside
+    backward; the look-ahead teacher and the warm-up schedule (a new learning rate every step) go through the same path."""
+    from erd_amd.engine import ERDTrainer
+    from erd_amd import kernels as K
+    tsd, ssd = f7_state_dicts()
+    batches = []
+    for seed in (0, 1):
+        imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=seed)
+        x, metas = O.preprocess(imgs)
+        batches.append((x.cuda(), make_samples(boxes, labels, metas)))
+    K.set_compute(mode)
+    try:
+        model = build_erd(tsd, ssd)
+        tr = ERDTrainer(model, lr=0.02, batch_size_per_gpu=2, auto_scale_lr=False, warmup_iters=5, bucket_mb=1)
+        assert tr.bucket_update and tr.sync is not None and not tr.sync.reduce
+        nb = len(tr.flat.buckets)
+        assert nb >= 4
+        for s, e, mem in tr.flat.buckets:                 # whole blocks per bucket
+            keys = {tr._block_of(tr.flat.names[i]) for i in mem}
+            assert all((tr._block_of(n) in keys) == (i in mem) for i, n in enumerate(tr.flat.names))
+        for i in range(4):
+            d0, m0 = tr.flat.data.clone(), tr.flat.momentum.clone()
+            first = tr._first
+            tr.train_step(*batches[i % 2], next_batch=batches[(i + 1) % 2])
+            assert tr.sync.issued_in_backward == nb - 1 and tr.sync.late_buckets == 0, (tr.sync.issued_in_backward, nb, tr.sync.missing)
+            tr.flush()
+            torch.cuda.synchronize()
+            assert tr.last_lr == pytest.approx(tr.lr_at(i))
+            K.sgd_momentum_(d0, tr.flat.grad.clone(), m0, tr.last_lr, tr.momentum, tr.weight_decay, 1.0, first)
+            assert torch.equal(d0, tr.flat.data) and torch.equal(m0, tr.flat.momentum), i
+            if mode == "bf16":
+                assert torch.equal(tr.flat.data_bf16, tr.flat.data.to(torch.bfloat16))
+        assert not tr._first
+    finally:
+        K.set_compute(K.DEFAULT_COMPUTE)
+
+
 def test_batched_bn_fold_equals_the_per_layer_fold_and_tracks_updates():
     """ERDTrainer folds every trainable frozen-statistics BN of the student in one launch after each optimizer update
     (functional.BnPrefold, erd_bn_fold_batch): the views it hands to the forward pass are bit-equal to a per-layer erd_bn_fold of
