@@ -487,8 +487,8 @@ def main():
             wino_on_bf16 = K.wino_x3()       # "f32x3": the Winograd launches run as wino_x3_kernel (six bf16 limb products per transform-domain product)
             symbols = dict(SYMBOLS)
             if wino_on_bf16:
-                symbols[K.wino_x3_symbol()] = symbols.pop("wino_conv_kernel")
-            wino_sym = K.wino_x3_symbol() if wino_on_bf16 else "wino_conv_kernel"
+                symbols["wino_x3_kernel"] = symbols.pop("wino_conv_kernel")
+            wino_sym = "wino_x3_kernel" if wino_on_bf16 else "wino_conv_kernel"
             groups = {}
             for sym, classes in symbols.items():
                 rs = [ktime[c] for c in classes if c in ktime]

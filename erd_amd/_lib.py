@@ -75,7 +75,6 @@ _SIGNATURES = {
     "erd_to_bf16": [P, P, i64, P],
     "erd_split3": [P, P, i64, P],
     "erd_conv_thin_enable": [i32],
-    "erd_wino_x3_wide": [i32],
     "erd_weight_transpose_x3": [P, P, P, i32, i32, i32, i32, P],
     "erd_wino_weights_elems": [i32, i32],
     "erd_wino_weights": [P, P, i32, i32, i32, P],

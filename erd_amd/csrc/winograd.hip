@@ -1012,10 +1012,11 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
         };
         auto issue_next = [&](float4* dst) {
             if (la_valid) {
-#pragma unroll
 #ifdef ERD_WX3_NORAW       // timing probe: no global loads of the raw patch (results are wrong)
+#pragma unroll
                 for (int i = 0; i < NCH; ++i) dst[i] = make_float4((float)la_soff, 1.f, 2.f, 3.f);
 #else
+#pragma unroll
                 for (int i = 0; i < NCH; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
 #endif
                 la_soff += KS * 4;
@@ -1175,506 +1176,6 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The SIXTEEN-wave form of wino_x3_kernel (8 data + 8 matrix waves, <= 128 registers, one workgroup per CU): the same item,
-// the same LDS layout, the same arithmetic in the same order -- results are BIT-identical to wino_x3_kernel -- with every
-// role split once more: a data wave pair transforms ONE row of the 4 x 4 grid (2 patch rows in, 4 positions out), a matrix
-// wave owns 32 couts x 32 tiles of ONE row (4 positions: 64 accumulator registers; weight-fragment ring two positions deep).
-// Why (tools/valu_rate.hip, tools/lds_rate.hip): a wave alone on its SIMD issues one VALU instruction every ~8 cycles and gets
-// 11-15 B/clk out of the LDS; four waves per SIMD reach one instruction every 2.2-3.5 cycles and 205 B/clk/CU.  The data
-// waves were wino_x3_kernel's critical path (3 240 busy cycles per slice against 1 536 of matrix work).
-// A^T (M A): every matrix wave forms z[c] = (M A)[row][c] locally and publishes it through a 1 KB LDS slot, four registers
-// per round (sent / acked counters per wave: the single slot is rewritten only after its one consumer has read it); wave 1
-// of a cout block finishes y0 = (z0 + z1) + z2, wave 2 y1 = (z1 - z2) - z3; waves 0 and 3 go on to the next item.
-constexpr int W16_RD = 2;
-constexpr int NCW = 2;                         // staged chunks of 512 float4 per slice
-
-__global__ __launch_bounds__(1024) void wino_x3w_kernel(const WinoDesc p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: raw0 | raw1 | V0 | V1 (2 x VX_B) | exchange [8 waves][XCH_B] | sent [8], acked [8] | sh_ss [4][128] | sh_item [2]
-    constexpr unsigned RAWB = RAW_LDS_F4 * 16, VOFF = 2 * RAWB, VB = VX_B, XOFF = VOFF + 2 * VB;
-    volatile int* xsent = reinterpret_cast<volatile int*>(smem + XOFF + 8 * XCH_B);      // rounds a wave has written into its slot
-    volatile int* xack = xsent + 8;                                                          // rounds its consumer has read
-    float* sh_ss = reinterpret_cast<float*>(smem + XOFF + 8 * XCH_B + 64);
-    int* sh_item = reinterpret_cast<int*>(sh_ss + 512);
-
-    const int tid = threadIdx.x;
-    const int Cin = p.Cin;
-    const int nks = Cin / KS;
-    const int nitems = p.nitems;
-    const int ncb32 = (p.Cout + 31) / 32;
-
-    auto decode = [&](int item) {
-        WinoItem it;
-        const int nb = item / p.blocks_per_nb;
-        int b = item - nb * p.blocks_per_nb;
-        int r = 0;
-        while (r + 1 < p.nreg && b >= p.reg[r + 1].block0) ++r;
-        const WinoRegion& rg = p.reg[r];
-        b -= rg.block0;
-        const int per_img = rg.nby * rg.nbx;
-        const int n = b / per_img;
-        const int rem = b - n * per_img;
-        const int by = rem / rg.nbx, bx = rem - by * rg.nbx;
-        const int lbw = rg.lbw;
-        it.s = __builtin_amdgcn_readfirstlane(rg.seg);
-        it.n = __builtin_amdgcn_readfirstlane(n);
-        it.y0 = __builtin_amdgcn_readfirstlane(2 * (rg.ty0 + by * (32 >> lbw)));
-        it.x0 = __builtin_amdgcn_readfirstlane(2 * (rg.tx0 + (bx << lbw)));
-        it.cout0 = __builtin_amdgcn_readfirstlane(nb * BN);
-        it.lbw = __builtin_amdgcn_readfirstlane(lbw);
-        it.yl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].H, 2 * rg.ty1));
-        it.xl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].W, 2 * rg.tx1));
-        return it;
-    };
-    auto claim = [&](int k) -> int {
-        return p.sched ? (int)gridDim.x + atomicAdd(p.sched, 1) : (int)blockIdx.x + (k + 1) * (int)gridDim.x;
-    };
-
-    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const bool is_mma = wave_id >= 8;
-    const int wave = wave_id & 7;
-    const int item0 = blockIdx.x;
-    if (item0 >= nitems) return;
-    if (tid < 16) xsent[tid] = 0;                // (published by the first workgroup barrier, long before the first exchange)
-
-    if (is_mma) {
-        // ------------------------------------------------------------------ matrix waves
-        const int li = lane & 31, h = lane >> 5;
-        const int cb = wave >> 2, ri = wave & 3;          // cout block, row of the 4 x 4 transform grid
-        const bool fin = ri == 1 || ri == 2;              // the waves that finish an output row (1: row 0, 2: row 1)
-        const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void*>(p.U3), 0, (int)((size_t)16 * 3 * ncb32 * nks * 1024), 0x00020000);
-        const unsigned u_lane = (unsigned)lane * 16u;
-        const unsigned per_xl_b = (unsigned)ncb32 * (unsigned)nks * 1024u;          // bytes per (position, limb)
-        const unsigned pos0_b = (unsigned)(ri * 4 * 3) * per_xl_b;                  // this wave's first position
-        // B-fragment address inside a V buffer: (position, limb) block of 1 KB, tile row 32 B, k half h
-        // (layout of a (position, limb) block: [k half h][tile][8 channels = 16 B], the tiles of half 1 XOR 8 -- see the data waves)
-        const unsigned v_lane = (unsigned)(ri * 4 * 3 * 1024 + h * 512 + ((li ^ (h * 8)) * 16));
-        const char* vbase0 = smem + VOFF;
-        char* const xmy = smem + XOFF + wave * XCH_B + lane * 16;
-        // rows arrive from: wave 1 (y0 = (z0 + z1) + z2) <- waves 0 and 2; wave 2 (y1 = (z1 - z2) - z3) <- waves 1 and 3
-        const int wa = 4 * cb + (ri == 1 ? 0 : 1), wb = 4 * cb + (ri == 1 ? 2 : 3);
-        const char* const xa = smem + XOFF + wa * XCH_B + lane * 16;
-        const char* const xb = smem + XOFF + wb * XCH_B + lane * 16;
-        int xr = 0;                                                                 // exchange rounds done
-
-        WinoItem cur = decode(item0);
-        int k_item = 0;
-        unsigned long long t_bar = 0, t_out = 0, t_xch = 0; (void)t_bar; (void)t_out; (void)t_xch;
-        ERD_T0(t_begin);
-        unsigned u_item = (unsigned)__builtin_amdgcn_readfirstlane(((cur.cout0 >> 5) + cb) * nks * 1024);   // byte offset of (cout block, ks = 0) inside a plane
-        f32x16 acc[4];
-        u32x4 ub[W16_RD][3];                                                             // weight-fragment ring: position q lives in slot q mod W16_RD
-        bf16x8 vf[2][3];                                                            // tile fragments [position parity][limb]
-        auto load_u = [&](const int q, const unsigned soff) {                      // q: compile-time after unrolling
-#pragma unroll
-            for (int l = 0; l < 3; ++l)
-                ub[q & (W16_RD - 1)][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)(q * 3 + l) * per_xl_b + soff, 0);
-        };
-#pragma unroll
-        for (int q = 0; q < W16_RD; ++q) load_u(q, u_item);
-        __syncthreads();                                    // P   (data waves: raw slice 0 is in LDS)
-        __syncthreads();                                    // B_0 (V(0) complete)
-#pragma unroll
-        for (int l = 0; l < 3; ++l) vf[0][l] = *reinterpret_cast<const bf16x8*>(vbase0 + v_lane + l * 1024);
-        int g = 0;
-        for (;;) {
-            const int nxt_item = __builtin_amdgcn_readfirstlane(sh_item[(k_item + 1) & 1]);
-            const bool has_next = nxt_item < nitems;
-            const WinoItem nxt = has_next ? decode(nxt_item) : cur;
-            const unsigned u_next = (unsigned)__builtin_amdgcn_readfirstlane(((nxt.cout0 >> 5) + cb) * nks * 1024);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-            for (int ks = 0; ks < nks; ++ks, ++g) {
-                const char* vc = vbase0 + v_lane + ((g & 1) ? VB : 0);
-                const char* vn = vbase0 + v_lane + ((g & 1) ? 0 : VB);
-                int lastflag = __builtin_amdgcn_readfirstlane(ks + 1 == nks ? 1 : 0);
-                asm volatile("" : "+s"(lastflag));          // (opaque: keeps the compiler from peeling the last slice)
-                const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(u_item + (unsigned)ks * 1024u));
-                const unsigned u_reload = (unsigned)__builtin_amdgcn_readfirstlane(
-                    (int)(lastflag ? u_next : u_item + (unsigned)(ks + 1) * 1024u));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q == 3) {                           // B_{g+1}: V(g+1) complete; every read of V(g) has been issued
-                        ERD_T0(tb);
-                        __syncthreads();
-                        ERD_TACC(t_bar, tb);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    const char* src = q < 3 ? vc + (q + 1) * 3 * 1024 : vn;
-#pragma unroll
-                    for (int l = 0; l < 3; ++l) vf[(q + 1) & 1][l] = *reinterpret_cast<const bf16x8*>(src + l * 1024);
-                    __builtin_amdgcn_sched_barrier(0);      // reads first: they travel behind this position's MFMAs
-                    const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[q & (W16_RD - 1)][0]), um = __builtin_bit_cast(bf16x8, ub[q & (W16_RD - 1)][1]),
-                                 ul = __builtin_bit_cast(bf16x8, ub[q & (W16_RD - 1)][2]);
-                    const bf16x8 vh = vf[q & 1][0], vm = vf[q & 1][1], vl = vf[q & 1][2];
-                    // rows = couts (U), columns = tiles (V); smallest terms first, as everywhere in the three-limb kernels
-#ifdef ERD_WX3_NOMFMA       // timing probe: everything but the matrix instructions (results are wrong)
-                    acc[q][0] += __builtin_bit_cast(float4, ul).x * __builtin_bit_cast(float4, vh).x + __builtin_bit_cast(float4, um).x * __builtin_bit_cast(float4, vm).x +
-                                 __builtin_bit_cast(float4, uh).x * __builtin_bit_cast(float4, vl).x;
-#else
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[q], 0, 0, 0);
-#endif
-                    // the slot is free: position q + 2 of this slice, or position q - 2 of the next one
-#ifndef ERD_WX3_NOLOAD      // (timing probe: the ring keeps the first slice's fragments)
-                    if (q + W16_RD < 4) load_u(q + W16_RD, u_cur); else load_u(q + W16_RD - 4, u_reload);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // ---- output stage: z[i][c] = (M A)[i][c] for this wave's two rows, one row swapped with the partner wave, y = A^T z
-            ERD_T0(to);
-            {
-                const WinoSeg& sg = p.seg[cur.s];
-                const float* ss = sh_ss + (k_item & 3) * 128;
-                const int lbw = cur.lbw, bwm = (1 << lbw) - 1;
-                const int ty = li >> lbw, tx = li & bwm;
-                const int oy = cur.y0 + 2 * ty + (ri - 1);                    // waves 1 / 2 finish output row 0 / 1 of every tile
-                const bool simple = !sg.res && !sg.mask && !p.colsum;
-                const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-                    sg.out, 0, (int)((long long)sg.N * sg.out_nstride * 4), 0x00020000);
-                const float lo = p.relu ? 0.f : -__builtin_inff();
-                float4 cs[4];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) cs[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
-                // z[c] = (M A)[ri][c] of this wave's row: the accumulators die here
-                f32x16 z[2];
-                z[0] = (acc[0] + acc[1]) + acc[2];
-                z[1] = (acc[1] - acc[2]) - acc[3];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const f32x16 zc = z[c];
-                    const int ox = cur.x0 + 2 * tx + c;
-                    const bool pix_ok = oy < cur.yl && ox < cur.xl;
-                    const int64_t opix = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {      // one round = registers 4 gq .. 4 gq + 3 = couts 8 gq + 4 h + {0..3} of the block:
-                                                          // published, (waves 1 / 2) received, finished and stored before the next round
-                        ERD_T0(tx_);
-                        while (xack[wave] < xr) __builtin_amdgcn_s_sleep(1);   // (one slot per wave: the previous round has been read)
-                        *reinterpret_cast<float4*>(xmy) = make_float4(zc[4 * gq], zc[4 * gq + 1], zc[4 * gq + 2], zc[4 * gq + 3]);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (lane == 0) xsent[wave] = xr + 1;
-                        if (!fin) { ++xr; ERD_TACC(t_xch, tx_); continue; }
-                        while (xsent[wa] < xr + 1) __builtin_amdgcn_s_sleep(1);
-                        const float4 r0 = *reinterpret_cast<const float4*>(xa);
-                        while (xsent[wb] < xr + 1) __builtin_amdgcn_s_sleep(1);
-                        const float4 r1 = *reinterpret_cast<const float4*>(xb);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (lane == 0) { xack[wa] = xr + 1; xack[wb] = xr + 1; }
-                        ++xr;
-                        ERD_TACC(t_xch, tx_);
-                        // wave 1: y[0][c] = (z0 + z1) + z2 ; wave 2: y[1][c] = (z1 - z2) - z3   (the fp32 kernel's order)
-                        float4 yv;
-                        if (ri == 1) yv = make_float4((r0.x + zc[4 * gq]) + r1.x, (r0.y + zc[4 * gq + 1]) + r1.y, (r0.z + zc[4 * gq + 2]) + r1.z,
-                                                      (r0.w + zc[4 * gq + 3]) + r1.w);
-                        else yv = make_float4((r0.x - zc[4 * gq]) - r1.x, (r0.y - zc[4 * gq + 1]) - r1.y, (r0.z - zc[4 * gq + 2]) - r1.z,
-                                              (r0.w - zc[4 * gq + 3]) - r1.w);
-                        const int cl = 32 * cb + 8 * gq + 4 * h;              // 0..63 inside the item's cout block
-                        const int co0 = cur.cout0 + cl;
-                        const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
-                        const float4 sh = *reinterpret_cast<const float4*>(ss + 64 + cl);
-                        float4 v = make_float4(yv.x * sc.x + sh.x, yv.y * sc.y + sh.y, yv.z * sc.z + sh.z, yv.w * sc.w + sh.w);
-                        if (simple && (p.Cout & 3) == 0) {
-                            const bool ok = pix_ok && co0 < p.Cout;
-                            u32x4 o;
-                            o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
-                            o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
-                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
-                        } else if (pix_ok && co0 < p.Cout) {
-                            const int64_t o = opix + co0;
-                            if ((p.Cout & 3) == 0) {
-                                if (sg.res) v = f4add(v, *reinterpret_cast<const float4*>(sg.res + o));
-                                if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                                if (sg.mask) {
-                                    const float4 mk = *reinterpret_cast<const float4*>(sg.mask + o);
-                                    v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
-                                                    mk.w > 0.f ? v.w : 0.f);
-                                }
-                                *reinterpret_cast<float4*>(sg.out + o) = v;
-                            } else {
-                                float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    if (co0 + r < p.Cout) {
-                                        float e = vv[r];
-                                        if (sg.res) e += sg.res[o + r];
-                                        if (p.relu) e = fmaxf(e, 0.f);
-                                        if (sg.mask) e = sg.mask[o + r] > 0.f ? e : 0.f;
-                                        sg.out[o + r] = e;
-                                        vv[r] = e;
-                                    } else vv[r] = 0.f;
-                                }
-                                v = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                            }
-                            cs[gq] = f4add(cs[gq], v);
-                        }
-                    }
-                }
-                if (p.colsum && fin) {                                        // (Cout % 4 == 0 is required with colsum)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) {
-                            cs[gq].x += __shfl_xor(cs[gq].x, o, 64); cs[gq].y += __shfl_xor(cs[gq].y, o, 64);
-                            cs[gq].z += __shfl_xor(cs[gq].z, o, 64); cs[gq].w += __shfl_xor(cs[gq].w, o, 64);
-                        }
-                        const int co0 = cur.cout0 + 32 * cb + 8 * gq + 4 * h;
-                        if (li == 0 && co0 < p.Cout) {
-                            float* cp = p.colsum + (p.colsum_copies > 1 ? (blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) + co0;
-                            atomicAdd(cp + 0, cs[gq].x); atomicAdd(cp + 1, cs[gq].y); atomicAdd(cp + 2, cs[gq].z); atomicAdd(cp + 3, cs[gq].w);
-                        }
-                    }
-                }
-            }
-            ERD_TACC(t_out, to);
-            if (!has_next) {
-#ifdef ERD_WINO_TRACE
-                if (wave == 0 && lane == 0 && blockIdx.x < 256) {
-                    g_wino_trace[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime() - t_begin;
-                    g_wino_trace[blockIdx.x * 8 + 1] = t_bar;
-                    g_wino_trace[blockIdx.x * 8 + 2] = t_out;
-                    g_wino_trace[blockIdx.x * 8 + 3] = t_xch;             // (x3: the exchange polls inside the output stage, not the item count)
-                }
-#endif
-                if (wave == 0 && lane == 0 && p.sched) {     // the last workgroup to leave re-arms the counters
-                    if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
-                }
-                break;
-            }
-            cur = nxt;
-            u_item = u_next;
-            ++k_item;
-        }
-    } else {
-        // ------------------------------------------------------------------ data waves: eight, one row of the transform grid per
-        // pair of waves (wino_x3_kernel's data waves transform two rows each)
-        __builtin_amdgcn_s_setprio(ERD_WINO_DATA_PRIO);
-        const int dt = tid & 511;
-        const int t_chunk = dt & 3, t_tile = (dt >> 2) & 31, t_row = __builtin_amdgcn_readfirstlane(dt >> 7);   // row of the transform grid
-        WinoItem la = decode(item0);
-        unsigned long long t_bar = 0, t_ent = 0, t_wait = 0; (void)t_bar; (void)t_ent; (void)t_wait;
-        ERD_T0(t_begin);
-        int la_ks = 0, k_la = 0;
-        unsigned la_soff = 0;
-        bool la_valid = true;
-        int slices_total = nks;
-        unsigned roff[NCW];
-        float4 rv[NCW], rvb[NCW];
-        __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0].in), 0, 0, 0x00020000);
-        float pend_sc = 1.f, pend_sh = 0.f;
-        int pend_claim = 0, pend_k = -1;
-        unsigned rd0 = 0, rd1 = 0, rd2 = 0;
-        unsigned nrd0 = 0, nrd1 = 0, nrd2 = 0;
-        int tr_left = 0;
-        WinoItem nx_it = la;
-        bool nx_valid = false;
-        unsigned nx_roff[NCW], nx_rd0 = 0, nx_rd1 = 0, nx_rd2 = 0;
-        __amdgpu_buffer_rsrc_t nx_rs = rs_in;
-        auto item_geometry = [&](const WinoItem& it, unsigned (&ro)[NCW], unsigned& g0, unsigned& g1, unsigned& g2,
-                                 __amdgpu_buffer_rsrc_t& rs) {
-            const WinoSeg& sg = p.seg[it.s];
-            rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
-            const int lbw = it.lbw, bw = 1 << lbw, bh = 32 >> lbw;
-            const int pc_n = 2 * bw + 2, npix = (2 * bh + 2) * pc_n;
-            const int recip = (65536 + pc_n - 1) / pc_n;
-            const unsigned base_n = (unsigned)(it.n * sg.in_nstride);
-#pragma unroll
-            for (int i = 0; i < NCW; ++i) {
-                const int idx = dt + 512 * i;
-                const int chunk = idx & 3, pix = idx >> 2;
-                const int pr = (pix * recip) >> 16, pc = pix - pr * pc_n;
-                const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
-                ro[i] = OOBV;
-                if (pix < npix && (unsigned)iy < (unsigned)sg.H && (unsigned)ix < (unsigned)sg.W)
-                    ro[i] = (base_n + (unsigned)((iy * sg.W + ix) * Cin + chunk * 4)) * 4u;
-            }
-            const int t_ty = t_tile >> lbw, t_tx = t_tile & (bw - 1);
-            // row t_row of B^T d needs two patch rows: d0 - d2, d1 + d2, d2 - d1, d1 - d3
-            const int ra_ = t_row == 0 ? 0 : 1, rb_ = t_row == 3 ? 3 : 2;
-            g0 = (unsigned)((((2 * t_ty + ra_) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
-            g1 = (unsigned)((((2 * t_ty + rb_) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
-            g2 = 0;
-        };
-        auto request_item_data = [&]() {
-            if (dt < 64) {
-                const int co = la.cout0 + dt;
-                pend_sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
-                pend_sh = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
-            }
-            if (dt == 64) pend_claim = claim(k_la);
-            pend_k = k_la;
-        };
-        auto flush_pending = [&]() {
-            if (pend_k >= 0) {
-                if (dt < 64) {
-                    float* ss = sh_ss + (pend_k & 3) * 128;
-                    ss[dt] = pend_sc;
-                    ss[64 + dt] = pend_sh;
-                }
-                if (dt == 64) sh_item[(pend_k + 1) & 1] = pend_claim;
-                pend_k = -1;
-            }
-        };
-        auto issue_next = [&](float4* dst) {
-            if (la_valid) {
-#pragma unroll
-                for (int i = 0; i < NCW; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
-                la_soff += KS * 4;
-                ++la_ks;
-                if (la_ks == 3) {
-                    const int nx = __builtin_amdgcn_readfirstlane(sh_item[(k_la + 1) & 1]);
-                    nx_valid = nx < nitems;
-                    if (nx_valid) nx_it = decode(nx);
-                }
-                if (la_ks == 4 && nx_valid) item_geometry(nx_it, nx_roff, nx_rd0, nx_rd1, nx_rd2, nx_rs);
-                if (la_ks == nks) {
-                    if (nx_valid) {
-                        la = nx_it;
-                        rs_in = nx_rs;
-#pragma unroll
-                        for (int i = 0; i < NCW; ++i) roff[i] = nx_roff[i];
-                        nrd0 = nx_rd0; nrd1 = nx_rd1; nrd2 = nx_rd2;
-                        la_ks = 0;
-                        la_soff = 0;
-                        ++k_la;
-                        slices_total += nks;
-                        request_item_data();
-                    } else la_valid = false;
-                }
-            }
-        };
-        char* const sm = smem;
-        const unsigned st_base = (unsigned)(((dt >> 2) * RCS + (dt & 3)) * 16);
-        // this thread's 8 bytes inside a (position, limb) block: tile row 32 B, channels 4 t_chunk .. + 3
-        // V block of a (position, limb): 1 KB = [k half h = channel / 8][tile 32][16 B].  A matrix wave's B-fragment read (lane = tile,
-        // h) then covers 256 CONTIGUOUS bytes per 16-lane service group -- with 32-byte tile rows ([tile][16 channels]) the sixteen
-        // 16-byte pieces of a group were spread over 512 bytes and every bank was hit twice.  The tiles of half 1 are XORed with 8
-        // so that the 8-byte stores of a data wave's 16-lane group (4 tiles x 4 channel quads: both halves) land on different banks.
-        const unsigned wr_base = VOFF + (unsigned)((t_chunk >> 1) * 512 + ((t_tile ^ ((t_chunk >> 1) * 8)) * 16) + (t_chunk & 1) * 8);
-        auto store_raw = [&](const float4* src, auto par_tag) {
-            constexpr unsigned PAR = decltype(par_tag)::value;
-#pragma unroll
-            for (int i = 0; i < NCW; ++i) *reinterpret_cast<float4*>(sm + PAR * RAWB + st_base + i * (128 * RCS * 16)) = src[i];
-        };
-        auto put = [&](char* dst, const float4 v) {        // four channels of one position -> three limb words of 8 bytes
-            uint2 hi, mid, lo;
-#ifdef ERD_WX3_NOSPLIT      // timing probe (tools/build_probe.sh): what the limb split costs the data waves (results are wrong)
-            hi.x = __builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u);
-            hi.y = __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u);
-            mid = hi; lo = hi;
-#else
-            erd::limbs3_pair(v.x, v.y, hi.x, mid.x, lo.x);
-            erd::limbs3_pair(v.z, v.w, hi.y, mid.y, lo.y);
-#endif
-            *reinterpret_cast<uint2*>(dst) = hi;
-            *reinterpret_cast<uint2*>(dst + 1024) = mid;
-            *reinterpret_cast<uint2*>(dst + 2048) = lo;
-        };
-        // the transform in two halves so that its 12 LDS reads can be issued BEFORE the raw store / next loads of the same
-        // iteration (they touch the other raw buffer) and travel under them: (1) the patch rows of this thread's (tile, 4 channels)
-        float4 pd[2][4];
-        auto transform_read = [&](auto rpar_tag) {
-            constexpr unsigned RPAR = decltype(rpar_tag)::value;
-            const char* r0 = sm + RPAR * RAWB + rd0;
-            const char* r1 = sm + RPAR * RAWB + rd1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                pd[0][c] = *reinterpret_cast<const float4*>(r0 + c * (RCS * 16));
-                pd[1][c] = *reinterpret_cast<const float4*>(r1 + c * (RCS * 16));
-            }
-            if (--tr_left == 0) {                             // the next slice belongs to the item the pointer entered last
-                rd0 = nrd0;
-                rd1 = nrd1;
-                rd2 = nrd2;
-                tr_left = nks;
-            }
-        };
-        // (2) row t_row of B^T d B (positions 4 t_row .. + 3), split into limbs, into V buffer VPAR
-        auto transform_write = [&](auto vpar_tag) {
-            constexpr unsigned VPAR = decltype(vpar_tag)::value;
-            float4 rr[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 da = pd[0][c], db = pd[1][c];
-                if (t_row == 1) rr[c] = f4add(da, db);
-                else if (t_row == 2) rr[c] = f4sub(db, da);
-                else rr[c] = f4sub(da, db);
-            }
-            char* v = sm + wr_base + VPAR * VB + (t_row * 4) * 3 * 1024;      // positions 3 KB apart
-            put(v + 0 * 3072, f4sub(rr[0], rr[2]));
-            put(v + 1 * 3072, f4add(rr[1], rr[2]));
-            put(v + 2 * 3072, f4sub(rr[2], rr[1]));
-            put(v + 3 * 3072, f4sub(rr[1], rr[3]));
-        };
-        using P0 = std::integral_constant<unsigned, 0>;
-        using P1 = std::integral_constant<unsigned, 1>;
-        auto run = [&]() {
-#pragma unroll
-            for (int i = 0; i < NCW; ++i) { rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rvb[i] = rv[i]; }
-            item_geometry(la, roff, nrd0, nrd1, nrd2, rs_in);
-            request_item_data();
-            rd0 = nrd0;
-            rd1 = nrd1;
-            rd2 = nrd2;
-            tr_left = nks;
-            flush_pending();
-            issue_next(rv);
-            issue_next(rvb);
-            store_raw(rv, P0{});
-            __syncthreads();                                  // P
-            transform_read(P0{});
-            transform_write(P0{});
-            store_raw(rvb, P1{});
-            flush_pending();
-            issue_next(rv);
-            __syncthreads();                                  // B_0
-            auto iter = [&](auto par_tag, auto npar_tag) {
-                ERD_T0(ts);
-                transform_read(npar_tag);                     // raw(g+1): requested first, consumed after the store / issue below
-                __builtin_amdgcn_sched_barrier(0);
-                store_raw(rv, par_tag);
-                flush_pending();
-                issue_next(rv);
-                ERD_TACC(t_ent, ts);
-                ERD_T0(tt);
-                transform_write(npar_tag);
-#ifdef ERD_WINO_TRACE
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                ERD_TACC(t_wait, tt);
-                ERD_T0(tb);
-                __syncthreads();                              // B_{g+1}
-                ERD_TACC(t_bar, tb);
-            };
-            for (int g = 0;;) {
-                if (g >= slices_total) break;
-                iter(P0{}, P1{});
-                if (++g >= slices_total) break;
-                iter(P1{}, P0{});
-                ++g;
-            }
-        };
-        run();
-#ifdef ERD_WINO_TRACE
-        if (wave == 0 && lane == 0 && blockIdx.x < 256) {
-            g_wino_trace[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime() - t_begin;
-            g_wino_trace[blockIdx.x * 8 + 5] = t_bar;
-            g_wino_trace[blockIdx.x * 8 + 6] = t_ent;
-            g_wino_trace[blockIdx.x * 8 + 7] = t_wait;
-        }
-#endif
-    }
-}
-
 __global__ __launch_bounds__(256) void wino_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ U3, int Cout,
                                                               int Cin, int flip) {
     const int cop = (Cout + 31) / 32 * 32;
@@ -1701,11 +1202,6 @@ extern "C" int erd_wino_trace(unsigned long long* out) {       // debug builds o
 #endif
 
 extern "C" size_t erd_wino_weights_elems(int Cout, int Cin) { return (size_t)16 * ((Cout + 15) / 16 * 16) * Cin; }
-
-// the three-limb launches run the sixteen-wave kernel (wino_x3w_kernel) unless ERD_WINO_WIDE=0 / erd_wino_x3_wide(0): the
-// eight-wave wino_x3_kernel gives bit-identical results and stays as the reference of that claim (tests/test_gpu_wino_x3.py)
-int g_x3_wide = getenv("ERD_WINO_WIDE") ? atoi(getenv("ERD_WINO_WIDE")) : 1;
-
 
 namespace {
 // the launch both forms share: descriptor (segments, block regions, item count) and the persistent grid
@@ -1792,16 +1288,6 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
     if (persist != 1) d.sched = nullptr;
-    if (U3 && g_x3_wide) {
-        const size_t lds = (size_t)2 * RAW_LDS_F4 * sizeof(float4) + 2 * VX_B + 8 * XCH_B + 64 + 2048 + 16;
-        static bool attrw_done = false;
-        if (!attrw_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attrw_done = true;
-        }
-        hipLaunchKernelGGL(wino_x3w_kernel, dim3((unsigned)grid), dim3(1024), lds, stream, d);
-        return erd::check_launch("wino_conv3x3_x3w");
-    }
     if (U3) {
         const size_t lds = (size_t)2 * RAW_LDS_F4 * sizeof(float4) + 2 * VX_B + 4 * 2 * XCH_B + 64 + 2048 + 16;
         static bool attr3_done = false;
@@ -1829,12 +1315,6 @@ extern "C" int erd_wino_conv3x3(const erd_conv_seg* segs, int nseg, const float*
                                 int* sched, erd_stream_t stream) {
     ERD_REQUIRE(U, "wino: null U");
     return wino_launch(segs, nseg, U, nullptr, Cin, Cout, scale, shift, relu, colsum, colsum_copies, sched, (hipStream_t)stream);
-}
-
-extern "C" int erd_wino_x3_wide(int on) {
-    const int prev = g_x3_wide;
-    if (on >= 0) g_x3_wide = on ? 1 : 0;
-    return prev;
 }
 
 extern "C" size_t erd_wino_weights_x3_elems(int Cout, int Cin) { return (size_t)16 * 3 * ((Cout + 31) / 32 * 32) * Cin; }

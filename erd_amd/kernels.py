@@ -489,11 +489,6 @@ def wino_x3() -> bool:
     return WINO_X3 and COMPUTE == "f32x3"
 
 
-def wino_x3_symbol() -> str:
-    """the kernel symbol behind erd_wino_conv3x3_x3 in this process (rocprof's name): the sixteen-wave kernel unless switched off"""
-    return "wino_x3w_kernel" if _lib.load().erd_wino_x3_wide(-1) else "wino_x3_kernel"
-
-
 def wino_weights(w_ohwi: Tensor, flip: bool = False, x3: Optional[bool] = None) -> Tensor:
     """U = G g G^T of a [Cout,3,3,Cin] weight in the layout erd_wino_conv3x3 streams (flip: taps reversed, for the
     input-gradient form on transposed weights); x3 (default: wino_x3()): the bf16 limb image erd_wino_conv3x3_x3 streams"""

@@ -155,11 +155,6 @@ size_t erd_wino_weights_x3_elems(int Cout, int Cin);
 int erd_wino_weights_x3(const float* w_ohwi, void* U3, int Cout, int Cin, int flip, erd_stream_t stream);
 int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout, const float* scale,
                         const float* shift, int relu, float* colsum, int colsum_copies, int* sched, erd_stream_t stream);
-/* The three-limb Winograd launches run a sixteen-wave kernel (wino_x3w_kernel: 8 data + 8 matrix waves, one row of the
- * 4 x 4 transform grid per wave pair / matrix wave) whose results are bit-identical to the eight-wave wino_x3_kernel.
- * on = 0 / 1 picks the kernel for the process (A/B runs and the bit-identity test), on < 0 only queries; returns the
- * previous setting.  Default: on (environment ERD_WINO_WIDE=0: off). */
-int erd_wino_x3_wide(int on);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).

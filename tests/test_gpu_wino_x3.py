@@ -110,60 +110,3 @@ def test_wino_x3_full_size_head_tower_launch_runs_twice_identically(K):
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0] - outs[2]).norm() / outs[2].norm()) < 2e-6
-
-
-def _wide(on):
-    from erd_amd import _lib
-    return _lib.load().erd_wino_x3_wide(on)
-
-
-@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES + [(4, 256, 256, 100, 168)])
-def test_sixteen_wave_kernel_is_bit_identical_to_the_eight_wave_kernel(K, N, Cin, Cout, H, W):
-    """wino_x3w_kernel (8 data + 8 matrix waves: one row of the 4 x 4 transform grid per wave pair / matrix wave, the default) performs
-    wino_x3_kernel's arithmetic in wino_x3_kernel's order: every form -- plain, folded BN + ReLU, residual aliasing the output +
-    ReLU mask + column sums -- on every block shape of the cover must agree BIT for bit (column sums: float atomics, to rounding)."""
-    xg = G.randn(71, N, H, W, Cin).cuda()
-    wg = G.randn(72, Cout, 3, 3, Cin, scale=(2.0 / (Cin * 9)) ** 0.5).cuda()
-    scale, shift = (0.5 + G.rand(73, Cout)).cuda(), G.randn(74, Cout, scale=0.1).cuda()
-    base, mask = G.randn(75, N, H, W, Cout).cuda(), G.randn(76, N, H, W, Cout).cuda()
-    U = K.wino_weights(wg, x3=True)
-    prev = _wide(-1)
-    res = []
-    try:
-        for on in (1, 0, 1):
-            _wide(on)
-            out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
-            K.wino_conv3x3([xg], U, [out], Cout)
-            out2 = torch.empty_like(out)
-            K.wino_conv3x3([xg], U, [out2], Cout, scale=scale, shift=shift, relu=True)
-            out3, cs = base.clone(), torch.zeros(Cout, device="cuda")
-            if Cout % 4 == 0:
-                K.wino_conv3x3([xg], U, [out3], Cout, res=[out3], mask=[mask], colsum=cs)
-            res.append((out, out2, out3, cs))
-    finally:
-        _wide(prev)
-    for r in (res[1], res[2]):
-        assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) and torch.equal(res[0][2], r[2])
-        assert torch.allclose(res[0][3], r[3], rtol=1e-5, atol=1e-3)
-    assert not torch.isnan(res[0][0]).any()
-
-
-def test_sixteen_wave_kernel_on_the_head_levels_launch(K):
-    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
-    N, Cc = 4, 256
-    A = sum(h * w for h, w in sizes)
-    from erd_amd.kernels import level_views
-    xg = G.randn(61, N, A, Cc).cuda()
-    wg = G.randn(62, Cc, Cc, 3, 3, scale=(2.0 / (Cc * 9)) ** 0.5).permute(0, 2, 3, 1).contiguous().cuda()
-    U = K.wino_weights(wg, x3=True)
-    prev = _wide(-1)
-    outs = []
-    try:
-        for on in (1, 0, 1):
-            _wide(on)
-            out = torch.empty((N, A, Cc), device="cuda")
-            K.wino_conv3x3(level_views(xg, sizes), U, level_views(out, sizes), Cc)
-            outs.append(out)
-    finally:
-        _wide(prev)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
