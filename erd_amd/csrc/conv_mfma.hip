@@ -647,13 +647,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
         constexpr int SLD = BN + 4;
         constexpr int C4N = BN / 4;                             // float4 columns of the tile
         constexpr int RPS = NT / C4N;                     // rows stored per sweep
-        bool wave_epilogue_done = false;
         if constexpr (X3) {
             // f32x3 (4 x 1 waves): every wave owns 32 complete output rows, so it stages them in its OWN LDS block and writes them
             // out by itself -- all four waves at once and without workgroup barriers between passes (the shared form below is
             // four sequential passes with two barriers each: 14 k of a tile's 56 k cycles on the K = 256 layers).
             {   // (Cout % 4 == 0: erd_conv_igemm sends other launches to the fp32 kernel)
-                wave_epilogue_done = true;
                 __syncthreads();                                // the row table behind the staging blocks is complete
                 float* wst = reinterpret_cast<float*>(smem + wave * WSTAGE_BYTES);
                 constexpr int RPW = 64 / C4N, NIT = 32 / RPW;   // rows per wave-instruction, instructions per block

@@ -866,7 +866,7 @@ extern "C" int erd_gn_relu_fwd(const void* c, void* y, const float* gamma, const
     const GnChunks ch = make_chunks(lv);
     const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
-    hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
+    ERD_ZERO_ASYNC(stats_ws, sizeof(double) * 2 * nst, st);
 #ifndef ERD_GN_NOSTATS      // timing probe (tools/build_probe.sh): the upper bound of what statistics fused into the producing
                             // convolution's output stage could save -- the pass is simply not run (results are wrong)
     ERD_MAP(map_type, hipLaunchKernelGGL((gn_stats_kernel<256, 32, T>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st,
@@ -889,7 +889,7 @@ extern "C" int erd_gn_relu_bwd(const void* c, const void* dy, const float* gamma
     const GnChunks ch = make_chunks(lv);
     const GnChunks chs = make_chunks(lv, GN_STAT_ROWS);
     const int nst = N * lv->nseg * G;
-    hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * nst, st);
+    ERD_ZERO_ASYNC(stats_ws, sizeof(double) * 2 * nst, st);
     ERD_MAP(map_type, hipLaunchKernelGGL((gn_bwd_stats_kernel<256, 32, T>), dim3(chs.start[lv->nseg], N, 4), dim3(256), 0, st,
                                          (const T*)c, (const T*)dy, gamma, beta, mean_rstd, stats_ws, dgamma, dbeta, A, *lv, chs));
     ERD_MAP(map_type, hipLaunchKernelGGL((gn_bwd_apply_kernel<256, 32, T>), dim3(ch.start[lv->nseg], N), dim3(256), 0, st,
@@ -918,7 +918,7 @@ extern "C" int erd_upsample2x_add_bwd(const void* dfine, void* dcoarse, int N, i
 extern "C" int erd_colsum(const void* x, int64_t rows, int C, float* out, int accumulate, int map_type, erd_stream_t stream) {
     ERD_REQUIRE(x && out && C > 0 && ERD_MAP_OK(map_type), "colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * C, st);
+    if (!accumulate) ERD_ZERO_ASYNC(out, sizeof(float) * C, st);
     if (rows == 0) return 0;
     int rpb = 64;
     while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
@@ -941,7 +941,7 @@ extern "C" int erd_level_scale_bwd(const float* x, const float* dy, const float*
     ERD_REQUIRE(x && dy && alphas && dx && dalphas && lv, "level_scale_bwd: null");
     hipStream_t st = (hipStream_t)stream;
     const GnChunks ch = make_chunks(lv);
-    hipMemsetAsync(dalphas, 0, sizeof(float) * lv->nseg, st);
+    ERD_ZERO_ASYNC(dalphas, sizeof(float) * lv->nseg, st);
     hipLaunchKernelGGL(level_scale_bwd_kernel, dim3(ch.start[lv->nseg], N), dim3(256), 0, st, x, dy, alphas, dx,
                        dalphas, A, C, *lv, ch);
     return erd::check_launch("level_scale_bwd");

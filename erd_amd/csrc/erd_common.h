@@ -32,6 +32,16 @@ inline int check_launch(const char* what) {
         }                                 \
     } while (0)
 
+// hipMemsetAsync(p, 0, bytes) whose failure is reported like a failed launch (the entry point returns the HIP error code)
+#define ERD_ZERO_ASYNC(p, bytes, st)                                           \
+    do {                                                                       \
+        const hipError_t e_ = hipMemsetAsync((p), 0, (bytes), (st));           \
+        if (e_ != hipSuccess) {                                                \
+            erd::set_error("hipMemsetAsync: %s", hipGetErrorString(e_));       \
+            return (int)e_;                                                    \
+        }                                                                      \
+    } while (0)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

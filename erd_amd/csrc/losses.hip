@@ -758,7 +758,7 @@ extern "C" int erd_ers_select(const float* cls, const float* bbox, int N, int64_
     double* sums = ws;
     float* m_c = reinterpret_cast<float*>(ws + (size_t)N * 4);
     float* m_b = m_c + (size_t)N * A;
-    hipMemsetAsync(sums, 0, sizeof(double) * 4 * N, st);
+    ERD_ZERO_ASYNC(sums, sizeof(double) * 4 * N, st);
     const int64_t rows = (int64_t)N * A;
     const unsigned nb = (unsigned)((rows + 255) / 256);
     if (Ccls % 4 == 0)
@@ -801,8 +801,8 @@ extern "C" int erd_atss_assign(const float* anchors, const uint8_t* valid, const
     hipStream_t st = (hipStream_t)stream;
     const Levels5 lv = make_levels(lvl_off, nullptr, nlvl, nullptr, nullptr);
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ws);
-    hipMemsetAsync(best, 0, sizeof(unsigned long long) * (size_t)N * A, st);
-    hipMemsetAsync(num_pos, 0, sizeof(int32_t) * N, st);
+    ERD_ZERO_ASYNC(best, sizeof(unsigned long long) * (size_t)N * A, st);
+    ERD_ZERO_ASYNC(num_pos, sizeof(int32_t) * N, st);
     if (max_gt > 0)
         hipLaunchKernelGGL(atss_candidates_kernel, dim3(max_gt, N), dim3(256), 0, st,
                            reinterpret_cast<const float4*>(anchors), valid, lv, A,
@@ -822,7 +822,7 @@ extern "C" int erd_gfl_losses_fwd(const float* cls, const float* bbox, const flo
     ERD_REQUIRE(c_all % 4 == 0 && c_old >= 0 && c_old < c_all && nlvl <= ERD_MAX_SEG, "gfl_losses_fwd: channels");
     hipStream_t st = (hipStream_t)stream;
     const Levels5 lv = make_levels(lvl_off, strides, nlvl, nullptr, nullptr);
-    hipMemsetAsync(out_sums, 0, sizeof(double) * 4 * nlvl, st);
+    ERD_ZERO_ASYNC(out_sums, sizeof(double) * 4 * nlvl, st);
     hipLaunchKernelGGL(gfl_losses_kernel<false>, dim3((unsigned)((A + GL_ROWS - 1) / GL_ROWS), N), dim3(256),
                        GL_ROWS * c_all * sizeof(float), st, cls, bbox, reinterpret_cast<const float4*>(anchors), labels,
                        label_weights, reinterpret_cast<const float4*>(bbox_targets), lv, A, c_old, c_all, score_ws,
@@ -850,7 +850,7 @@ extern "C" int erd_l2_distill(const float* s_cls, const float* t_cls, const int6
                               int N, int64_t A, int c_s, int c_t, int c_old, double* sums, erd_stream_t stream) {
     ERD_REQUIRE(s_cls && t_cls && idx_cls && counts && sums, "l2: null");
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(sums, 0, sizeof(double) * N, st);
+    ERD_ZERO_ASYNC(sums, sizeof(double) * N, st);
     hipLaunchKernelGGL(l2_distill_kernel<false>, dim3(64, N), dim3(256), 0, st, s_cls, t_cls, idx_cls, counts, A, c_s,
                        c_t, c_old, sums, nullptr, nullptr);
     return erd::check_launch("l2_distill");
@@ -880,7 +880,7 @@ extern "C" int erd_kd_kl(const float* s_bbox, const float* t_bbox, const float* 
                          int64_t A, int c_s, int c_old, float T, double* sums, erd_stream_t stream) {
     ERD_REQUIRE(s_bbox && t_bbox && s_cls && keep_mask && sums, "kd_kl: null");
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(sums, 0, sizeof(double) * N, st);
+    ERD_ZERO_ASYNC(sums, sizeof(double) * N, st);
     hipLaunchKernelGGL(kd_kl_kernel<false>, dim3((unsigned)((A + 63) / 64), N), dim3(256), 0, st, s_bbox, t_bbox, s_cls,
                        keep_mask, A, c_s, c_old, T, sums, nullptr, nullptr);
     return erd::check_launch("kd_kl");

@@ -455,7 +455,7 @@ extern "C" int erd_predict_topk(const float* cls, const float* bbox, const float
     Sel* sel = reinterpret_cast<Sel*>(w + segs * HB * sizeof(uint32_t));
     size_t o = (segs * HB * sizeof(uint32_t) + segs * sizeof(Sel) + 255) / 256 * 256;
     uint64_t* cand = reinterpret_cast<uint64_t*>(w + o);
-    hipMemsetAsync(w, 0, segs * HB * sizeof(uint32_t) + segs * sizeof(Sel), st);
+    ERD_ZERO_ASYNC(w, segs * HB * sizeof(uint32_t) + segs * sizeof(Sel), st);
     const dim3 gs(lm.chunk0[lv->nseg], N), gseg((unsigned)segs);
     hipLaunchKernelGGL(pred_hist_kernel<0>, gs, dim3(256), 0, st, cls, A, C, lm, score_thr, sel, hist);
     hipLaunchKernelGGL(pred_scan_kernel<0>, gseg, dim3(256), 0, st, hist, sel, nms_pre);
