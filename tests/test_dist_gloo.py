@@ -86,3 +86,66 @@ def test_bucketed_grad_sync_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def _worker_update(rank, world, port, q):
+    """per-bucket update at world size 2: all-reduce -> on_bucket per bucket, released by the first report from another bucket;
+    rank 1 leaves the last layer out of its loss in the second step (its first bucket stays open until wait())"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from erd_amd.engine import BucketedGradSync, FlatParams
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                                  torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 1))
+        named = list(net.named_parameters()); named.reverse()
+        flat = FlatParams(named, "cpu", bucket_bytes=2000, tail_bytes=1500, group_key=lambda n: n.split(".")[0])
+        lr = 0.05
+        order = []
+
+        def on_bucket(b):                               # plain SGD on the bucket's slice with the MEAN gradient
+            s, e, _ = flat.buckets[b]
+            order.append(b)
+            flat.data[s:e].sub_(lr * flat.grad[s:e] / world)
+
+        sync = BucketedGradSync(flat, on_bucket=on_bucket)
+        x = torch.randn(2, 4, 6, 6, generator=torch.Generator().manual_seed(100 + rank))
+        ok = len(flat.buckets) >= 3
+        for step in range(2):
+            before = flat.data.clone()
+            # reference: every rank's local gradient of the CURRENT parameters, gathered and averaged
+            flat.zero_grad()
+            loss = lambda: (net(x) if (step == 0 or rank == 0) else net[:6](x)).square().mean()
+            loss().backward()
+            loc = [torch.zeros_like(flat.grad) for _ in range(world)]
+            dist.all_gather(loc, flat.grad.clone())
+            want = before - lr * sum(loc) / world
+            flat.zero_grad(); sync.arm(); order.clear()
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                loss().backward()
+                sync.wait()
+            ok = ok and order == list(range(len(flat.buckets)))
+            ok = ok and torch.allclose(flat.data, want, rtol=1e-6, atol=1e-8)
+            ok = ok and sync.late_buckets == (1 if (step == 1 and rank == 1) else 0)
+        both = [torch.zeros_like(flat.data) for _ in range(world)]
+        dist.all_gather(both, flat.data.clone())
+        ok = ok and torch.equal(both[0], both[1])       # the ranks stay bit-identical
+        q.put((rank, bool(ok), len(flat.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_per_bucket_update_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_update, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
