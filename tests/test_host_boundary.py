@@ -221,3 +221,12 @@ def test_resnet_init_cfg_pretrained_is_honoured(tmp_path, monkeypatch):
     monkeypatch.setenv("ERD_PRETRAINED_DIR", str(hub))
     with pytest.raises(RuntimeError):
         MODELS.build({**cfg, "depth": 101, "init_cfg": dict(type="Pretrained", checkpoint=str(hub / "resnet50-0676ba61.pth"))}).init_weights()
+
+
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md's binding table covers the whole C ABI: every function include/erd_hip.h declares is named there"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set(re.findall(r"\b(erd_[a-z0-9_]+)\s*\(", open(os.path.join(root, "include", "erd_hip.h")).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert not [n for n in sorted(names) if n not in doc]
