@@ -252,7 +252,6 @@ def self_launch(args, argv) -> int:
 SYMBOLS = {"wino_conv_kernel": ("conv_wino_fwd", "conv_wino_dgrad"),
            "conv_igemm_kernel": ("conv_igemm_fwd", "conv_igemm_dgrad"),
            "conv_thin_x3_kernel": ("conv_thin_fwd", "conv_thin_dgrad"),
-           "conv_thin_bf16_kernel": ("conv_thin_fwd", "conv_thin_dgrad"),
            "conv_wgrad_row3_kernel": ("conv_wgrad_row3",),
            "conv_wgrad_kernel": ("conv_wgrad",)}
 WINO_EXECUTED = 16.0 / 36.0       # F(2x2,3x3) runs 16 of the 36 multiplications a direct 3x3 convolution counts per 2x2 outputs
@@ -487,7 +486,6 @@ def main():
             # one symbol) and its roofline on the flops it EXECUTES
             wino_on_bf16 = K.wino_x3()       # "f32x3": the Winograd launches run as wino_x3_kernel (six bf16 limb products per transform-domain product)
             symbols = dict(SYMBOLS)
-            symbols.pop("conv_thin_x3_kernel" if args.compute == "bf16" else "conv_thin_bf16_kernel")      # (one thin kernel per mode)
             if wino_on_bf16:
                 symbols["wino_x3_kernel"] = symbols.pop("wino_conv_kernel")
             wino_sym = "wino_x3_kernel" if wino_on_bf16 else "wino_conv_kernel"

@@ -1853,7 +1853,6 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     // want the fp32 kernel's four small workgroups per CU (the three-limb kernel holds 80 KB of LDS: two per CU)
     // thin 1x1 layers (Cin <= 128): activations stationary in registers, weights streamed (conv_thin.hip; bit-identical results)
     if (erd::conv_thin_x3_ok(d)) return erd::conv_thin_x3(d, st);
-    if (erd::conv_thin_bf16_ok(d)) return erd::conv_thin_bf16(d, st);
     static const int x3_min_k = getenv("ERD_X3_MIN_K") ? atoi(getenv("ERD_X3_MIN_K")) : 0;
     if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0 && (d->Cout % 4 == 0 || !d->w) && (d->ntaps * d->Cin >= x3_min_k || !d->w)) {
         ERD_REQUIRE(d->Cout % 4 == 0, "conv: the three-limb kernel stores 16-byte rows (Cout %% 4 == 0); pass `w` for Cout=%d", d->Cout);

@@ -27,7 +27,6 @@
 // input-gradient forms (res / mask / colsum / alpha / accumulate) through the same descriptor as erd_conv_igemm, which
 // dispatches here (ERD_THIN=0: off, A/B aid).
 #include <algorithm>
-#include <type_traits>
 #include "erd_common.h"
 #include <stdlib.h>
 
@@ -49,20 +48,12 @@ struct TRow {
 
 constexpr int SLD = 36;                    // floats per staged row (32 couts + 4: rows land on different banks)
 
-// BF = true: the bf16 matrix-core mode's form of the same loop nest (erd_conv_desc::w_bf16 with bf16-STORED maps on both sides,
-// in_bf16 / out_bf16): the activation rows arrive as bf16 and ARE the MFMA fragments (one 16-byte load per k16 step, no split),
-// one weight plane, one MFMA per step -- the accumulation order of conv_igemm_kernel<..., BF> without a K split, i.e.
-// bit-identical results --, residual / mask / output cells are bf16.  32 fragment registers and 36 KB of LDS at K = 128:
-// three workgroups per CU (four at K = 64).
-template <int KS, bool BF>                 // K / 16: MFMA k-steps of the whole reduction (4: Cin = 64, 8: Cin = 128)
-__device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int mtiles, const int nb, const int xcd_order) {
+template <int KS>                          // K / 16: MFMA k-steps of the whole reduction (4: Cin = 64, 8: Cin = 128)
+__global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_desc p, const int mtiles, const int nb, const int xcd_order) {
     constexpr int K = KS * 16;
     constexpr int CPR = K / 8;                         // 16-byte chunks (8 bf16) per weight row
-    constexpr int NPL = BF ? 1 : 3;                    // weight planes
-    constexpr int UNIT_B = NPL * 32 * K * 2;           // one cout block's planes
-    constexpr int NQ = UNIT_B / 16 / 256;              // 16-byte loads per thread and block (f32x3: 6 at K = 128, 3 at K = 64; bf16: 2, 1)
-    using MapT = typename std::conditional<BF, erd::bf16s, float>::type;      // storage cell of the maps
-    constexpr unsigned MAPB = BF ? 2u : 4u;
+    constexpr int UNIT_B = 3 * 32 * K * 2;             // one cout block's three planes
+    constexpr int NQ = UNIT_B / 16 / 256;              // 16-byte loads per thread and block (6 at K = 128, 3 at K = 64)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                                     // [2][UNIT_B]
     float* stage = reinterpret_cast<float*>(smem + 2 * UNIT_B);            // [4 waves][32][SLD]
@@ -81,7 +72,7 @@ __device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int
     if (t_begin >= t_end) return;
 
     const unsigned plane_b = (unsigned)((long long)p.Cout * p.wrow * 2);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BF ? p.w_bf16 : p.w_x3), 0, (int)((unsigned)NPL * plane_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_x3), 0, (int)(3u * plane_b), 0x00020000);
     // this thread's share of a block's weight planes: (plane, row, chunk) of load q, the same for every block
     unsigned w_off[NQ];
     int l_off[NQ];
@@ -104,7 +95,7 @@ __device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int
         for (int q = 0; q < NQ; ++q) *reinterpret_cast<u4v*>(ring + buf * UNIT_B + l_off[q]) = rb[q];
     };
 
-    u4v ah[KS], am[BF ? 1 : KS], al[BF ? 1 : KS];      // the wave's activation rows: (limb) fragments of every k16 step
+    u4v ah[KS], am[KS], al[KS];            // the wave's activation rows: limb fragments of every k16 step
     int pend_cb = -1;                      // cout block whose column sums wait in `red` for their atomics
     float* const cs_row = p.colsum ? p.colsum + (p.colsum_copies > 1 ? (int64_t)(blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) : nullptr;
     const float alpha_dummy = 1.f;
@@ -141,29 +132,24 @@ __device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int
             }
             __syncthreads();
             const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-                erd::uniform_ptr(const_cast<float*>(sg.in)), 0, erd::uniform_int((int)((long long)sg.N * sg.in_nstride * MAPB)), 0x00020000);
+                erd::uniform_ptr(const_cast<float*>(sg.in)), 0, erd::uniform_int((int)((long long)sg.N * sg.in_nstride * 4)), 0x00020000);
             const int ibase = rows[wave * 32 + li].in_off;
-            // lane (li, h) holds channels 16 s + 8 h .. + 7 of pixel row li for every step s
-            if constexpr (BF) {            // bf16-stored map: the eight values ARE the fragment
+            // lane (li, h) holds channels 16 s + 8 h .. + 7 of pixel row li for every step s: two 16-byte loads per step
+            u4v xa[KS], xb[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) ah[s] = buf_load16(rs_in, ibase < 0 ? OOB : (unsigned)(ibase + 16 * s + 8 * h) * 2u);
-            } else {                       // fp32 map: two 16-byte loads per step, split into limbs once
-                u4v xa[KS], xb[KS];
+            for (int s = 0; s < KS; ++s) {
+                const unsigned o = ibase < 0 ? OOB : (unsigned)(ibase + 16 * s + 8 * h) * 4u;
+                xa[s] = buf_load16(rs_in, o);
+                xb[s] = buf_load16(rs_in, ibase < 0 ? OOB : o + 16u);
+            }
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const unsigned o = ibase < 0 ? OOB : (unsigned)(ibase + 16 * s + 8 * h) * 4u;
-                    xa[s] = buf_load16(rs_in, o);
-                    xb[s] = buf_load16(rs_in, ibase < 0 ? OOB : o + 16u);
-                }
+            for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {      // value pair e of the step: words (2 e, 2 e + 1) of the eight fp32 values
-                        const u4v& x = e < 2 ? xa[s] : xb[s];
-                        unsigned hi, mid, lo;
-                        erd::limbs3_pair(__uint_as_float(x[(e & 1) * 2]), __uint_as_float(x[(e & 1) * 2 + 1]), hi, mid, lo);
-                        ah[s][e] = hi; am[BF ? 0 : s][e] = mid; al[BF ? 0 : s][e] = lo;
-                    }
+                for (int e = 0; e < 4; ++e) {      // value pair e of the step: words (2 e, 2 e + 1) of the eight fp32 values
+                    const u4v& x = e < 2 ? xa[s] : xb[s];
+                    unsigned hi, mid, lo;
+                    erd::limbs3_pair(__uint_as_float(x[(e & 1) * 2]), __uint_as_float(x[(e & 1) * 2 + 1]), hi, mid, lo);
+                    ah[s][e] = hi; am[s][e] = mid; al[s][e] = lo;
                 }
             }
         }
@@ -185,16 +171,15 @@ __device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int
         // ---- residual / mask rows of this block are requested before its MFMAs ---------------------------------------------
         const int c4 = lane & 7, rsub = lane >> 3;
         const int co = cb * 32 + c4 * 4;
-        const MapT* res = reinterpret_cast<const MapT*>(sg.res);
-        const MapT* msk = reinterpret_cast<const MapT*>(sg.mask);
-        MapT* const outp = reinterpret_cast<MapT*>(sg.out);
-        const MapT* pf_src = res ? res : msk;
+        const float* res = sg.res;
+        const float* msk = sg.mask;
+        const float* pf_src = res ? res : msk;
         int oo[4];
         float4 pf[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             oo[q] = rows[wave * 32 + q * 8 + rsub].out_off;
-            if (pf_src && oo[q] >= 0) pf[q] = erd::ld4(pf_src + oo[q] + co);
+            if (pf_src && oo[q] >= 0) pf[q] = *reinterpret_cast<const float4*>(pf_src + oo[q] + co);
         }
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
@@ -207,24 +192,19 @@ __device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int
         const char* Bb = ring + buf * UNIT_B;
         // (weight fragments are read ONE step ahead by hand and the schedule is pinned per step: left alone the compiler hoists
         //  every step's LDS reads to the top of the block -- 96 more live registers -- and spills the limb fragments)
-        bf16x8 wf[2][NPL];
+        bf16x8 wf[2][3];
         auto read_w = [&](int s, int slot) {
             const int ch = 2 * s + h;
             const int sw = CPR == 16 ? (ch ^ (li & 15)) : (ch ^ ((li >> 1) & 7));
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) wf[slot][pl] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 32 + li) * CPR + sw) * 16);
+            for (int pl = 0; pl < 3; ++pl) wf[slot][pl] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 32 + li) * CPR + sw) * 16);
         };
         read_w(0, 0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) read_w(s + 1, (s + 1) & 1);
-            if constexpr (BF) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[s]), wf[s & 1][0], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                continue;
-            }
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[s]), a1 = __builtin_bit_cast(bf16x8, am[BF ? 0 : s]), a2 = __builtin_bit_cast(bf16x8, al[BF ? 0 : s]);
-            const bf16x8 w0 = wf[s & 1][0], w1 = wf[s & 1][NPL > 1 ? 1 : 0], w2 = wf[s & 1][NPL > 2 ? 2 : 0];
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[s]), a1 = __builtin_bit_cast(bf16x8, am[s]), a2 = __builtin_bit_cast(bf16x8, al[s]);
+            const bf16x8 w0 = wf[s & 1][0], w1 = wf[s & 1][1], w2 = wf[s & 1][2];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc, 0, 0, 0);
@@ -254,11 +234,11 @@ __device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int
             if (res) { const float4 rv = pf[q]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (msk) {
-                const float4 mv = res ? erd::ld4(msk + oo[q] + co) : pf[q];
+                const float4 mv = res ? *reinterpret_cast<const float4*>(msk + oo[q] + co) : pf[q];
                 v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
                 v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
             }
-            erd::st4(outp + oo[q] + co, v);
+            *reinterpret_cast<float4*>(sg.out + oo[q] + co) = v;
             csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
         }
         if (cs_row) {      // lanes that share a column group (lane bits 3..5), then the wave's row of `red`
@@ -282,16 +262,6 @@ __device__ __forceinline__ void conv_thin_body(const erd_conv_desc& p, const int
     }
 }
 
-template <int KS>
-__global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_desc p, const int mtiles, const int nb, const int xcd_order) {
-    conv_thin_body<KS, false>(p, mtiles, nb, xcd_order);
-}
-
-template <int KS>
-__global__ __launch_bounds__(256, KS == 4 ? 4 : 3) void conv_thin_bf16_kernel(const erd_conv_desc p, const int mtiles, const int nb, const int xcd_order) {
-    conv_thin_body<KS, true>(p, mtiles, nb, xcd_order);
-}
-
 int num_cus_thin() {
     static int n = 0;
     if (n == 0) {
@@ -303,15 +273,15 @@ int num_cus_thin() {
     return n;
 }
 
-template <int KS, bool BF>
+template <int KS>
 int launch_thin(const erd_conv_desc* d, hipStream_t st) {
     constexpr int K = KS * 16;
     int mtiles = 0;
     for (int s = 0; s < d->nseg; ++s) mtiles += (int)(((int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW + 127) / 128);
     const int nb = d->Cout / 32;
     if (mtiles == 0) return 0;
-    const size_t lds = (size_t)2 * ((BF ? 1 : 3) * 32 * K * 2) + 4 * 32 * SLD * 4 + 128 * sizeof(TRow) + 2 * 4 * 32 * 4;
-    auto kern = BF ? conv_thin_bf16_kernel<KS> : conv_thin_x3_kernel<KS>;
+    const size_t lds = (size_t)2 * (3 * 32 * K * 2) + 4 * 32 * SLD * 4 + 128 * sizeof(TRow) + 2 * 4 * 32 * 4;
+    auto kern = conv_thin_x3_kernel<KS>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -321,10 +291,10 @@ int launch_thin(const erd_conv_desc* d, hipStream_t st) {
     const long long T = (long long)mtiles * nb;
     // two workgroups per CU at K = 128 (226 registers, 68 KB of LDS); three at K = 64 (154 registers, 45 KB).  ERD_THIN_WGS: A/B aid
     static const int wgs_env = getenv("ERD_THIN_WGS") ? atoi(getenv("ERD_THIN_WGS")) : 0;
-    const int per_cu = wgs_env > 0 ? wgs_env : (BF ? (KS == 4 ? 4 : 3) : (KS == 4 ? 3 : 2));
+    const int per_cu = wgs_env > 0 ? wgs_env : (KS == 4 ? 3 : 2);
     const int G = (int)std::min<long long>(T, (long long)per_cu * num_cus_thin());
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, *d, mtiles, nb, xcd ? 1 : 0);
-    return erd::check_launch(BF ? "conv_thin_bf16" : "conv_thin_x3");
+    return erd::check_launch("conv_thin_x3");
 }
 
 }  // namespace
@@ -351,20 +321,7 @@ bool conv_thin_x3_ok(const erd_conv_desc* d) {
 }
 
 int conv_thin_x3(const erd_conv_desc* d, hipStream_t st) {
-    return d->Cin == 64 ? launch_thin<4, false>(d, st) : launch_thin<8, false>(d, st);
-}
-
-bool conv_thin_bf16_ok(const erd_conv_desc* d) {
-    const int on = conv_thin_enable(-1);
-    if (!on || !d->w_bf16 || d->w_x3 || !d->in_bf16 || !d->out_bf16 || d->ntaps != 1) return false;
-    if (!(d->Cin == 64 || d->Cin == 128) || d->Cout % 32 != 0 || d->wrow % 8 != 0 || d->wk[0] % 8 != 0) return false;
-    for (int s = 0; s < d->nseg; ++s)
-        if (d->seg[s].ntaps > 0) return false;
-    return true;
-}
-
-int conv_thin_bf16(const erd_conv_desc* d, hipStream_t st) {
-    return d->Cin == 64 ? launch_thin<4, true>(d, st) : launch_thin<8, true>(d, st);
+    return d->Cin == 64 ? launch_thin<4>(d, st) : launch_thin<8>(d, st);
 }
 
 }  // namespace erd

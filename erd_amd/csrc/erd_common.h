@@ -14,8 +14,6 @@ void set_error(const char* fmt, ...);
 // conv_thin.hip: the activation-stationary three-limb kernel for 1x1 convolutions with Cin <= 128 (erd_conv_igemm dispatches to it)
 bool conv_thin_x3_ok(const erd_conv_desc* d);
 int conv_thin_x3(const erd_conv_desc* d, hipStream_t st);
-bool conv_thin_bf16_ok(const erd_conv_desc* d);      // ... and its bf16 matrix-core form (w_bf16, bf16-stored maps on both sides)
-int conv_thin_bf16(const erd_conv_desc* d, hipStream_t st);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
