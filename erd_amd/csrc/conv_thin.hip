@@ -205,12 +205,17 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
             if (s + 1 < KS) read_w(s + 1, (s + 1) & 1);
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[s]), a1 = __builtin_bit_cast(bf16x8, am[s]), a2 = __builtin_bit_cast(bf16x8, al[s]);
             const bf16x8 w0 = wf[s & 1][0], w1 = wf[s & 1][1], w2 = wf[s & 1][2];
+#ifdef ERD_THIN_NOMFMA     // timing probe: everything but the matrix instructions (results are wrong)
+            acc[0] += __builtin_bit_cast(float4, a0).x * __builtin_bit_cast(float4, w2).x + __builtin_bit_cast(float4, a1).x * __builtin_bit_cast(float4, w1).x +
+                      __builtin_bit_cast(float4, a2).x * __builtin_bit_cast(float4, w0).x;
+#else
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc, 0, 0, 0);
+#endif
 #ifdef ERD_X3_NINE        // accuracy probe, as in conv_igemm_kernel: the three dropped limb products
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w1, acc, 0, 0, 0);
@@ -238,7 +243,11 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
                 v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
                 v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
             }
+#ifdef ERD_THIN_NOSTORE    // timing probe: nothing is written (results are wrong)
+            asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
             *reinterpret_cast<float4*>(sg.out + oo[q] + co) = v;
+#endif
             csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
         }
         if (cs_row) {      // lanes that share a column group (lane bits 3..5), then the wave's row of `red`
