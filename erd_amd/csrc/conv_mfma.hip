@@ -1282,12 +1282,19 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
 
     // ---- staging roles: threads [0, NA) own a dz micro-tile (4 px x 4 co), threads [128, 128 + 80) an x micro-tile (4 entries x 4 ci)
     constexpr int NA = (BMR / 4) * 4;                           // dz micro-tiles: (BMR / 4) channel groups x 4 pixel groups
-    constexpr int NB = (BNR / 4) * ((BX + 3) / 4);              // x micro-tiles: 16 x 5 with the halo, 32 x 4 without
+    constexpr int NBG = (BX + 3) / 4;                           // x entry groups: 5 with the halo, 4 without
+    constexpr int NB = (BNR / 4) * ((NBG + 1) / 2 * 2);        // x micro-tiles: 16 x 5 with the halo (a sixth, idle, group pads the lane pairs), 32 x 4 without
     static_assert(NA <= 128 && NB <= 128, "staging roles");
-    const bool is_a = tid < NA, is_b = tid >= 128 && tid < 128 + NB;
     const int tb = tid - 128;
-    const int cg = is_a ? tid % (BMR / 4) : tb % (BNR / 4);     // channel group
-    const int pg = is_a ? tid / (BMR / 4) : tb / (BNR / 4);     // group of 4 pixels (dz: 0..3) / entries (x: 0..4)
+    // Both operands: neighbouring lanes alternate between two pixel groups and the LDS rows are PERMUTED (channel 4 cg + c lives in
+    // row cg + (rows / 4) c, undone when the partial slab is written): the 8-byte limb stores of a half-wave then hit 32 different
+    // bank pairs.  With channel-major rows and lanes = consecutive channel groups every store instruction touched 8 banks (row stride
+    // 128 B): SQ_LDS_BANK_CONFLICT 0.17 of the wave cycles against 0.00 for the implicit GEMM (tools/pmc_waves.py)
+    constexpr int QA = BMR / 4, QB = BNR / 4;
+    const bool is_a = tid < NA;
+    const int cg = is_a ? (tid >> 1) % QA : (tb >> 1) % QB;     // channel group
+    const int pg = is_a ? (tid & 1) + 2 * (tid / (2 * QA)) : (tb & 1) + 2 * (tb / (2 * QB));     // group of 4 pixels (dz: 0..3) / entries (x: 0..4)
+    const bool is_b = tid >= 128 && tid < 128 + NB && pg < NBG;
     const int col = is_a ? co0 + cg * 4 : ci0 + cg * 4;
     const bool cok = is_a ? (col < p.Cout) : (is_b && col < p.Cin);
     float4 rv[4];
@@ -1308,7 +1315,7 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
         char* base = smem + buf * BUF + (is_a ? 0 : 3 * A_PL);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int row = cg * 4 + c;
+            const int row = is_a ? cg + QA * c : cg + QB * c;
             uint2 hi, mid, lo;      // four pixels of channel c per limb plane (round-to-nearest limbs, erd_common.h)
             erd::limbs3_pair(v[0][c], v[1][c], hi.x, mid.x, lo.x);
             erd::limbs3_pair(v[2][c], v[3][c], hi.y, mid.y, lo.y);
@@ -1404,7 +1411,8 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
     float* __restrict__ part = p.part + (int64_t)bz * p.Cout * ntaps_all * p.Cin;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int ci = ci0 + (wn * FN + j) * 32 + li;
+        const int brow = (wn * FN + j) * 32 + li;              // LDS row of the x operand ...
+        const int ci = ci0 + 4 * (brow % QB) + brow / QB;      // ... holds this input channel
         if (ci >= p.Cin) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -1412,7 +1420,8 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int arow = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // LDS row of the dz operand ...
+                    const int co = co0 + 4 * (arow % QA) + arow / QA;                          // ... holds this output channel
                     if (co < p.Cout) part[((int64_t)co * ntaps_all + (ROW3 ? ky * 3 + t : ky)) * p.Cin + ci] = acc[t][i][j][r];
                 }
     }

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""What the waves of each GEMM-shaped kernel do with their cycles: per-kernel totals of SQ counters from separate
+`rocprofv3 --pmc` passes (tools/profile_round.sh's recipe: `-- python3 bench.py --serial --steps 2 --warmup 1 ...`), as fractions
+of SQ_WAVE_CYCLES (wave-resident cycles) / SQ_BUSY_CYCLES.  usage: python tools/pmc_waves.py DIR_PASS_A DIR_PASS_B ... > table"""
+import csv, collections, glob, os, sys
+
+KEEP = ("wino_x3_kernel", "conv_igemm_kernel", "conv_thin_x3_kernel", "conv_wgrad_row3_x3_kernel", "gn_apply_kernel", "wgrad_reduce_kernel")
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for d in sys.argv[1:]:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            sym = next((s for s in KEEP if k.startswith(s)), None)
+            if sym is None:
+                continue
+            if sym == "conv_wgrad_row3_x3_kernel":
+                sym += "<3 taps>" if "true>" in k else "<1 tap>"
+            tot[sym][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[sym][r["Counter_Name"]] += 1
+names = sorted({n for v in tot.values() for n in v})
+base = "SQ_WAVE_CYCLES"
+print("counters per kernel symbol as a fraction of %s (summed over all launches of two serialized steps)" % base)
+print("%-34s %8s " % ("kernel", "launches") + " ".join("%22s" % n.replace("SQ_", "") for n in names if n != base))
+for sym, c in sorted(tot.items(), key=lambda kv: -kv[1].get(base, 0)):
+    b = c.get(base, 0.0)
+    print("%-34s %8d " % (sym, cnt[sym].get(base, 0)) + " ".join("%22s" % ("%.3f" % (c[n] / b) if b else "-") for n in names if n != base))
