@@ -1413,6 +1413,49 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
     }
     const int ntaps_all = ROW3 ? 9 : p.ntaps;
     float* __restrict__ part = p.part + (int64_t)bz * p.Cout * ntaps_all * p.Cin;
+    if ((p.Cin & 3) == 0) {
+        // ---- partial slab through LDS, one tap (and at most 128 x 64 / 64 x 128 values) at a time: the accumulators' one-float-per-lane
+        // layout would be 16 x FM x FN x taps four-byte stores per lane (8 % of a launch, timing probe ERD_WG3_NOSLAB); staged, the
+        // (co, ci) permutations of the operand rows are undone on the way and every thread writes whole 16-byte pieces of slab rows
+        constexpr int SLDW = BNR + 4;                                            // floats per staged row
+        constexpr int RPASS = (BMR * SLDW * 4 <= 2 * BUF) ? BMR : BMR / 2;       // accumulator rows per pass
+        constexpr int NPASS = BMR / RPASS, C4 = BNR / 4;
+        static_assert(RPASS * SLDW * 4 <= 2 * BUF && RPASS % 32 == 0, "slab staging");
+        float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                __syncthreads();               // the K loop's fragment reads / the previous pass are done with the operand buffers
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    if (((wm * FM + i) * 32) / RPASS != ps) continue;            // (wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int brow = (wn * FN + j) * 32 + li;                  // LDS row of the x operand -> input channel of the tile
+                        const int col = PERM_B ? 4 * (brow % QB) + brow / QB : brow;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int arow = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            stage[(arow - ps * RPASS) * SLDW + col] = acc[t][i][j][r];
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < RPASS * C4 / NTHREADS; ++q) {
+                    const int idx = q * NTHREADS + tid;
+                    const int row = idx / C4, c4 = idx - row * C4;
+                    const int arow = ps * RPASS + row;                              // LDS row of the dz operand -> output channel
+                    const int co = co0 + 4 * (arow % QA) + arow / QA, ci = ci0 + 4 * c4;
+                    if (co < p.Cout && ci < p.Cin)
+                        *reinterpret_cast<float4*>(part + ((int64_t)co * ntaps_all + (ROW3 ? ky * 3 + t : ky)) * p.Cin + ci) =
+                            *reinterpret_cast<const float4*>(stage + row * SLDW + 4 * c4);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int brow = (wn * FN + j) * 32 + li;              // LDS row of the x operand ...
@@ -1426,7 +1469,11 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
                 for (int r = 0; r < 16; ++r) {
                     const int arow = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // LDS row of the dz operand ...
                     const int co = co0 + 4 * (arow % QA) + arow / QA;                          // ... holds this output channel
+#ifdef ERD_WG3_NOSLAB      // timing probe: the partial slab is not written (results are wrong; read against the build BEFORE the staged slab write)
+                    if (co < p.Cout) asm volatile("" :: "v"(acc[t][i][j][r]));
+#else
                     if (co < p.Cout) part[((int64_t)co * ntaps_all + (ROW3 ? ky * 3 + t : ky)) * p.Cin + ci] = acc[t][i][j][r];
+#endif
                 }
     }
 }
