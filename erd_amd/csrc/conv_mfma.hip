@@ -1286,15 +1286,11 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
     constexpr int NB = (BNR / 4) * ((NBG + 1) / 2 * 2);        // x micro-tiles: 16 x 5 with the halo (a sixth, idle, group pads the lane pairs), 32 x 4 without
     static_assert(NA <= 128 && NB <= 128, "staging roles");
     const int tb = tid - 128;
-    // Neighbouring lanes alternate between two pixel groups and the LDS rows are PERMUTED (channel 4 cg + c lives in
+    // Both operands: neighbouring lanes alternate between two pixel groups and the LDS rows are PERMUTED (channel 4 cg + c lives in
     // row cg + (rows / 4) c, undone when the partial slab is written): the 8-byte limb stores of a half-wave then hit 32 different
     // bank pairs.  With channel-major rows and lanes = consecutive channel groups every store instruction touched 8 banks (row stride
     // 128 B): SQ_LDS_BANK_CONFLICT 0.17 of the wave cycles against 0.00 for the implicit GEMM (tools/pmc_waves.py)
     constexpr int QA = BMR / 4, QB = BNR / 4;
-    // (the x rows are permuted in the three-tap form only: lane = x row = input channel of the slab write, and the single-tap form's
-    //  short K loops lose more to the uncoalesced slab write than they gain from conflict-free x stores: 1x1 layers 1 592-1 618 us summed
-    //  with the dz rows alone against 1 648-1 651 with both, tools/bench_conv.py)
-    constexpr bool PERM_B = ROW3;
     const bool is_a = tid < NA;
     const int cg = is_a ? (tid >> 1) % QA : (tb >> 1) % QB;     // channel group
     const int pg = is_a ? (tid & 1) + 2 * (tid / (2 * QA)) : (tb & 1) + 2 * (tb / (2 * QB));     // group of 4 pixels (dz: 0..3) / entries (x: 0..4)
@@ -1319,7 +1315,7 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
         char* base = smem + buf * BUF + (is_a ? 0 : 3 * A_PL);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int row = is_a ? cg + QA * c : (PERM_B ? cg + QB * c : cg * 4 + c);
+            const int row = is_a ? cg + QA * c : cg + QB * c;
             uint2 hi, mid, lo;      // four pixels of channel c per limb plane (round-to-nearest limbs, erd_common.h)
             erd::limbs3_pair(v[0][c], v[1][c], hi.x, mid.x, lo.x);
             erd::limbs3_pair(v[2][c], v[3][c], hi.y, mid.y, lo.y);
@@ -1433,7 +1429,7 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
                         const int brow = (wn * FN + j) * 32 + li;                  // LDS row of the x operand -> input channel of the tile
-                        const int col = PERM_B ? 4 * (brow % QB) + brow / QB : brow;
+                        const int col = 4 * (brow % QB) + brow / QB;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int arow = (wm * FM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1459,7 +1455,7 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int brow = (wn * FN + j) * 32 + li;              // LDS row of the x operand ...
-        const int ci = ci0 + (PERM_B ? 4 * (brow % QB) + brow / QB : brow);      // ... holds this input channel
+        const int ci = ci0 + 4 * (brow % QB) + brow / QB;      // ... holds this input channel
         if (ci >= p.Cin) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
