@@ -1650,6 +1650,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(const erd_
         }
     }
     float* __restrict__ part = p.part + (int64_t)bz * p.Cout * p.ntaps * p.Cin;
+    if ((p.Cin & 3) == 0) {
+        // partial slab through the (now idle) operand buffers, 64 accumulator rows at a time, written as 16-byte pieces of whole slab
+        // rows instead of 64 four-byte stores per lane (conv_wgrad_row3_x3_kernel does the same)
+        constexpr int SLDW = BN + 4, RPASS = 64, C4 = BN / 4;
+        static_assert(RPASS * SLDW * 4 <= 2 * (BM + BN) * 8 * 16 && FM * 32 == RPASS, "slab staging");
+        float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int ps = 0; ps < BM / RPASS; ++ps) {
+            __syncthreads();
+            if (wm == ps) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * SLDW + (wn * FN + j) * 32 + li] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < RPASS * C4 / NTHREADS; ++q) {
+                const int idx = q * NTHREADS + tid;
+                const int row = idx / C4, c4 = idx - row * C4;
+                const int co = co0 + ps * RPASS + row, ci = ci0 + 4 * c4;
+                if (co < p.Cout && ci < p.Cin)
+                    *reinterpret_cast<float4*>(part + ((int64_t)co * p.ntaps + tap) * p.Cin + ci) =
+                        *reinterpret_cast<const float4*>(stage + row * SLDW + 4 * c4);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int ci = ci0 + (wn * FN + j) * 32 + li;
