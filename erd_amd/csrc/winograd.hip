@@ -68,6 +68,7 @@ __device__ __forceinline__ int vswz2(int row, int c) { return c ^ ((0 - (row >> 
 
 #ifdef ERD_WINO_TRACE       // debug builds only (tools/build_abl.sh): per-workgroup cycle accounting of both wave roles
 __device__ unsigned long long g_wino_trace[256 * 8];       // [0..3] matrix wave 0, [4..7] data wave 0
+__device__ unsigned long long g_wino_trace_p[256 * 16];    // wino_x3p_kernel: [0..7] wave 0, [8..15] wave 4
 #define ERD_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define ERD_TACC(acc, v) acc += __builtin_amdgcn_s_memtime() - v
 #else
@@ -1176,6 +1177,961 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
     }
 }
 
+// =====================================================================================================================
+// The three-limb form for 128 OUTPUT CHANNELS PER ITEM with eight PHASED waves (round 5; the default where Cout % 128 == 0 and
+// the launch has enough items).  wino_x3_kernel transforms every 32-tile block once per 64 output channels -- raw patch load,
+// B^T d B and the limb split run Cout / 64 times per tile (four times on the 256 -> 256 head towers) -- and its four data waves
+// (3 240 busy cycles per slice) are the critical path next to 1 536 cycles of matrix work (profiles/r04_wino_x3_trace.txt).
+// Here an item is 32 tiles x 128 couts: the same data work per slice feeds TWICE the matrix work.  128 couts x 32 tiles x 16
+// positions are 128 accumulator registers on each of EIGHT waves, so there is no room for separate data waves (twelve waves
+// would leave 168 registers each): every wave does both jobs, in two PHASES per slice --
+//   M: its share of slice g: wave w owns transform ROW w & 3 (positions 4 (w & 3) .. + 3) of cout blocks 2 (w >> 2), + 1 (of
+//      four): a position's V fragments (three limbs, 3 KB of LDS reads) feed TWELVE MFMAs (two cout blocks x six limb products) --
+//      a first version with wino_x3_kernel's ownership (eight positions x one cout block: 24 KB of fragment reads per wave and
+//      slice, 320 KB of LDS traffic per slice and workgroup) measured 7 400 cycles per slice, LDS-bound (profiles/
+//      r05_wino_x3p_trace.txt); weight fragments: a ring of four (position, cout block) units straight from L2 as before;
+//   D: its eighth of the data work for slice g + 1 (thread t: tile (t >> 2) & 31, channels 4 (t & 3) .., transform row t >> 7:
+//      two patch rows from the raw slice, row pass, column pass, limb split, twelve 8-byte stores; 2 x 16 bytes of raw staging);
+// -- and the two waves of a SIMD run them in OPPOSITE order (waves 0-3: M then D, waves 4-7: D then M), so that at any time a
+// SIMD hosts one wave issuing dependent MFMA chains (its issue slots are idle 28 of 32 cycles) and one wave issuing VALU / LDS
+// work at the lone-wave rate: the occupancy pattern of the role-split kernel with every wave busy all the time.  One workgroup
+// barrier per slice as before (V(g+1) complete, V(g) and raw(g+1) consumed).
+// Output: z[c] = (M A)[row][c] is local to a wave (the fp32 kernel's order (m0 + m1) + m2, (m1 - m2) - m3); y = A^T z needs three
+// rows: wave (row i) finishes output pixel (a, c) = (i >> 1, i & 1) of every tile for its two cout blocks from its own z and two
+// others', which travel IN BULK through the V buffer the last slice has just released (two rounds -- one per cout block -- of
+// 6 x 4 KB per cout pair, a barrier behind the writes and one behind the reads) instead of wino_x3_kernel's flag-polled
+// four-register rounds.  Same V values, same MFMA sequence per accumulator, same order of every sum: results are BIT-identical
+// to wino_x3_kernel (tests/test_gpu_wino_x3.py).
+constexpr int BNP = 128;                       // output channels per item
+constexpr int HPIX = 208;                      // raw pixel slots (the largest patch, 6 x 34, needs 204)
+
+__global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: raw0 | raw1 (2 x [HPIX][RCS] float4) | V0 | V1 (2 x VX_B) | sh_ss [4][scale 128 | shift 128] | sh_item [2]
+    constexpr unsigned RAWB = HPIX * RCS * 16, VOFF = 2 * RAWB, VB = VX_B, XOFF = VOFF + 2 * VB;
+    float* sh_ss = reinterpret_cast<float*>(smem + XOFF);
+    int* sh_item = reinterpret_cast<int*>(sh_ss + 4 * 2 * BNP);
+    char* const sm = smem;
+
+    const int tid = threadIdx.x;
+    const int Cin = p.Cin;
+    const int nks = Cin / KS;
+    const int nitems = p.nitems;
+    const int ncb32 = (p.Cout + 31) / 32;
+
+    auto decode = [&](int item) {
+        WinoItem it;
+        const int nb = item / p.blocks_per_nb;
+        int b = item - nb * p.blocks_per_nb;
+        int r = 0;
+        while (r + 1 < p.nreg && b >= p.reg[r + 1].block0) ++r;
+        const WinoRegion& rg = p.reg[r];
+        b -= rg.block0;
+        const int per_img = rg.nby * rg.nbx;
+        const int n = b / per_img;
+        const int rem = b - n * per_img;
+        const int by = rem / rg.nbx, bx = rem - by * rg.nbx;
+        const int lbw = rg.lbw;
+        it.s = __builtin_amdgcn_readfirstlane(rg.seg);
+        it.n = __builtin_amdgcn_readfirstlane(n);
+        it.y0 = __builtin_amdgcn_readfirstlane(2 * (rg.ty0 + by * (32 >> lbw)));
+        it.x0 = __builtin_amdgcn_readfirstlane(2 * (rg.tx0 + (bx << lbw)));
+        it.cout0 = __builtin_amdgcn_readfirstlane(nb * BNP);
+        it.lbw = __builtin_amdgcn_readfirstlane(lbw);
+        it.yl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].H, 2 * rg.ty1));
+        it.xl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].W, 2 * rg.tx1));
+        return it;
+    };
+    auto claim = [&](int k) -> int {
+        return p.sched ? (int)gridDim.x + atomicAdd(p.sched, 1) : (int)blockIdx.x + (k + 1) * (int)gridDim.x;
+    };
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int item0 = blockIdx.x;
+    if (item0 >= nitems) return;
+
+    // ---- roles -----------------------------------------------------------------------------------------------------------
+    const int li = lane & 31, h = lane >> 5;
+    const int ri = wave & 3, cp = wave >> 2;                         // matrix work: transform row (four positions), cout pair (of two)
+    const int t_chunk = tid & 3, t_tile = (tid >> 2) & 31;          // data work: (tile, 4 channels) ...
+    const int t_row = __builtin_amdgcn_readfirstlane(tid >> 7);     // ... and transform row (uniform per wave)
+    // row pass of B^T d B: R = d[A] +- d[B] with (A, B, sign) = (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -)
+    const int rowA = t_row == 0 ? 0 : (t_row == 2 ? 2 : 1), rowB = t_row == 2 ? 1 : (t_row == 3 ? 3 : 2);
+
+    // ---- matrix side state (wino_x3_kernel's matrix waves) ------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.U3), 0, (int)((size_t)16 * 3 * ncb32 * nks * 1024), 0x00020000);
+    const unsigned u_lane = (unsigned)lane * 16u;
+    const unsigned per_xl_b = (unsigned)ncb32 * (unsigned)nks * 1024u;          // bytes per (position, limb)
+    const unsigned pos0_b = (unsigned)(ri * 4 * 3) * per_xl_b;                  // this wave's first position
+    const unsigned cb_b = (unsigned)nks * 1024u;                                // bytes from a cout block to the next inside a plane
+    const unsigned v_lane = (unsigned)(ri * 4 * 3 * 1024 + h * 512 + ((li ^ (h * 8)) * 16));
+    WinoItem cur = decode(item0);
+    int k_item = 0;
+    unsigned u_item = (unsigned)__builtin_amdgcn_readfirstlane(((cur.cout0 >> 5) + 2 * cp) * nks * 1024);
+    // unit u = 2 j + b: position 4 ri + j, cout block 2 cp + b
+    f32x16 acc[8];
+    u32x4 ub[4][3];                                                             // weight-fragment ring: unit u lives in slot u & 3
+    bf16x8 vf[2][3];                                                            // tile fragments [position parity][limb]
+    auto load_u = [&](const int u, const unsigned soff) {                      // u: compile-time after unrolling
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            ub[u & 3][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)((u >> 1) * 3 + l) * per_xl_b + soff + (u & 1) * cb_b, 0);
+    };
+
+    // ---- data side state (wino_conv_kernel's data waves, on 512 threads) --------------------------------------------------
+    // The look-ahead pointer (raw slices are requested three slices ahead of the matrix slice) enters the next item inside ONE
+    // data phase: decode + this thread's two patch offsets + its two patch rows are ~60 instructions once per item (the role-split
+    // kernels stage them over three slices because their data waves are the critical path; here every wave carries an eighth).
+    WinoItem la = cur;                                   // the item of the look-ahead pointer
+    int la_ks = 0, k_la = 0;
+    unsigned la_soff = 0;
+    bool la_valid = true;
+    unsigned roff[2];
+    float4 rv[2];
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0].in), 0, 0, 0x00020000);
+    unsigned rdA = 0, rdB = 0, nrdA = 0, nrdB = 0;       // the transform's patch rows (it runs two slices behind the pointer) / of the item entered last
+    int tr_left = 0;
+    auto item_geometry = [&](const WinoItem& it, unsigned (&ro)[2], unsigned& gA, unsigned& gB, __amdgpu_buffer_rsrc_t& rs) {
+        const WinoSeg& sg = p.seg[it.s];
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+        const int lbw = it.lbw, bw = 1 << lbw, bh = 32 >> lbw;
+        const int pc_n = 2 * bw + 2, npix = (2 * bh + 2) * pc_n;
+        const int recip = (65536 + pc_n - 1) / pc_n;
+        const unsigned base_n = (unsigned)(it.n * sg.in_nstride);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i;
+            const int chunk = idx & 3, pix = idx >> 2;
+            const int pr = (pix * recip) >> 16, pc = pix - pr * pc_n;
+            const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
+            ro[i] = OOBV;
+            if (pix < npix && (unsigned)iy < (unsigned)sg.H && (unsigned)ix < (unsigned)sg.W)
+                ro[i] = (base_n + (unsigned)((iy * sg.W + ix) * Cin + chunk * 4)) * 4u;
+        }
+        const int t_ty = t_tile >> lbw, t_tx = t_tile & (bw - 1);
+        gA = (unsigned)((((2 * t_ty + rowA) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
+        gB = (unsigned)((((2 * t_ty + rowB) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
+    };
+    // the scale / shift slice of the item the pointer has just entered and the claim of the item after it: requested on entry,
+    // written to LDS at the end of the same phase (readable behind the slice's barrier)
+    struct Pending { float sc, sh; int claim, k; };
+    auto request_item_data = [&](Pending& pe) {
+        if (tid < BNP) {
+            const int co = la.cout0 + tid;
+            pe.sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
+            pe.sh = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
+        }
+        if (tid == BNP) pe.claim = claim(k_la);
+        pe.k = k_la;
+    };
+    auto flush_pending = [&](const Pending& pe) {
+        if (pe.k >= 0) {
+            if (tid < BNP) {
+                float* ss = sh_ss + (pe.k & 3) * (2 * BNP);
+                ss[tid] = pe.sc;
+                ss[BNP + tid] = pe.sh;
+            }
+            if (tid == BNP) sh_item[(pe.k + 1) & 1] = pe.claim;
+        }
+    };
+    // request the next raw slice of the look-ahead item ...
+    auto issue_next = [&](float4* dst) {
+        if (la_valid) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
+            la_soff += KS * 4;
+            ++la_ks;
+        }
+    };
+    // ... and, at the END of the phase (the transform's registers are dead), move the pointer on if that was its item's last slice
+    auto advance_item = [&](Pending& pe) {
+        if (la_valid && la_ks == nks) {                   // the pointer leaves item k_la (its successor was claimed >= 3 slices ago)
+            const int nx = __builtin_amdgcn_readfirstlane(sh_item[(k_la + 1) & 1]);
+            if (nx < nitems) {
+                la = decode(nx);
+                item_geometry(la, roff, nrdA, nrdB, rs_in);
+                la_ks = 0;
+                la_soff = 0;
+                ++k_la;
+                request_item_data(pe);
+            } else la_valid = false;
+        }
+    };
+    const bool st1_ok = (tid >> 2) + 128 < HPIX;
+    auto store_raw = [&](const float4* src, const unsigned par) {
+        // pixel tid >> 2 (+ 128 for the second chunk); recomputed per slice (three instructions) rather than kept in a register
+        // across the matrix phase -- the allocator otherwise spills it and its reload waits for EVERY load in flight
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const unsigned st_base = (unsigned)(((t >> 2) * RCS + (t & 3)) * 16);
+        *reinterpret_cast<float4*>(sm + par * RAWB + st_base) = src[0];
+        if (st1_ok) *reinterpret_cast<float4*>(sm + par * RAWB + st_base + 128 * RCS * 16) = src[1];
+    };
+    float4 pd[2][4];
+    auto transform_read = [&](const unsigned rpar) {
+        const char* rA = sm + rpar * RAWB + rdA;
+        const char* rB = sm + rpar * RAWB + rdB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            pd[0][c] = *reinterpret_cast<const float4*>(rA + c * (RCS * 16));
+            pd[1][c] = *reinterpret_cast<const float4*>(rB + c * (RCS * 16));
+        }
+        if (--tr_left == 0) {                             // the next slice belongs to the item the pointer entered last
+            rdA = nrdA;
+            rdB = nrdB;
+            tr_left = nks;
+        }
+    };
+    // this thread's 8 bytes inside a (position, limb) block of 1 KB = [k half][tile ^ 8 (k half)][8 channels] (wino_x3_kernel's layout)
+    // (recomputed where it is used -- eight instructions per slice -- for the same reason as store_raw's base)
+    auto v_write_base = [&]() -> unsigned {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int c = t & 3, tl = (t >> 2) & 31;
+        return VOFF + (unsigned)(t_row * 4 * 3072 + (c >> 1) * 512 + ((tl ^ ((c >> 1) * 8)) * 16) + (c & 1) * 8);
+    };
+    auto put = [&](char* dst, const float4 v) {        // four channels of one position -> three limb words of 8 bytes
+        uint2 hi, mid, lo;
+        erd::limbs3_pair(v.x, v.y, hi.x, mid.x, lo.x);
+        erd::limbs3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + 1024) = mid;
+        *reinterpret_cast<uint2*>(dst + 2048) = lo;
+    };
+    // D phase: raw(g+1) -> V(g+1) (this thread's row of four positions), raw(g+2) regs -> LDS over raw(g), request raw(g+3)
+    // row pass of B^T d B for this wave's transform row (uniform branch: a packed add or a packed subtract, no sign operand)
+    auto row_pass = [&](float4 (&R)[4]) __attribute__((always_inline)) {
+        if (t_row == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) R[c] = f4add(pd[0][c], pd[1][c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) R[c] = f4sub(pd[0][c], pd[1][c]);
+        }
+    };
+    unsigned long long t_d1 = 0, t_d2 = 0, t_d3 = 0, t_out = 0; (void)t_d1; (void)t_d2; (void)t_d3; (void)t_out;
+    auto data_phase = [&](const unsigned par, const unsigned u_tail) __attribute__((always_inline)) {
+        const unsigned npar = par ^ 1u;
+        ERD_T0(ta);
+        transform_read(npar);
+        __builtin_amdgcn_sched_barrier(0);
+        store_raw(rv, par);
+        issue_next(rv);
+#ifdef ERD_WINO_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        ERD_TACC(t_d1, ta);
+        ERD_T0(tb2);
+        float4 R[4];
+        row_pass(R);
+        char* v = sm + v_write_base() + npar * VB;
+        put(v + 0 * 3072, f4sub(R[0], R[2]));
+        put(v + 1 * 3072, f4add(R[1], R[2]));
+        put(v + 2 * 3072, f4sub(R[2], R[1]));
+        put(v + 3 * 3072, f4sub(R[1], R[3]));
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef ERD_WINO_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        ERD_TACC(t_d2, tb2);
+        ERD_T0(tc3);
+        Pending pe;
+        pe.sc = 1.f; pe.sh = 0.f; pe.claim = 0; pe.k = -1;
+        advance_item(pe);
+        flush_pending(pe);
+        // the ring slots of positions 2 and 3 are empty across this phase (its registers are the transform's); their fragments
+        // for the NEXT matrix phase are requested here, two positions (~400 matrix cycles) ahead of their use
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(2, u_tail);
+        load_u(3, u_tail);
+        ERD_TACC(t_d3, tc3);
+    };
+    // M phase: this wave's four positions x two cout blocks of slice g; the ring slot of unit u is re-loaded with unit u + 4 of
+    // this slice or u - 4 of the next one as soon as its six MFMAs have been issued
+    auto matrix_phase = [&](const unsigned par, const unsigned u_cur, const unsigned u_reload) __attribute__((always_inline)) {
+        const char* vc = sm + VOFF + v_lane + par * VB;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) vf[0][l] = *reinterpret_cast<const bf16x8*>(vc + l * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < 3) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) vf[(j + 1) & 1][l] = *reinterpret_cast<const bf16x8*>(vc + (j + 1) * 3072 + l * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // reads first: they travel behind this position's MFMAs
+            const bf16x8 vh = vf[j & 1][0], vm = vf[j & 1][1], vl = vf[j & 1][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int u = 2 * j + b;
+                const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[u & 3][0]), um = __builtin_bit_cast(bf16x8, ub[u & 3][1]),
+                             ul = __builtin_bit_cast(bf16x8, ub[u & 3][2]);
+                // rows = couts (U), columns = tiles (V); smallest terms first, as everywhere in the three-limb kernels
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[u], 0, 0, 0);
+                // the slot is free: unit u + 4 of this slice, or unit u - 4 of the next one for u = 4, 5 (slots 2 and 3 stay
+                // empty until the end of the following data phase)
+                if (u + 4 < 8) load_u(u + 4, u_cur); else if (u < 6) load_u(u - 4, u_reload);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // Output stage of the finished item (behind the last slice's barrier: V buffer xpar is free, every wave is here).
+    // Exchange slots of a cout pair (4 KB each = [4 register quads][64 lanes][16 B]): 0: z1[0], 1: z2[0], 2: z3[0], 3: z0[1],
+    // 4: z2[1], 5: z1[1]  (z0[0] and z3[1] are only needed by their owners).
+    auto output_stage = [&](const unsigned xpar) __attribute__((always_inline)) {
+        const WinoSeg& sg = p.seg[cur.s];
+        const float* ss = sh_ss + (k_item & 3) * (2 * BNP);
+        const int lbw = cur.lbw, bwm = (1 << lbw) - 1;
+        const int ty = li >> lbw, tx = li & bwm;
+        const int fa = ri >> 1, fc = ri & 1;                           // this wave finishes output pixel (fa, fc) of every tile
+        const int oy = cur.y0 + 2 * ty + fa, ox = cur.x0 + 2 * tx + fc;
+        const bool pix_ok = oy < cur.yl && ox < cur.xl;
+        const int64_t opix = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout;
+        const bool simple = !sg.res && !sg.mask && !p.colsum;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+            sg.out, 0, (int)((long long)sg.N * sg.out_nstride * 4), 0x00020000);
+        const float lo = p.relu ? 0.f : -__builtin_inff();
+        char* const xb = sm + VOFF + xpar * VB + cp * (6 * 4096) + lane * 16;
+        // slots this wave writes (its z[0] / z[1]; -1: nobody else needs it) and reads (the two other rows of its output, ascending)
+        const int w0 = ri == 1 ? 0 : ri == 2 ? 1 : ri == 3 ? 2 : -1;
+        const int w1 = ri == 0 ? 3 : ri == 1 ? 5 : ri == 2 ? 4 : -1;
+        const int rA = ri == 0 ? 0 : ri == 1 ? 3 : ri == 2 ? 0 : 5;
+        const int rB = ri == 0 ? 1 : ri == 1 ? 4 : ri == 2 ? 2 : 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            // z[c] = (M A)[row][c] of cout block b: the accumulators die here
+            const f32x16 z0 = (acc[0 + b] + acc[2 + b]) + acc[4 + b];
+            const f32x16 z1 = (acc[2 + b] - acc[4 + b]) - acc[6 + b];
+            if (w0 >= 0) {
+#pragma unroll
+                for (int qr = 0; qr < 4; ++qr)
+                    *reinterpret_cast<float4*>(xb + w0 * 4096 + qr * 1024) = make_float4(z0[4 * qr], z0[4 * qr + 1], z0[4 * qr + 2], z0[4 * qr + 3]);
+            }
+            if (w1 >= 0) {
+#pragma unroll
+                for (int qr = 0; qr < 4; ++qr)
+                    *reinterpret_cast<float4*>(xb + w1 * 4096 + qr * 1024) = make_float4(z1[4 * qr], z1[4 * qr + 1], z1[4 * qr + 2], z1[4 * qr + 3]);
+            }
+            __syncthreads();
+            f32x16 sa, sb;
+#pragma unroll
+            for (int qr = 0; qr < 4; ++qr) {
+                const float4 a4 = *reinterpret_cast<const float4*>(xb + rA * 4096 + qr * 1024);
+                const float4 b4 = *reinterpret_cast<const float4*>(xb + rB * 4096 + qr * 1024);
+                sa[4 * qr] = a4.x; sa[4 * qr + 1] = a4.y; sa[4 * qr + 2] = a4.z; sa[4 * qr + 3] = a4.w;
+                sb[4 * qr] = b4.x; sb[4 * qr + 1] = b4.y; sb[4 * qr + 2] = b4.z; sb[4 * qr + 3] = b4.w;
+            }
+            // y[0][c] = (z0 + z1) + z2 ; y[1][c] = (z1 - z2) - z3 with (own, sa, sb) put back in row order (the fp32 kernel's sums)
+            f32x16 yv;
+            if (ri == 0) yv = (z0 + sa) + sb;            // own = z0[0], sa = z1[0], sb = z2[0]
+            else if (ri == 1) yv = (sa + z1) + sb;       // sa = z0[1], own = z1[1], sb = z2[1]
+            else if (ri == 2) yv = (sa - z0) - sb;       // sa = z1[0], own = z2[0], sb = z3[0]
+            else yv = (sa - sb) - z1;                    // sa = z1[1], sb = z2[1], own = z3[1]
+            float4 cs[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {                          // registers 4 gq .. 4 gq + 3: couts 8 gq + 4 h + {0..3} of the block
+                const int cl = 32 * (2 * cp + b) + 8 * gq + 4 * h;   // 0..127 inside the item's cout block
+                const int co0 = cur.cout0 + cl;
+                const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                const float4 sh = *reinterpret_cast<const float4*>(ss + BNP + cl);
+                float4 v = make_float4(yv[4 * gq] * sc.x + sh.x, yv[4 * gq + 1] * sc.y + sh.y, yv[4 * gq + 2] * sc.z + sh.z,
+                                       yv[4 * gq + 3] * sc.w + sh.w);
+                cs[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (simple) {
+                    u32x4 o;
+                    o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
+                    o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix_ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
+                } else if (pix_ok) {
+                    const int64_t o = opix + co0;
+                    if (sg.res) v = f4add(v, *reinterpret_cast<const float4*>(sg.res + o));
+                    if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    if (sg.mask) {
+                        const float4 mk = *reinterpret_cast<const float4*>(sg.mask + o);
+                        v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
+                                        mk.w > 0.f ? v.w : 0.f);
+                    }
+                    *reinterpret_cast<float4*>(sg.out + o) = v;
+                    cs[gq] = v;
+                }
+            }
+            if (p.colsum) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        cs[gq].x += __shfl_xor(cs[gq].x, o, 64); cs[gq].y += __shfl_xor(cs[gq].y, o, 64);
+                        cs[gq].z += __shfl_xor(cs[gq].z, o, 64); cs[gq].w += __shfl_xor(cs[gq].w, o, 64);
+                    }
+                    const int co0 = cur.cout0 + 32 * (2 * cp + b) + 8 * gq + 4 * h;
+                    if (li == 0) {
+                        float* cpt = p.colsum + (p.colsum_copies > 1 ? (blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) + co0;
+                        atomicAdd(cpt + 0, cs[gq].x); atomicAdd(cpt + 1, cs[gq].y); atomicAdd(cpt + 2, cs[gq].z); atomicAdd(cpt + 3, cs[gq].w);
+                    }
+                }
+            }
+            __syncthreads();                              // the slots are free: next round's writes / the next slice's V stores
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------
+    {
+        float4 rvb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rvb[i] = rv[i]; }
+        item_geometry(la, roff, nrdA, nrdB, rs_in);
+        Pending pe;
+        pe.sc = 1.f; pe.sh = 0.f; pe.claim = 0; pe.k = -1;
+        request_item_data(pe);
+        rdA = nrdA;
+        rdB = nrdB;
+        tr_left = nks;
+        flush_pending(pe);
+        pe.k = -1;
+        issue_next(rv);                                   // raw(0)
+        issue_next(rvb);                                  // raw(1)   (nks >= 4: the pointer cannot leave the first item here)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_u(q, u_item);
+        store_raw(rv, 0);
+        __syncthreads();                                  // raw(0) is in LDS, the first claim is published
+        transform_read(0);
+        float4 R[4];
+        row_pass(R);
+        char* v = sm + v_write_base();
+        put(v + 0 * 3072, f4sub(R[0], R[2]));
+        put(v + 1 * 3072, f4add(R[1], R[2]));
+        put(v + 2 * 3072, f4sub(R[2], R[1]));
+        put(v + 3 * 3072, f4sub(R[1], R[3]));
+        store_raw(rvb, 1);
+        issue_next(rv);                                   // raw(2)
+        __syncthreads();                                  // V(0) complete, raw(1) in LDS
+    }
+
+    // ---- the slice stream: iteration g multiplies slice g (M) and transforms raw(g+1) -> V(g+1), stores raw(g+2), requests
+    //      raw(g+3) (D); waves 0-3: M then D, waves 4-7: D then M (uniform branches around the two call sites of D) ----
+#ifndef ERD_WX3P_ORDER
+#define ERD_WX3P_ORDER 1                       // tuning: 1: staggered (waves 4-7 transform first), 0: all waves M then D, 2: all D then M
+#endif
+    const bool d_first = ERD_WX3P_ORDER == 1 ? __builtin_amdgcn_readfirstlane(wave >> 2) != 0 : ERD_WX3P_ORDER >= 2;
+    unsigned long long t_bar = 0, t_m = 0, t_d = 0; (void)t_bar; (void)t_m; (void)t_d;
+    ERD_T0(t_begin);
+    int g = 0;
+    for (;;) {
+        const int nxt_item = __builtin_amdgcn_readfirstlane(sh_item[(k_item + 1) & 1]);
+        const bool has_next = nxt_item < nitems;
+        const WinoItem nxt = has_next ? decode(nxt_item) : cur;
+        const unsigned u_next = (unsigned)__builtin_amdgcn_readfirstlane(((nxt.cout0 >> 5) + 2 * cp) * nks * 1024);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        for (int ks = 0; ks < nks; ++ks, ++g) {
+            const unsigned par = (unsigned)(g & 1);
+            const bool last = ks + 1 == nks;
+            const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(u_item + (unsigned)ks * 1024u));
+            const unsigned u_reload = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)(last ? u_next : u_item + (unsigned)(ks + 1) * 1024u));
+            { ERD_T0(td); if (d_first) data_phase(par, u_cur); ERD_TACC(t_d, td); }
+            __builtin_amdgcn_sched_barrier(0);
+#if ERD_WX3P_ORDER == 3       // tuning: all waves transform, workgroup barrier, all waves multiply (no VALU work beside an MFMA stream)
+            { ERD_T0(tb); __syncthreads(); ERD_TACC(t_bar, tb); }
+#endif
+            { ERD_T0(tm); matrix_phase(par, u_cur, u_reload); ERD_TACC(t_m, tm); }
+            __builtin_amdgcn_sched_barrier(0);
+            { ERD_T0(td); if (!d_first) data_phase(par, u_reload); ERD_TACC(t_d, td); }
+            { ERD_T0(tb); __syncthreads(); ERD_TACC(t_bar, tb); }  // V(g+1) complete, V(g) and raw(g+1) consumed, raw(g+2) stored
+        }
+        { ERD_T0(to); output_stage((unsigned)((g - 1) & 1)); ERD_TACC(t_out, to); }
+        if (!has_next) {
+#ifdef ERD_WINO_TRACE       // [0..7] wave 0 (M then D), [8..15] wave 4 (D then M): total, barrier wait, matrix phases, data phases (of which:
+                            // reads + raw store, transform + V stores, item switch + ring tail), output stage
+            if ((wave & 3) == 0 && lane == 0 && blockIdx.x < 256) {
+                unsigned long long* tr = g_wino_trace_p + blockIdx.x * 16 + (wave >> 2) * 8;
+                tr[0] = __builtin_amdgcn_s_memtime() - t_begin;
+                tr[1] = t_bar;
+                tr[2] = t_m;
+                tr[3] = t_d;
+                tr[4] = t_d1;
+                tr[5] = t_d2;
+                tr[6] = t_d3;
+                tr[7] = t_out;
+            }
+#endif
+            if (tid == 0 && p.sched) {                       // the last workgroup to leave re-arms the counters
+                if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
+            }
+            break;
+        }
+        cur = nxt;
+        u_item = u_next;
+        ++k_item;
+    }
+}
+
+// =====================================================================================================================
+// The three-limb form for 128 output channels per item on FOUR waves -- ONE PER SIMD, 512 registers each (round 5).
+// What the measurements of this round say (tools/mfma_valu_coissue.hip, tools/mfma_valu_interleave.hip, profiles/r05_*):
+//   * VALU instructions placed BETWEEN the dependent MFMAs of the same wave are free up to ~6 per v_mfma_f32_32x32x16_bf16 (33.3 ->
+//     35.0 cycles per MFMA, dependent or independent VALU chains alike): in-order issue stalls on the next dependent MFMA for 32
+//     cycles anyway;
+//   * a VALU wave BESIDE an MFMA wave of the same SIMD gets one issue slot per 8 cycles, and the phases of wino_x3p_kernel (eight
+//     waves, each alternating a matrix phase and a data phase) never overlapped as planned: 7 300 cycles per slice against 3 072 of
+//     matrix work, whatever the order of the phases (profiles/r05_wino_x3p_trace.txt).
+// So: one wave per SIMD that owns its matrix pipe, with the data work of the NEXT slice woven into its MFMA stream, ~4 vector
+// instructions behind each MFMA.  512 registers (256 accumulators: transform row `wave` = four positions x all four cout blocks of
+// 32 x 32 tiles; a ring of four weight-fragment units; the transform's 12 patch reads and both output rows live) leave room for
+// that.  A position's V fragments (3 KB) feed 24 MFMAs; LDS traffic per slice and workgroup: 48 KB of fragment reads + 48 KB patch
+// reads + 48 + 16 KB of stores (wino_x3_kernel: 96 + 48 + 64 per 64 couts).  Data work per thread = wino_x3_kernel's data waves'
+// (256 threads: tile, four channels, two transform rows).  Output: the bulk exchange of wino_x3p_kernel, two cout blocks per round.
+// Same V values, same MFMA sequence per accumulator, same order of every sum: results BIT-identical to wino_x3_kernel.
+constexpr int BNS = 128;                       // output channels per item
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_x3s_kernel(const WinoDesc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: raw0 | raw1 (2 x [MAXPIX][RCS] float4) | V0 | V1 (2 x VX_B) | sh_ss [4][scale 128 | shift 128] | sh_item [2]
+    constexpr unsigned RAWB = RAW_LDS_F4 * 16, VOFF = 2 * RAWB, VB = VX_B, XOFF = VOFF + 2 * VB;
+    float* sh_ss = reinterpret_cast<float*>(smem + XOFF);
+    int* sh_item = reinterpret_cast<int*>(sh_ss + 4 * 2 * BNS);
+    char* const sm = smem;
+
+    const int tid = threadIdx.x;
+    const int Cin = p.Cin;
+    const int nks = Cin / KS;
+    const int nitems = p.nitems;
+    const int ncb32 = (p.Cout + 31) / 32;
+
+    auto decode = [&](int item) {
+        WinoItem it;
+        const int nb = item / p.blocks_per_nb;
+        int b = item - nb * p.blocks_per_nb;
+        int r = 0;
+        while (r + 1 < p.nreg && b >= p.reg[r + 1].block0) ++r;
+        const WinoRegion& rg = p.reg[r];
+        b -= rg.block0;
+        const int per_img = rg.nby * rg.nbx;
+        const int n = b / per_img;
+        const int rem = b - n * per_img;
+        const int by = rem / rg.nbx, bx = rem - by * rg.nbx;
+        const int lbw = rg.lbw;
+        it.s = __builtin_amdgcn_readfirstlane(rg.seg);
+        it.n = __builtin_amdgcn_readfirstlane(n);
+        it.y0 = __builtin_amdgcn_readfirstlane(2 * (rg.ty0 + by * (32 >> lbw)));
+        it.x0 = __builtin_amdgcn_readfirstlane(2 * (rg.tx0 + (bx << lbw)));
+        it.cout0 = __builtin_amdgcn_readfirstlane(nb * BNS);
+        it.lbw = __builtin_amdgcn_readfirstlane(lbw);
+        it.yl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].H, 2 * rg.ty1));
+        it.xl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].W, 2 * rg.tx1));
+        return it;
+    };
+    auto claim = [&](int k) -> int {
+        return p.sched ? (int)gridDim.x + atomicAdd(p.sched, 1) : (int)blockIdx.x + (k + 1) * (int)gridDim.x;
+    };
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int item0 = blockIdx.x;
+    if (item0 >= nitems) return;
+
+    // ---- roles -----------------------------------------------------------------------------------------------------------
+    const int li = lane & 31, h = lane >> 5;
+    const int ri = wave;                                             // matrix work: transform row (four positions), all four cout blocks
+    const int t_chunk = tid & 3, t_tile = (tid >> 2) & 31;          // data work: (tile, 4 channels) ...
+    const int t_half = __builtin_amdgcn_readfirstlane(tid >> 7);    // ... and transform rows 2 t_half, 2 t_half + 1 (uniform per wave)
+
+    // ---- matrix side state ------------------------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.U3), 0, (int)((size_t)16 * 3 * ncb32 * nks * 1024), 0x00020000);
+    const unsigned u_lane = (unsigned)lane * 16u;
+    const unsigned per_xl_b = (unsigned)ncb32 * (unsigned)nks * 1024u;          // bytes per (position, limb)
+    const unsigned pos0_b = (unsigned)(ri * 4 * 3) * per_xl_b;                  // this wave's first position
+    const unsigned cb_b = (unsigned)nks * 1024u;                                // bytes from a cout block to the next inside a plane
+    const unsigned v_lane = (unsigned)(ri * 4 * 3 * 1024 + h * 512 + ((li ^ (h * 8)) * 16));
+    WinoItem cur = decode(item0);
+    int k_item = 0;
+    unsigned u_item = (unsigned)__builtin_amdgcn_readfirstlane((cur.cout0 >> 5) * nks * 1024);
+    // unit u = 4 j + c: position 4 ri + j, cout block c
+    f32x16 acc[16];
+    u32x4 ub[4][3];                                                             // weight-fragment ring: unit u lives in slot u & 3
+    bf16x8 vf[2][3];                                                            // tile fragments [position parity][limb]
+    auto load_u = [&](const int u, const unsigned soff) {                      // u: compile-time after unrolling
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            ub[u & 3][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)((u >> 2) * 3 + l) * per_xl_b + soff + (u & 3) * cb_b, 0);
+    };
+
+    // ---- data side state (wino_x3_kernel's data waves, on all 256 threads) -------------------------------------------------
+    WinoItem la = cur;                                   // the item of the look-ahead pointer (raw slices are requested three slices ahead)
+    int la_ks = 0, k_la = 0;
+    unsigned la_soff = 0;
+    bool la_valid = true;
+    unsigned roff[NCH];
+    float4 rv[NCH];
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0].in), 0, 0, 0x00020000);
+    unsigned rd0 = 0, rd1 = 0, rd2 = 0, nrd0 = 0, nrd1 = 0, nrd2 = 0;
+    int tr_left = 0;
+    auto item_geometry = [&](const WinoItem& it, unsigned (&ro)[NCH], unsigned& g0, unsigned& g1, unsigned& g2, __amdgpu_buffer_rsrc_t& rs) {
+        const WinoSeg& sg = p.seg[it.s];
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
+        const int lbw = it.lbw, bw = 1 << lbw, bh = 32 >> lbw;
+        const int pc_n = 2 * bw + 2, npix = (2 * bh + 2) * pc_n;
+        const int recip = (65536 + pc_n - 1) / pc_n;
+        const unsigned base_n = (unsigned)(it.n * sg.in_nstride);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + 256 * i;
+            const int chunk = idx & 3, pix = idx >> 2;
+            const int pr = (pix * recip) >> 16, pc = pix - pr * pc_n;
+            const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
+            ro[i] = OOBV;
+            if (pix < npix && (unsigned)iy < (unsigned)sg.H && (unsigned)ix < (unsigned)sg.W)
+                ro[i] = (base_n + (unsigned)((iy * sg.W + ix) * Cin + chunk * 4)) * 4u;
+        }
+        const int t_ty = t_tile >> lbw, t_tx = t_tile & (bw - 1);
+        g0 = (unsigned)((((2 * t_ty + t_half) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
+        g1 = g0 + (unsigned)(pc_n * RCS * 16);
+        g2 = g1 + (unsigned)(pc_n * RCS * 16);
+    };
+    struct Pending { float sc, sh; int claim, k; };
+    auto request_item_data = [&](Pending& pe) {
+        if (tid < BNS) {
+            const int co = la.cout0 + tid;
+            pe.sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
+            pe.sh = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
+        }
+        if (tid == BNS) pe.claim = claim(k_la);
+        pe.k = k_la;
+    };
+    auto flush_pending = [&](const Pending& pe) {
+        if (pe.k >= 0) {
+            if (tid < BNS) {
+                float* ss = sh_ss + (pe.k & 3) * (2 * BNS);
+                ss[tid] = pe.sc;
+                ss[BNS + tid] = pe.sh;
+            }
+            if (tid == BNS) sh_item[(pe.k + 1) & 1] = pe.claim;
+        }
+    };
+    auto issue_next = [&](float4* dst) {
+        if (la_valid) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
+            la_soff += KS * 4;
+            ++la_ks;
+        }
+    };
+    auto advance_item = [&](Pending& pe) {
+        if (la_valid && la_ks == nks) {                   // the pointer leaves item k_la (its successor was claimed >= 3 slices ago)
+            const int nx = __builtin_amdgcn_readfirstlane(sh_item[(k_la + 1) & 1]);
+            if (nx < nitems) {
+                la = decode(nx);
+                item_geometry(la, roff, nrd0, nrd1, nrd2, rs_in);
+                la_ks = 0;
+                la_soff = 0;
+                ++k_la;
+                request_item_data(pe);
+            } else la_valid = false;
+        }
+    };
+    const unsigned st_base = (unsigned)(((tid >> 2) * RCS + (tid & 3)) * 16);
+    auto store_raw = [&](const float4* src, const unsigned par) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *reinterpret_cast<float4*>(sm + par * RAWB + st_base + i * (64 * RCS * 16)) = src[i];
+    };
+    float4 pd[3][4];
+    auto transform_read = [&](const unsigned rpar) {
+        const char* r0 = sm + rpar * RAWB + rd0;
+        const char* r1 = sm + rpar * RAWB + rd1;
+        const char* r2 = sm + rpar * RAWB + rd2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            pd[0][c] = *reinterpret_cast<const float4*>(r0 + c * (RCS * 16));
+            pd[1][c] = *reinterpret_cast<const float4*>(r1 + c * (RCS * 16));
+            pd[2][c] = *reinterpret_cast<const float4*>(r2 + c * (RCS * 16));
+        }
+        if (--tr_left == 0) {                             // the next slice belongs to the item the pointer entered last
+            rd0 = nrd0;
+            rd1 = nrd1;
+            rd2 = nrd2;
+            tr_left = nks;
+        }
+    };
+    // rows 2 t_half, 2 t_half + 1 of B^T d: half 0 needs patch rows 0,1,2 (r0 = d0 - d2, r1 = d1 + d2); half 1 rows 1,2,3 (r2 = d2 - d1, r3 = d1 - d3)
+    float4 rr[2][4];
+    auto row_pass = [&]() {
+        if (t_half == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { rr[0][c] = f4sub(pd[0][c], pd[2][c]); rr[1][c] = f4add(pd[1][c], pd[2][c]); }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { rr[0][c] = f4sub(pd[1][c], pd[0][c]); rr[1][c] = f4sub(pd[0][c], pd[2][c]); }
+        }
+    };
+    // this thread's 8 bytes inside a (position, limb) block of 1 KB = [k half][tile ^ 8 (k half)][8 channels] (wino_x3_kernel's layout)
+    const unsigned wr_base = VOFF + (unsigned)(t_half * 8 * 3072 + (t_chunk >> 1) * 512 + ((t_tile ^ ((t_chunk >> 1) * 8)) * 16) + (t_chunk & 1) * 8);
+    auto put = [&](char* dst, const float4 v) {        // four channels of one position -> three limb words of 8 bytes
+        uint2 hi, mid, lo;
+        erd::limbs3_pair(v.x, v.y, hi.x, mid.x, lo.x);
+        erd::limbs3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + 1024) = mid;
+        *reinterpret_cast<uint2*>(dst + 2048) = lo;
+    };
+    // position (2 t_half + a) * 4 + k of V buffer vpar
+    auto put_pos = [&](const int a, const int k, const unsigned vpar) {
+        char* v = sm + wr_base + vpar * VB + (a * 4 + k) * 3072;
+        if (k == 0) put(v, f4sub(rr[a][0], rr[a][2]));
+        if (k == 1) put(v, f4add(rr[a][1], rr[a][2]));
+        if (k == 2) put(v, f4sub(rr[a][2], rr[a][1]));
+        if (k == 3) put(v, f4sub(rr[a][1], rr[a][3]));
+    };
+    // The data work of one slice in sixteen pieces, one behind each unit's six MFMAs: raw(g+1) -> V(g+1), raw(g+2) registers ->
+    // LDS over raw(g), request raw(g+3); the pointer bookkeeping last
+    auto data_piece = [&](const int u, const unsigned par) __attribute__((always_inline)) {
+        const unsigned npar = par ^ 1u;
+        if (u == 0) transform_read(npar);
+        if (u == 1) { store_raw(rv, par); issue_next(rv); }
+        if (u == 2) row_pass();
+        if (u >= 3 && u < 11) put_pos((u - 3) >> 2, (u - 3) & 3, npar);
+        if (u == 11) {
+            Pending pe;
+            pe.sc = 1.f; pe.sh = 0.f; pe.claim = 0; pe.k = -1;
+            advance_item(pe);
+            flush_pending(pe);
+        }
+    };
+    // One slice: sixteen units of six MFMAs (position 4 ri + (u >> 2), cout block u & 3), each followed by its piece of the data
+    // work; the ring slot of unit u is re-loaded with unit u + 4 of this slice or u - 12 of the next one
+    auto slice = [&](const unsigned par, const unsigned u_cur, const unsigned u_reload) __attribute__((always_inline)) {
+        const char* vc = sm + VOFF + v_lane + par * VB;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) vf[0][l] = *reinterpret_cast<const bf16x8*>(vc + l * 1024);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = u >> 2;
+            if ((u & 3) == 0 && j < 3) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) vf[(j + 1) & 1][l] = *reinterpret_cast<const bf16x8*>(vc + (j + 1) * 3072 + l * 1024);
+            }
+            const bf16x8 vh = vf[j & 1][0], vm = vf[j & 1][1], vl = vf[j & 1][2];
+            const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[u & 3][0]), um = __builtin_bit_cast(bf16x8, ub[u & 3][1]),
+                         ul = __builtin_bit_cast(bf16x8, ub[u & 3][2]);
+            // rows = couts (U), columns = tiles (V); smallest terms first, as everywhere in the three-limb kernels
+#ifdef ERD_WX3S_NOMFMA      // timing probe: everything but the matrix instructions (results are wrong)
+            acc[u][0] += __builtin_bit_cast(float4, ul).x * __builtin_bit_cast(float4, vh).x + __builtin_bit_cast(float4, um).x * __builtin_bit_cast(float4, vm).x +
+                         __builtin_bit_cast(float4, uh).x * __builtin_bit_cast(float4, vl).x;
+#else
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[u], 0, 0, 0);
+#endif
+#ifndef ERD_WX3S_NOLOAD     // (timing probe: the ring keeps the first slice's fragments)
+            if (u + 4 < 16) load_u(u + 4, u_cur); else load_u(u - 12, u_reload);
+#endif
+#ifndef ERD_WX3S_NODATA     // (timing probe: no transform -- V keeps the prologue's slice)
+            data_piece(u, par);
+#endif
+            // pin: LDS reads of this unit first (they are consumed units later), then one MFMA / five vector instructions, six times;
+            // LDS stores and the fragment loads fall behind
+#ifndef ERD_WX3S_NOPIN
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // Output stage of the finished item (behind the last slice's barrier: V buffer xpar is free, every wave is here).
+    // Two rounds of two cout blocks; exchange slots of a cout block (4 KB each = [4 register quads][64 lanes][16 B]):
+    // 0: z1[0], 1: z2[0], 2: z3[0], 3: z0[1], 4: z2[1], 5: z1[1]  (z0[0] and z3[1] are only needed by their owners).
+    auto output_stage = [&](const unsigned xpar) __attribute__((always_inline)) {
+        const WinoSeg& sg = p.seg[cur.s];
+        const float* ss = sh_ss + (k_item & 3) * (2 * BNS);
+        const int lbw = cur.lbw, bwm = (1 << lbw) - 1;
+        const int ty = li >> lbw, tx = li & bwm;
+        const int fa = ri >> 1, fc = ri & 1;                           // this wave finishes output pixel (fa, fc) of every tile
+        const int oy = cur.y0 + 2 * ty + fa, ox = cur.x0 + 2 * tx + fc;
+        const bool pix_ok = oy < cur.yl && ox < cur.xl;
+        const int64_t opix = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout;
+        const bool simple = !sg.res && !sg.mask && !p.colsum;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+            sg.out, 0, (int)((long long)sg.N * sg.out_nstride * 4), 0x00020000);
+        const float lo = p.relu ? 0.f : -__builtin_inff();
+        char* const xb = sm + VOFF + xpar * VB + lane * 16;
+        const int w0 = ri == 1 ? 0 : ri == 2 ? 1 : ri == 3 ? 2 : -1;
+        const int w1 = ri == 0 ? 3 : ri == 1 ? 5 : ri == 2 ? 4 : -1;
+        const int rA = ri == 0 ? 0 : ri == 1 ? 3 : ri == 2 ? 0 : 5;
+        const int rB = ri == 0 ? 1 : ri == 1 ? 4 : ri == 2 ? 2 : 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f32x16 z0[2], z1[2];
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int c = 2 * r + bb;
+                // z[.] = (M A)[row][.] of cout block c: the accumulators die here
+                z0[bb] = (acc[0 + c] + acc[4 + c]) + acc[8 + c];
+                z1[bb] = (acc[4 + c] - acc[8 + c]) - acc[12 + c];
+                if (w0 >= 0) {
+#pragma unroll
+                    for (int qr = 0; qr < 4; ++qr)
+                        *reinterpret_cast<float4*>(xb + (bb * 6 + w0) * 4096 + qr * 1024) =
+                            make_float4(z0[bb][4 * qr], z0[bb][4 * qr + 1], z0[bb][4 * qr + 2], z0[bb][4 * qr + 3]);
+                }
+                if (w1 >= 0) {
+#pragma unroll
+                    for (int qr = 0; qr < 4; ++qr)
+                        *reinterpret_cast<float4*>(xb + (bb * 6 + w1) * 4096 + qr * 1024) =
+                            make_float4(z1[bb][4 * qr], z1[bb][4 * qr + 1], z1[bb][4 * qr + 2], z1[bb][4 * qr + 3]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int c = 2 * r + bb;
+                f32x16 sa, sb;
+#pragma unroll
+                for (int qr = 0; qr < 4; ++qr) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(xb + (bb * 6 + rA) * 4096 + qr * 1024);
+                    const float4 b4 = *reinterpret_cast<const float4*>(xb + (bb * 6 + rB) * 4096 + qr * 1024);
+                    sa[4 * qr] = a4.x; sa[4 * qr + 1] = a4.y; sa[4 * qr + 2] = a4.z; sa[4 * qr + 3] = a4.w;
+                    sb[4 * qr] = b4.x; sb[4 * qr + 1] = b4.y; sb[4 * qr + 2] = b4.z; sb[4 * qr + 3] = b4.w;
+                }
+                // y[0][c] = (z0 + z1) + z2 ; y[1][c] = (z1 - z2) - z3 with (own, sa, sb) put back in row order (the fp32 kernel's sums)
+                f32x16 yv;
+                if (ri == 0) yv = (z0[bb] + sa) + sb;            // own = z0[0], sa = z1[0], sb = z2[0]
+                else if (ri == 1) yv = (sa + z1[bb]) + sb;       // sa = z0[1], own = z1[1], sb = z2[1]
+                else if (ri == 2) yv = (sa - z0[bb]) - sb;       // sa = z1[0], own = z2[0], sb = z3[0]
+                else yv = (sa - sb) - z1[bb];                    // sa = z1[1], sb = z2[1], own = z3[1]
+                float4 cs[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {                          // registers 4 gq .. 4 gq + 3: couts 8 gq + 4 h + {0..3} of the block
+                    const int cl = 32 * c + 8 * gq + 4 * h;              // 0..127 inside the item's cout block
+                    const int co0 = cur.cout0 + cl;
+                    const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                    const float4 sh = *reinterpret_cast<const float4*>(ss + BNS + cl);
+                    float4 v = make_float4(yv[4 * gq] * sc.x + sh.x, yv[4 * gq + 1] * sc.y + sh.y, yv[4 * gq + 2] * sc.z + sh.z,
+                                           yv[4 * gq + 3] * sc.w + sh.w);
+                    cs[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (simple) {
+                        u32x4 o;
+                        o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
+                        o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix_ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
+                    } else if (pix_ok) {
+                        const int64_t o = opix + co0;
+                        if (sg.res) v = f4add(v, *reinterpret_cast<const float4*>(sg.res + o));
+                        if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                        if (sg.mask) {
+                            const float4 mk = *reinterpret_cast<const float4*>(sg.mask + o);
+                            v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
+                                            mk.w > 0.f ? v.w : 0.f);
+                        }
+                        *reinterpret_cast<float4*>(sg.out + o) = v;
+                        cs[gq] = v;
+                    }
+                }
+                if (p.colsum) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) {
+                            cs[gq].x += __shfl_xor(cs[gq].x, o, 64); cs[gq].y += __shfl_xor(cs[gq].y, o, 64);
+                            cs[gq].z += __shfl_xor(cs[gq].z, o, 64); cs[gq].w += __shfl_xor(cs[gq].w, o, 64);
+                        }
+                        const int co0 = cur.cout0 + 32 * c + 8 * gq + 4 * h;
+                        if (li == 0) {
+                            float* cpt = p.colsum + (p.colsum_copies > 1 ? (blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) + co0;
+                            atomicAdd(cpt + 0, cs[gq].x); atomicAdd(cpt + 1, cs[gq].y); atomicAdd(cpt + 2, cs[gq].z); atomicAdd(cpt + 3, cs[gq].w);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                              // the slots are free: next round's writes / the next slice's V stores
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------
+    {
+        float4 rvb[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) { rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rvb[i] = rv[i]; }
+        item_geometry(la, roff, nrd0, nrd1, nrd2, rs_in);
+        Pending pe;
+        pe.sc = 1.f; pe.sh = 0.f; pe.claim = 0; pe.k = -1;
+        request_item_data(pe);
+        rd0 = nrd0;
+        rd1 = nrd1;
+        rd2 = nrd2;
+        tr_left = nks;
+        flush_pending(pe);
+        issue_next(rv);                                   // raw(0)
+        issue_next(rvb);                                  // raw(1)   (nks >= 4: the pointer cannot leave the first item here)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_u(u, u_item);
+        store_raw(rv, 0);
+        __syncthreads();                                  // raw(0) is in LDS, the first claim is published
+        transform_read(0);
+        row_pass();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) put_pos(q >> 2, q & 3, 0);
+        store_raw(rvb, 1);
+        issue_next(rv);                                   // raw(2)
+        __syncthreads();                                  // V(0) complete, raw(1) in LDS
+    }
+
+    // ---- the slice stream ---------------------------------------------------------------------------------------------------
+    unsigned long long t_bar = 0, t_out = 0; (void)t_bar; (void)t_out;
+    ERD_T0(t_begin);
+    int g = 0;
+    for (;;) {
+        const int nxt_item = __builtin_amdgcn_readfirstlane(sh_item[(k_item + 1) & 1]);
+        const bool has_next = nxt_item < nitems;
+        const WinoItem nxt = has_next ? decode(nxt_item) : cur;
+        const unsigned u_next = (unsigned)__builtin_amdgcn_readfirstlane((nxt.cout0 >> 5) * nks * 1024);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        for (int ks = 0; ks < nks; ++ks, ++g) {
+            const unsigned par = (unsigned)(g & 1);
+            const bool last = ks + 1 == nks;
+            const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(u_item + (unsigned)ks * 1024u));
+            const unsigned u_reload = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)(last ? u_next : u_item + (unsigned)(ks + 1) * 1024u));
+            slice(par, u_cur, u_reload);
+            { ERD_T0(tb); __syncthreads(); ERD_TACC(t_bar, tb); }  // V(g+1) complete, V(g) and raw(g+1) consumed, raw(g+2) stored
+        }
+        { ERD_T0(to); output_stage((unsigned)((g - 1) & 1)); ERD_TACC(t_out, to); }
+        if (!has_next) {
+#ifdef ERD_WINO_TRACE       // [0..3] wave 0: total, barrier wait, output stage, items
+            if (wave == 0 && lane == 0 && blockIdx.x < 256) {
+                unsigned long long* tr = g_wino_trace_p + blockIdx.x * 16;
+                tr[0] = __builtin_amdgcn_s_memtime() - t_begin;
+                tr[1] = t_bar;
+                tr[2] = t_out;
+                tr[3] = (unsigned long long)(k_item + 1);
+            }
+#endif
+            if (tid == 0 && p.sched) {                       // the last workgroup to leave re-arms the counters
+                if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
+            }
+            break;
+        }
+        cur = nxt;
+        u_item = u_next;
+        ++k_item;
+    }
+}
+
 __global__ __launch_bounds__(256) void wino_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ U3, int Cout,
                                                               int Cin, int flip) {
     const int cop = (Cout + 31) / 32 * 32;
@@ -1198,6 +2154,10 @@ extern "C" int erd_wino_weights(const float* w_ohwi, float* U, int Cout, int Cin
 extern "C" int erd_wino_trace(unsigned long long* out) {       // debug builds only
     (void)hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_trace), sizeof(g_wino_trace));
+}
+extern "C" int erd_wino_trace_p(unsigned long long* out) {     // debug builds only
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_trace_p), sizeof(g_wino_trace_p));
 }
 #endif
 
@@ -1271,9 +2231,7 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     }
     d.nreg = nreg;
     d.blocks_per_nb = blocks;
-    const int ncb = (Cout + BN - 1) / BN;
     if (blocks == 0) return 0;
-    d.nitems = blocks * ncb;
     int ncu = 0;
     {
         int dev = 0;
@@ -1283,11 +2241,42 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
             cached = prop.multiProcessorCount;
         ncu = cached > 0 ? cached : 256;
     }
+    // 128 couts per item (wino_x3p_kernel) where the cout count allows it and the launch still has enough items to balance over
+    // the persistent grid; ERD_WINO_P=0: never, 2: whenever Cout % 128 == 0 (A/B aids), ERD_WINO_P_MIN: items per CU x 100
+    // (read per launch, not cached: tests/test_gpu_wino_x3.py flips it inside one process to compare the two kernels bit for bit)
+    const char* const e_mode = getenv("ERD_WINO_P");
+    const char* const e_min = getenv("ERD_WINO_P_MIN");
+    const int p_mode = e_mode ? atoi(e_mode) : 1;
+    const int p_min = e_min ? atoi(e_min) : 200;
+    const bool phased = U3 && p_mode != 0 && Cout % BNP == 0 &&
+                        (p_mode >= 2 || (int64_t)blocks * (Cout / BNP) * 100 >= (int64_t)p_min * ncu);
+    const int ncb = phased ? Cout / BNP : (Cout + BN - 1) / BN;
+    d.nitems = blocks * ncb;
     // persistent grid (one workgroup per CU), items claimed from `sched`; ERD_WINO_PERSIST=2: static item stride,
     // 0: one workgroup per item (A/B aids)
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
     if (persist != 1) d.sched = nullptr;
+    if (phased && p_mode >= 3) {
+        const size_t lds = (size_t)2 * RAW_LDS_F4 * sizeof(float4) + 2 * VX_B + 4 * 2 * BNS * sizeof(float) + 16;
+        static bool attrs_done = false;
+        if (!attrs_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_x3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attrs_done = true;
+        }
+        hipLaunchKernelGGL(wino_x3s_kernel, dim3((unsigned)grid), dim3(256), lds, stream, d);
+        return erd::check_launch("wino_conv3x3_x3s");
+    }
+    if (phased) {
+        const size_t lds = (size_t)2 * HPIX * RCS * 16 + 2 * VX_B + 4 * 2 * BNP * sizeof(float) + 16;
+        static bool attrp_done = false;
+        if (!attrp_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_x3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attrp_done = true;
+        }
+        hipLaunchKernelGGL(wino_x3p_kernel, dim3((unsigned)grid), dim3(512), lds, stream, d);
+        return erd::check_launch("wino_conv3x3_x3p");
+    }
     if (U3) {
         const size_t lds = (size_t)2 * RAW_LDS_F4 * sizeof(float4) + 2 * VX_B + 4 * 2 * XCH_B + 64 + 2048 + 16;
         static bool attr3_done = false;
