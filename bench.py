@@ -486,9 +486,10 @@ def main():
             # one symbol) and its roofline on the flops it EXECUTES
             wino_on_bf16 = K.wino_x3()       # "f32x3": the Winograd launches run as wino_x3_kernel (six bf16 limb products per transform-domain product)
             symbols = dict(SYMBOLS)
-            if wino_on_bf16:
+            if wino_on_bf16:     # two symbols: items of 128 output channels (wino_x3p_kernel; the launch picks, kernels.wino_conv3x3 names it) and of 64
                 symbols["wino_x3_kernel"] = symbols.pop("wino_conv_kernel")
-            wino_sym = "wino_x3_kernel" if wino_on_bf16 else "wino_conv_kernel"
+                symbols["wino_x3p_kernel"] = ("conv_wino_fwd_p", "conv_wino_dgrad_p")
+            wino_syms = ("wino_x3_kernel", "wino_x3p_kernel") if wino_on_bf16 else ("wino_conv_kernel",)
             groups = {}
             for sym, classes in symbols.items():
                 rs = [ktime[c] for c in classes if c in ktime]
@@ -500,8 +501,8 @@ def main():
             # form of the direct launches 6 bf16 MFMA flops per fp32 flop on the bf16 pipe
             x3 = args.compute == "f32x3"
             X3_SYMS = ("conv_igemm_kernel", "conv_thin_x3_kernel", "conv_wgrad_row3_kernel", "conv_wgrad_kernel")      # launch classes that run in the three-limb form
-            execf = WINO_EXECUTED * (6.0 if wino_on_bf16 else 1.0) if sym == wino_sym else (6.0 if (x3 and sym in X3_SYMS) else 1.0)
-            if (x3 and sym in X3_SYMS) or (sym == wino_sym and wino_on_bf16):
+            execf = WINO_EXECUTED * (6.0 if wino_on_bf16 else 1.0) if sym in wino_syms else (6.0 if (x3 and sym in X3_SYMS) else 1.0)
+            if (x3 and sym in X3_SYMS) or (sym in wino_syms and wino_on_bf16):
                 peak_tf = BF16_MFMA_PEAK_TFLOPS
             alg_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
             # PMC counters cannot be read from inside this process: `traffic` / `mfma_busy_pmc` are STATIC values from the
@@ -515,7 +516,7 @@ def main():
                                "frac": round(alg_tf * execf / peak_tf, 4),
                                "basis": "flops the kernel executes on the matrix cores" + (
                                    " (Winograd F(2x2,3x3): 16/36 of the direct-convolution count, x 6 bf16 limb products per product, against the bf16 MFMA peak)"
-                                   if (sym == wino_sym and wino_on_bf16) else
+                                   if (sym in wino_syms and wino_on_bf16) else
                                    " (Winograd F(2x2,3x3): 16/36 of the direct-convolution count)" if execf < 1 else (
                                        " (six bf16 limb products per fp32 product, against the bf16 MFMA peak)" if execf > 1 else " (= the direct-convolution count)")),
                                "algorithmic_tflops": round(alg_tf, 2), "executed_flop_fraction": round(execf, 4),
@@ -532,8 +533,8 @@ def main():
             # numbers of this run + the committed PMC passes (static, labelled); everything needed to recompute a fraction is in the row
             per_kernel = {}
             for ksym, g in groups.items():
-                on_bf16 = args.compute == "bf16" or (x3 and ksym in X3_SYMS) or (ksym == wino_sym and wino_on_bf16)
-                k_exec = WINO_EXECUTED * (6.0 if wino_on_bf16 else 1.0) if ksym == wino_sym else (6.0 if (x3 and ksym in X3_SYMS) else 1.0)
+                on_bf16 = args.compute == "bf16" or (x3 and ksym in X3_SYMS) or (ksym in wino_syms and wino_on_bf16)
+                k_exec = WINO_EXECUTED * (6.0 if wino_on_bf16 else 1.0) if ksym in wino_syms else (6.0 if (x3 and ksym in X3_SYMS) else 1.0)
                 k_peak = BF16_MFMA_PEAK_TFLOPS if on_bf16 else FP32_MFMA_PEAK_TFLOPS
                 k_alg = g["flop"] / (g["ms"] * 1e-3) / 1e12
                 k_us = 1e3 * g["ms"] / g["launches"]
@@ -569,7 +570,7 @@ def main():
             step_s = dt / args.steps
             skipped = (TRUNK_GFLOP_PER_IMAGE if shared else 0.0) * rel_area
             per_step = lambda classes: sum(ktime[c]["flop"] for c in classes if c in ktime) / rsteps / 1e9     # GFLOP per step (rank 0's batch)
-            wino_alg = per_step(SYMBOLS["wino_conv_kernel"])
+            wino_alg = per_step(SYMBOLS["wino_conv_kernel"] + ("conv_wino_fwd_p", "conv_wino_dgrad_p"))
             igemm_alg = sum(per_step(SYMBOLS[k_]) for k_ in X3_SYMS) if x3 else 0.0      # (every three-limb class, not only the implicit GEMM)
             exec_gflop_step = args.batch * (g_img - skipped) - wino_alg * (1.0 - WINO_EXECUTED)
             wino_exec = wino_alg * WINO_EXECUTED                                          # Winograd-executed GFLOP per step

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "erd_wino_weights_x3_elems": [i32, i32],
     "erd_wino_weights_x3": [P, P, i32, i32, i32, P],
     "erd_wino_conv3x3_x3": [P, i32, P, i32, i32, P, P, i32, P, i32, P, P],
+    "erd_wino_x3_couts_per_item": [P, i32, i32],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_row3_slices": [C.POINTER(WgradDesc)],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
@@ -161,7 +162,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t if name.endswith(("_ws_bytes", "_elems")) else C.c_int
-    if lib.erd_abi_version() != 4:
+    if lib.erd_abi_version() != 5:
         raise ErdHipError("liberd_hip.so ABI version mismatch")
     lib.erd_probe_build.restype = C.c_int
     if lib.erd_probe_build() and not os.environ.get("ERD_HIP_LIB"):

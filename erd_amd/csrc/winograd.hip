@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
 
 // =====================================================================================================================
 // The three-limb form for 128 OUTPUT CHANNELS PER ITEM with eight PHASED waves (round 5; the default where Cout % 128 == 0 and
-// the launch has enough items).  wino_x3_kernel transforms every 32-tile block once per 64 output channels -- raw patch load,
+// it saves dispatch rounds: wino_launch).  wino_x3_kernel transforms every 32-tile block once per 64 output channels -- raw patch load,
 // B^T d B and the limb split run Cout / 64 times per tile (four times on the 256 -> 256 head towers) -- and its four data waves
 // (3 240 busy cycles per slice) are the critical path next to 1 536 cycles of matrix work (profiles/r04_wino_x3_trace.txt).
 // Here an item is 32 tiles x 128 couts: the same data work per slice feeds TWICE the matrix work.  128 couts x 32 tiles x 16
@@ -1187,15 +1187,18 @@ __global__ __launch_bounds__(512, 2) void wino_x3_kernel(const WinoDesc p) {
 // would leave 168 registers each): every wave does both jobs, in two PHASES per slice --
 //   M: its share of slice g: wave w owns transform ROW w & 3 (positions 4 (w & 3) .. + 3) of cout blocks 2 (w >> 2), + 1 (of
 //      four): a position's V fragments (three limbs, 3 KB of LDS reads) feed TWELVE MFMAs (two cout blocks x six limb products) --
-//      a first version with wino_x3_kernel's ownership (eight positions x one cout block: 24 KB of fragment reads per wave and
-//      slice, 320 KB of LDS traffic per slice and workgroup) measured 7 400 cycles per slice, LDS-bound (profiles/
-//      r05_wino_x3p_trace.txt); weight fragments: a ring of four (position, cout block) units straight from L2 as before;
+//      (a first version with wino_x3_kernel's ownership -- eight positions x one cout block, 24 KB of fragment reads per wave and
+//      slice, the flag-polled pair exchange -- ran the head towers in 363 us against 350: profiles/r05_wino_x3p_trace.txt);
+//      weight fragments: a ring of four (position, cout block) units straight from L2 as before;
 //   D: its eighth of the data work for slice g + 1 (thread t: tile (t >> 2) & 31, channels 4 (t & 3) .., transform row t >> 7:
 //      two patch rows from the raw slice, row pass, column pass, limb split, twelve 8-byte stores; 2 x 16 bytes of raw staging);
-// -- and the two waves of a SIMD run them in OPPOSITE order (waves 0-3: M then D, waves 4-7: D then M), so that at any time a
-// SIMD hosts one wave issuing dependent MFMA chains (its issue slots are idle 28 of 32 cycles) and one wave issuing VALU / LDS
-// work at the lone-wave rate: the occupancy pattern of the role-split kernel with every wave busy all the time.  One workgroup
-// barrier per slice as before (V(g+1) complete, V(g) and raw(g+1) consumed).
+// -- every wave M then D, one workgroup barrier per slice as before (V(g+1) complete, V(g) and raw(g+1) consumed).  Measured
+// alternatives (profiles/r05_wino_x3p_trace.txt): the two waves of a SIMD in OPPOSITE order (one multiplies while the other
+// transforms) is 7 % SLOWER -- a VALU wave beside an MFMA stream gets one issue slot per 8 cycles (tools/mfma_valu_coissue.hip) and
+// its dependent chains crawl (a data phase takes 3 950 cycles beside a matrix phase, 2 000 beside another data phase); D then M, an
+// extra barrier between the phases, raised priority for the transform: level or slower; FOUR waves with 512 registers, one per
+// SIMD, the data work woven into the MFMA stream (wino_x3s_kernel, commit 64a9de0): 410 us against 350 -- a lone wave cannot issue
+// the ~400 non-matrix instructions of a slice in less than 6 100 cycles.
 // Output: z[c] = (M A)[row][c] is local to a wave (the fp32 kernel's order (m0 + m1) + m2, (m1 - m2) - m3); y = A^T z needs three
 // rows: wave (row i) finishes output pixel (a, c) = (i >> 1, i & 1) of every tile for its two cout blocks from its own z and two
 // others', which travel IN BULK through the V buffer the last slice has just released (two rounds -- one per cout block -- of
@@ -1614,10 +1617,6 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
 
     // ---- the slice stream: iteration g multiplies slice g (M) and transforms raw(g+1) -> V(g+1), stores raw(g+2), requests
     //      raw(g+3) (D); waves 0-3: M then D, waves 4-7: D then M (uniform branches around the two call sites of D) ----
-#ifndef ERD_WX3P_ORDER
-#define ERD_WX3P_ORDER 1                       // tuning: 1: staggered (waves 4-7 transform first), 0: all waves M then D, 2: all D then M
-#endif
-    const bool d_first = ERD_WX3P_ORDER == 1 ? __builtin_amdgcn_readfirstlane(wave >> 2) != 0 : ERD_WX3P_ORDER >= 2;
     unsigned long long t_bar = 0, t_m = 0, t_d = 0; (void)t_bar; (void)t_m; (void)t_d;
     ERD_T0(t_begin);
     int g = 0;
@@ -1636,19 +1635,14 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
             const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(u_item + (unsigned)ks * 1024u));
             const unsigned u_reload = (unsigned)__builtin_amdgcn_readfirstlane(
                 (int)(last ? u_next : u_item + (unsigned)(ks + 1) * 1024u));
-            { ERD_T0(td); if (d_first) data_phase(par, u_cur); ERD_TACC(t_d, td); }
-            __builtin_amdgcn_sched_barrier(0);
-#if ERD_WX3P_ORDER == 3       // tuning: all waves transform, workgroup barrier, all waves multiply (no VALU work beside an MFMA stream)
-            { ERD_T0(tb); __syncthreads(); ERD_TACC(t_bar, tb); }
-#endif
             { ERD_T0(tm); matrix_phase(par, u_cur, u_reload); ERD_TACC(t_m, tm); }
             __builtin_amdgcn_sched_barrier(0);
-            { ERD_T0(td); if (!d_first) data_phase(par, u_reload); ERD_TACC(t_d, td); }
+            { ERD_T0(td); data_phase(par, u_reload); ERD_TACC(t_d, td); }
             { ERD_T0(tb); __syncthreads(); ERD_TACC(t_bar, tb); }  // V(g+1) complete, V(g) and raw(g+1) consumed, raw(g+2) stored
         }
         { ERD_T0(to); output_stage((unsigned)((g - 1) & 1)); ERD_TACC(t_out, to); }
         if (!has_next) {
-#ifdef ERD_WINO_TRACE       // [0..7] wave 0 (M then D), [8..15] wave 4 (D then M): total, barrier wait, matrix phases, data phases (of which:
+#ifdef ERD_WINO_TRACE       // [0..7] wave 0, [8..15] wave 4 (its SIMD mate): total, barrier wait, matrix phases, data phases (of which:
                             // reads + raw store, transform + V stores, item switch + ring tail), output stage
             if ((wave & 3) == 0 && lane == 0 && blockIdx.x < 256) {
                 unsigned long long* tr = g_wino_trace_p + blockIdx.x * 16 + (wave >> 2) * 8;
@@ -1660,465 +1654,6 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
                 tr[5] = t_d2;
                 tr[6] = t_d3;
                 tr[7] = t_out;
-            }
-#endif
-            if (tid == 0 && p.sched) {                       // the last workgroup to leave re-arms the counters
-                if (atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) { p.sched[0] = 0; p.sched[1] = 0; }
-            }
-            break;
-        }
-        cur = nxt;
-        u_item = u_next;
-        ++k_item;
-    }
-}
-
-// =====================================================================================================================
-// The three-limb form for 128 output channels per item on FOUR waves -- ONE PER SIMD, 512 registers each (round 5).
-// What the measurements of this round say (tools/mfma_valu_coissue.hip, tools/mfma_valu_interleave.hip, profiles/r05_*):
-//   * VALU instructions placed BETWEEN the dependent MFMAs of the same wave are free up to ~6 per v_mfma_f32_32x32x16_bf16 (33.3 ->
-//     35.0 cycles per MFMA, dependent or independent VALU chains alike): in-order issue stalls on the next dependent MFMA for 32
-//     cycles anyway;
-//   * a VALU wave BESIDE an MFMA wave of the same SIMD gets one issue slot per 8 cycles, and the phases of wino_x3p_kernel (eight
-//     waves, each alternating a matrix phase and a data phase) never overlapped as planned: 7 300 cycles per slice against 3 072 of
-//     matrix work, whatever the order of the phases (profiles/r05_wino_x3p_trace.txt).
-// So: one wave per SIMD that owns its matrix pipe, with the data work of the NEXT slice woven into its MFMA stream, ~4 vector
-// instructions behind each MFMA.  512 registers (256 accumulators: transform row `wave` = four positions x all four cout blocks of
-// 32 x 32 tiles; a ring of four weight-fragment units; the transform's 12 patch reads and both output rows live) leave room for
-// that.  A position's V fragments (3 KB) feed 24 MFMAs; LDS traffic per slice and workgroup: 48 KB of fragment reads + 48 KB patch
-// reads + 48 + 16 KB of stores (wino_x3_kernel: 96 + 48 + 64 per 64 couts).  Data work per thread = wino_x3_kernel's data waves'
-// (256 threads: tile, four channels, two transform rows).  Output: the bulk exchange of wino_x3p_kernel, two cout blocks per round.
-// Same V values, same MFMA sequence per accumulator, same order of every sum: results BIT-identical to wino_x3_kernel.
-constexpr int BNS = 128;                       // output channels per item
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_x3s_kernel(const WinoDesc p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: raw0 | raw1 (2 x [MAXPIX][RCS] float4) | V0 | V1 (2 x VX_B) | sh_ss [4][scale 128 | shift 128] | sh_item [2]
-    constexpr unsigned RAWB = RAW_LDS_F4 * 16, VOFF = 2 * RAWB, VB = VX_B, XOFF = VOFF + 2 * VB;
-    float* sh_ss = reinterpret_cast<float*>(smem + XOFF);
-    int* sh_item = reinterpret_cast<int*>(sh_ss + 4 * 2 * BNS);
-    char* const sm = smem;
-
-    const int tid = threadIdx.x;
-    const int Cin = p.Cin;
-    const int nks = Cin / KS;
-    const int nitems = p.nitems;
-    const int ncb32 = (p.Cout + 31) / 32;
-
-    auto decode = [&](int item) {
-        WinoItem it;
-        const int nb = item / p.blocks_per_nb;
-        int b = item - nb * p.blocks_per_nb;
-        int r = 0;
-        while (r + 1 < p.nreg && b >= p.reg[r + 1].block0) ++r;
-        const WinoRegion& rg = p.reg[r];
-        b -= rg.block0;
-        const int per_img = rg.nby * rg.nbx;
-        const int n = b / per_img;
-        const int rem = b - n * per_img;
-        const int by = rem / rg.nbx, bx = rem - by * rg.nbx;
-        const int lbw = rg.lbw;
-        it.s = __builtin_amdgcn_readfirstlane(rg.seg);
-        it.n = __builtin_amdgcn_readfirstlane(n);
-        it.y0 = __builtin_amdgcn_readfirstlane(2 * (rg.ty0 + by * (32 >> lbw)));
-        it.x0 = __builtin_amdgcn_readfirstlane(2 * (rg.tx0 + (bx << lbw)));
-        it.cout0 = __builtin_amdgcn_readfirstlane(nb * BNS);
-        it.lbw = __builtin_amdgcn_readfirstlane(lbw);
-        it.yl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].H, 2 * rg.ty1));
-        it.xl = __builtin_amdgcn_readfirstlane(min(p.seg[rg.seg].W, 2 * rg.tx1));
-        return it;
-    };
-    auto claim = [&](int k) -> int {
-        return p.sched ? (int)gridDim.x + atomicAdd(p.sched, 1) : (int)blockIdx.x + (k + 1) * (int)gridDim.x;
-    };
-
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int item0 = blockIdx.x;
-    if (item0 >= nitems) return;
-
-    // ---- roles -----------------------------------------------------------------------------------------------------------
-    const int li = lane & 31, h = lane >> 5;
-    const int ri = wave;                                             // matrix work: transform row (four positions), all four cout blocks
-    const int t_chunk = tid & 3, t_tile = (tid >> 2) & 31;          // data work: (tile, 4 channels) ...
-    const int t_half = __builtin_amdgcn_readfirstlane(tid >> 7);    // ... and transform rows 2 t_half, 2 t_half + 1 (uniform per wave)
-
-    // ---- matrix side state ------------------------------------------------------------------------------------------------
-    const __amdgpu_buffer_rsrc_t rs_U = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.U3), 0, (int)((size_t)16 * 3 * ncb32 * nks * 1024), 0x00020000);
-    const unsigned u_lane = (unsigned)lane * 16u;
-    const unsigned per_xl_b = (unsigned)ncb32 * (unsigned)nks * 1024u;          // bytes per (position, limb)
-    const unsigned pos0_b = (unsigned)(ri * 4 * 3) * per_xl_b;                  // this wave's first position
-    const unsigned cb_b = (unsigned)nks * 1024u;                                // bytes from a cout block to the next inside a plane
-    const unsigned v_lane = (unsigned)(ri * 4 * 3 * 1024 + h * 512 + ((li ^ (h * 8)) * 16));
-    WinoItem cur = decode(item0);
-    int k_item = 0;
-    unsigned u_item = (unsigned)__builtin_amdgcn_readfirstlane((cur.cout0 >> 5) * nks * 1024);
-    // unit u = 4 j + c: position 4 ri + j, cout block c
-    f32x16 acc[16];
-    u32x4 ub[4][3];                                                             // weight-fragment ring: unit u lives in slot u & 3
-    bf16x8 vf[2][3];                                                            // tile fragments [position parity][limb]
-    auto load_u = [&](const int u, const unsigned soff) {                      // u: compile-time after unrolling
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-            ub[u & 3][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_U, u_lane, pos0_b + (unsigned)((u >> 2) * 3 + l) * per_xl_b + soff + (u & 3) * cb_b, 0);
-    };
-
-    // ---- data side state (wino_x3_kernel's data waves, on all 256 threads) -------------------------------------------------
-    WinoItem la = cur;                                   // the item of the look-ahead pointer (raw slices are requested three slices ahead)
-    int la_ks = 0, k_la = 0;
-    unsigned la_soff = 0;
-    bool la_valid = true;
-    unsigned roff[NCH];
-    float4 rv[NCH];
-    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0].in), 0, 0, 0x00020000);
-    unsigned rd0 = 0, rd1 = 0, rd2 = 0, nrd0 = 0, nrd1 = 0, nrd2 = 0;
-    int tr_left = 0;
-    auto item_geometry = [&](const WinoItem& it, unsigned (&ro)[NCH], unsigned& g0, unsigned& g1, unsigned& g2, __amdgpu_buffer_rsrc_t& rs) {
-        const WinoSeg& sg = p.seg[it.s];
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.in), 0, (int)((long long)sg.N * sg.in_nstride * 4), 0x00020000);
-        const int lbw = it.lbw, bw = 1 << lbw, bh = 32 >> lbw;
-        const int pc_n = 2 * bw + 2, npix = (2 * bh + 2) * pc_n;
-        const int recip = (65536 + pc_n - 1) / pc_n;
-        const unsigned base_n = (unsigned)(it.n * sg.in_nstride);
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + 256 * i;
-            const int chunk = idx & 3, pix = idx >> 2;
-            const int pr = (pix * recip) >> 16, pc = pix - pr * pc_n;
-            const int iy = it.y0 - 1 + pr, ix = it.x0 - 1 + pc;
-            ro[i] = OOBV;
-            if (pix < npix && (unsigned)iy < (unsigned)sg.H && (unsigned)ix < (unsigned)sg.W)
-                ro[i] = (base_n + (unsigned)((iy * sg.W + ix) * Cin + chunk * 4)) * 4u;
-        }
-        const int t_ty = t_tile >> lbw, t_tx = t_tile & (bw - 1);
-        g0 = (unsigned)((((2 * t_ty + t_half) * pc_n + 2 * t_tx) * RCS + t_chunk) * 16);
-        g1 = g0 + (unsigned)(pc_n * RCS * 16);
-        g2 = g1 + (unsigned)(pc_n * RCS * 16);
-    };
-    struct Pending { float sc, sh; int claim, k; };
-    auto request_item_data = [&](Pending& pe) {
-        if (tid < BNS) {
-            const int co = la.cout0 + tid;
-            pe.sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
-            pe.sh = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
-        }
-        if (tid == BNS) pe.claim = claim(k_la);
-        pe.k = k_la;
-    };
-    auto flush_pending = [&](const Pending& pe) {
-        if (pe.k >= 0) {
-            if (tid < BNS) {
-                float* ss = sh_ss + (pe.k & 3) * (2 * BNS);
-                ss[tid] = pe.sc;
-                ss[BNS + tid] = pe.sh;
-            }
-            if (tid == BNS) sh_item[(pe.k + 1) & 1] = pe.claim;
-        }
-    };
-    auto issue_next = [&](float4* dst) {
-        if (la_valid) {
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) dst[i] = buf_load16_s(rs_in, roff[i], la_soff);
-            la_soff += KS * 4;
-            ++la_ks;
-        }
-    };
-    auto advance_item = [&](Pending& pe) {
-        if (la_valid && la_ks == nks) {                   // the pointer leaves item k_la (its successor was claimed >= 3 slices ago)
-            const int nx = __builtin_amdgcn_readfirstlane(sh_item[(k_la + 1) & 1]);
-            if (nx < nitems) {
-                la = decode(nx);
-                item_geometry(la, roff, nrd0, nrd1, nrd2, rs_in);
-                la_ks = 0;
-                la_soff = 0;
-                ++k_la;
-                request_item_data(pe);
-            } else la_valid = false;
-        }
-    };
-    const unsigned st_base = (unsigned)(((tid >> 2) * RCS + (tid & 3)) * 16);
-    auto store_raw = [&](const float4* src, const unsigned par) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) *reinterpret_cast<float4*>(sm + par * RAWB + st_base + i * (64 * RCS * 16)) = src[i];
-    };
-    float4 pd[3][4];
-    auto transform_read = [&](const unsigned rpar) {
-        const char* r0 = sm + rpar * RAWB + rd0;
-        const char* r1 = sm + rpar * RAWB + rd1;
-        const char* r2 = sm + rpar * RAWB + rd2;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            pd[0][c] = *reinterpret_cast<const float4*>(r0 + c * (RCS * 16));
-            pd[1][c] = *reinterpret_cast<const float4*>(r1 + c * (RCS * 16));
-            pd[2][c] = *reinterpret_cast<const float4*>(r2 + c * (RCS * 16));
-        }
-        if (--tr_left == 0) {                             // the next slice belongs to the item the pointer entered last
-            rd0 = nrd0;
-            rd1 = nrd1;
-            rd2 = nrd2;
-            tr_left = nks;
-        }
-    };
-    // rows 2 t_half, 2 t_half + 1 of B^T d: half 0 needs patch rows 0,1,2 (r0 = d0 - d2, r1 = d1 + d2); half 1 rows 1,2,3 (r2 = d2 - d1, r3 = d1 - d3)
-    float4 rr[2][4];
-    auto row_pass = [&]() {
-        if (t_half == 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { rr[0][c] = f4sub(pd[0][c], pd[2][c]); rr[1][c] = f4add(pd[1][c], pd[2][c]); }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { rr[0][c] = f4sub(pd[1][c], pd[0][c]); rr[1][c] = f4sub(pd[0][c], pd[2][c]); }
-        }
-    };
-    // this thread's 8 bytes inside a (position, limb) block of 1 KB = [k half][tile ^ 8 (k half)][8 channels] (wino_x3_kernel's layout)
-    const unsigned wr_base = VOFF + (unsigned)(t_half * 8 * 3072 + (t_chunk >> 1) * 512 + ((t_tile ^ ((t_chunk >> 1) * 8)) * 16) + (t_chunk & 1) * 8);
-    auto put = [&](char* dst, const float4 v) {        // four channels of one position -> three limb words of 8 bytes
-        uint2 hi, mid, lo;
-        erd::limbs3_pair(v.x, v.y, hi.x, mid.x, lo.x);
-        erd::limbs3_pair(v.z, v.w, hi.y, mid.y, lo.y);
-        *reinterpret_cast<uint2*>(dst) = hi;
-        *reinterpret_cast<uint2*>(dst + 1024) = mid;
-        *reinterpret_cast<uint2*>(dst + 2048) = lo;
-    };
-    // position (2 t_half + a) * 4 + k of V buffer vpar
-    auto put_pos = [&](const int a, const int k, const unsigned vpar) {
-        char* v = sm + wr_base + vpar * VB + (a * 4 + k) * 3072;
-        if (k == 0) put(v, f4sub(rr[a][0], rr[a][2]));
-        if (k == 1) put(v, f4add(rr[a][1], rr[a][2]));
-        if (k == 2) put(v, f4sub(rr[a][2], rr[a][1]));
-        if (k == 3) put(v, f4sub(rr[a][1], rr[a][3]));
-    };
-    // The data work of one slice in sixteen pieces, one behind each unit's six MFMAs: raw(g+1) -> V(g+1), raw(g+2) registers ->
-    // LDS over raw(g), request raw(g+3); the pointer bookkeeping last
-    auto data_piece = [&](const int u, const unsigned par) __attribute__((always_inline)) {
-        const unsigned npar = par ^ 1u;
-        if (u == 0) transform_read(npar);
-        if (u == 1) { store_raw(rv, par); issue_next(rv); }
-        if (u == 2) row_pass();
-        if (u >= 3 && u < 11) put_pos((u - 3) >> 2, (u - 3) & 3, npar);
-        if (u == 11) {
-            Pending pe;
-            pe.sc = 1.f; pe.sh = 0.f; pe.claim = 0; pe.k = -1;
-            advance_item(pe);
-            flush_pending(pe);
-        }
-    };
-    // One slice: sixteen units of six MFMAs (position 4 ri + (u >> 2), cout block u & 3), each followed by its piece of the data
-    // work; the ring slot of unit u is re-loaded with unit u + 4 of this slice or u - 12 of the next one
-    auto slice = [&](const unsigned par, const unsigned u_cur, const unsigned u_reload) __attribute__((always_inline)) {
-        const char* vc = sm + VOFF + v_lane + par * VB;
-#pragma unroll
-        for (int l = 0; l < 3; ++l) vf[0][l] = *reinterpret_cast<const bf16x8*>(vc + l * 1024);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = u >> 2;
-            if ((u & 3) == 0 && j < 3) {
-#pragma unroll
-                for (int l = 0; l < 3; ++l) vf[(j + 1) & 1][l] = *reinterpret_cast<const bf16x8*>(vc + (j + 1) * 3072 + l * 1024);
-            }
-            const bf16x8 vh = vf[j & 1][0], vm = vf[j & 1][1], vl = vf[j & 1][2];
-            const bf16x8 uh = __builtin_bit_cast(bf16x8, ub[u & 3][0]), um = __builtin_bit_cast(bf16x8, ub[u & 3][1]),
-                         ul = __builtin_bit_cast(bf16x8, ub[u & 3][2]);
-            // rows = couts (U), columns = tiles (V); smallest terms first, as everywhere in the three-limb kernels
-#ifdef ERD_WX3S_NOMFMA      // timing probe: everything but the matrix instructions (results are wrong)
-            acc[u][0] += __builtin_bit_cast(float4, ul).x * __builtin_bit_cast(float4, vh).x + __builtin_bit_cast(float4, um).x * __builtin_bit_cast(float4, vm).x +
-                         __builtin_bit_cast(float4, uh).x * __builtin_bit_cast(float4, vl).x;
-#else
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[u], 0, 0, 0);
-#endif
-#ifndef ERD_WX3S_NOLOAD     // (timing probe: the ring keeps the first slice's fragments)
-            if (u + 4 < 16) load_u(u + 4, u_cur); else load_u(u - 12, u_reload);
-#endif
-#ifndef ERD_WX3S_NODATA     // (timing probe: no transform -- V keeps the prologue's slice)
-            data_piece(u, par);
-#endif
-            // pin: LDS reads of this unit first (they are consumed units later), then one MFMA / five vector instructions, six times;
-            // LDS stores and the fragment loads fall behind
-#ifndef ERD_WX3S_NOPIN
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // Output stage of the finished item (behind the last slice's barrier: V buffer xpar is free, every wave is here).
-    // Two rounds of two cout blocks; exchange slots of a cout block (4 KB each = [4 register quads][64 lanes][16 B]):
-    // 0: z1[0], 1: z2[0], 2: z3[0], 3: z0[1], 4: z2[1], 5: z1[1]  (z0[0] and z3[1] are only needed by their owners).
-    auto output_stage = [&](const unsigned xpar) __attribute__((always_inline)) {
-        const WinoSeg& sg = p.seg[cur.s];
-        const float* ss = sh_ss + (k_item & 3) * (2 * BNS);
-        const int lbw = cur.lbw, bwm = (1 << lbw) - 1;
-        const int ty = li >> lbw, tx = li & bwm;
-        const int fa = ri >> 1, fc = ri & 1;                           // this wave finishes output pixel (fa, fc) of every tile
-        const int oy = cur.y0 + 2 * ty + fa, ox = cur.x0 + 2 * tx + fc;
-        const bool pix_ok = oy < cur.yl && ox < cur.xl;
-        const int64_t opix = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout;
-        const bool simple = !sg.res && !sg.mask && !p.colsum;
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-            sg.out, 0, (int)((long long)sg.N * sg.out_nstride * 4), 0x00020000);
-        const float lo = p.relu ? 0.f : -__builtin_inff();
-        char* const xb = sm + VOFF + xpar * VB + lane * 16;
-        const int w0 = ri == 1 ? 0 : ri == 2 ? 1 : ri == 3 ? 2 : -1;
-        const int w1 = ri == 0 ? 3 : ri == 1 ? 5 : ri == 2 ? 4 : -1;
-        const int rA = ri == 0 ? 0 : ri == 1 ? 3 : ri == 2 ? 0 : 5;
-        const int rB = ri == 0 ? 1 : ri == 1 ? 4 : ri == 2 ? 2 : 4;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            f32x16 z0[2], z1[2];
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int c = 2 * r + bb;
-                // z[.] = (M A)[row][.] of cout block c: the accumulators die here
-                z0[bb] = (acc[0 + c] + acc[4 + c]) + acc[8 + c];
-                z1[bb] = (acc[4 + c] - acc[8 + c]) - acc[12 + c];
-                if (w0 >= 0) {
-#pragma unroll
-                    for (int qr = 0; qr < 4; ++qr)
-                        *reinterpret_cast<float4*>(xb + (bb * 6 + w0) * 4096 + qr * 1024) =
-                            make_float4(z0[bb][4 * qr], z0[bb][4 * qr + 1], z0[bb][4 * qr + 2], z0[bb][4 * qr + 3]);
-                }
-                if (w1 >= 0) {
-#pragma unroll
-                    for (int qr = 0; qr < 4; ++qr)
-                        *reinterpret_cast<float4*>(xb + (bb * 6 + w1) * 4096 + qr * 1024) =
-                            make_float4(z1[bb][4 * qr], z1[bb][4 * qr + 1], z1[bb][4 * qr + 2], z1[bb][4 * qr + 3]);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int c = 2 * r + bb;
-                f32x16 sa, sb;
-#pragma unroll
-                for (int qr = 0; qr < 4; ++qr) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(xb + (bb * 6 + rA) * 4096 + qr * 1024);
-                    const float4 b4 = *reinterpret_cast<const float4*>(xb + (bb * 6 + rB) * 4096 + qr * 1024);
-                    sa[4 * qr] = a4.x; sa[4 * qr + 1] = a4.y; sa[4 * qr + 2] = a4.z; sa[4 * qr + 3] = a4.w;
-                    sb[4 * qr] = b4.x; sb[4 * qr + 1] = b4.y; sb[4 * qr + 2] = b4.z; sb[4 * qr + 3] = b4.w;
-                }
-                // y[0][c] = (z0 + z1) + z2 ; y[1][c] = (z1 - z2) - z3 with (own, sa, sb) put back in row order (the fp32 kernel's sums)
-                f32x16 yv;
-                if (ri == 0) yv = (z0[bb] + sa) + sb;            // own = z0[0], sa = z1[0], sb = z2[0]
-                else if (ri == 1) yv = (sa + z1[bb]) + sb;       // sa = z0[1], own = z1[1], sb = z2[1]
-                else if (ri == 2) yv = (sa - z0[bb]) - sb;       // sa = z1[0], own = z2[0], sb = z3[0]
-                else yv = (sa - sb) - z1[bb];                    // sa = z1[1], sb = z2[1], own = z3[1]
-                float4 cs[4];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {                          // registers 4 gq .. 4 gq + 3: couts 8 gq + 4 h + {0..3} of the block
-                    const int cl = 32 * c + 8 * gq + 4 * h;              // 0..127 inside the item's cout block
-                    const int co0 = cur.cout0 + cl;
-                    const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
-                    const float4 sh = *reinterpret_cast<const float4*>(ss + BNS + cl);
-                    float4 v = make_float4(yv[4 * gq] * sc.x + sh.x, yv[4 * gq + 1] * sc.y + sh.y, yv[4 * gq + 2] * sc.z + sh.z,
-                                           yv[4 * gq + 3] * sc.w + sh.w);
-                    cs[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (simple) {
-                        u32x4 o;
-                        o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
-                        o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix_ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
-                    } else if (pix_ok) {
-                        const int64_t o = opix + co0;
-                        if (sg.res) v = f4add(v, *reinterpret_cast<const float4*>(sg.res + o));
-                        if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                        if (sg.mask) {
-                            const float4 mk = *reinterpret_cast<const float4*>(sg.mask + o);
-                            v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
-                                            mk.w > 0.f ? v.w : 0.f);
-                        }
-                        *reinterpret_cast<float4*>(sg.out + o) = v;
-                        cs[gq] = v;
-                    }
-                }
-                if (p.colsum) {
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) {
-                            cs[gq].x += __shfl_xor(cs[gq].x, o, 64); cs[gq].y += __shfl_xor(cs[gq].y, o, 64);
-                            cs[gq].z += __shfl_xor(cs[gq].z, o, 64); cs[gq].w += __shfl_xor(cs[gq].w, o, 64);
-                        }
-                        const int co0 = cur.cout0 + 32 * c + 8 * gq + 4 * h;
-                        if (li == 0) {
-                            float* cpt = p.colsum + (p.colsum_copies > 1 ? (blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) + co0;
-                            atomicAdd(cpt + 0, cs[gq].x); atomicAdd(cpt + 1, cs[gq].y); atomicAdd(cpt + 2, cs[gq].z); atomicAdd(cpt + 3, cs[gq].w);
-                        }
-                    }
-                }
-            }
-            __syncthreads();                              // the slots are free: next round's writes / the next slice's V stores
-        }
-    };
-
-    // ---- prologue ---------------------------------------------------------------------------------------------------------
-    {
-        float4 rvb[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) { rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rvb[i] = rv[i]; }
-        item_geometry(la, roff, nrd0, nrd1, nrd2, rs_in);
-        Pending pe;
-        pe.sc = 1.f; pe.sh = 0.f; pe.claim = 0; pe.k = -1;
-        request_item_data(pe);
-        rd0 = nrd0;
-        rd1 = nrd1;
-        rd2 = nrd2;
-        tr_left = nks;
-        flush_pending(pe);
-        issue_next(rv);                                   // raw(0)
-        issue_next(rvb);                                  // raw(1)   (nks >= 4: the pointer cannot leave the first item here)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) load_u(u, u_item);
-        store_raw(rv, 0);
-        __syncthreads();                                  // raw(0) is in LDS, the first claim is published
-        transform_read(0);
-        row_pass();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) put_pos(q >> 2, q & 3, 0);
-        store_raw(rvb, 1);
-        issue_next(rv);                                   // raw(2)
-        __syncthreads();                                  // V(0) complete, raw(1) in LDS
-    }
-
-    // ---- the slice stream ---------------------------------------------------------------------------------------------------
-    unsigned long long t_bar = 0, t_out = 0; (void)t_bar; (void)t_out;
-    ERD_T0(t_begin);
-    int g = 0;
-    for (;;) {
-        const int nxt_item = __builtin_amdgcn_readfirstlane(sh_item[(k_item + 1) & 1]);
-        const bool has_next = nxt_item < nitems;
-        const WinoItem nxt = has_next ? decode(nxt_item) : cur;
-        const unsigned u_next = (unsigned)__builtin_amdgcn_readfirstlane((nxt.cout0 >> 5) * nks * 1024);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-        for (int ks = 0; ks < nks; ++ks, ++g) {
-            const unsigned par = (unsigned)(g & 1);
-            const bool last = ks + 1 == nks;
-            const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(u_item + (unsigned)ks * 1024u));
-            const unsigned u_reload = (unsigned)__builtin_amdgcn_readfirstlane(
-                (int)(last ? u_next : u_item + (unsigned)(ks + 1) * 1024u));
-            slice(par, u_cur, u_reload);
-            { ERD_T0(tb); __syncthreads(); ERD_TACC(t_bar, tb); }  // V(g+1) complete, V(g) and raw(g+1) consumed, raw(g+2) stored
-        }
-        { ERD_T0(to); output_stage((unsigned)((g - 1) & 1)); ERD_TACC(t_out, to); }
-        if (!has_next) {
-#ifdef ERD_WINO_TRACE       // [0..3] wave 0: total, barrier wait, output stage, items
-            if (wave == 0 && lane == 0 && blockIdx.x < 256) {
-                unsigned long long* tr = g_wino_trace_p + blockIdx.x * 16;
-                tr[0] = __builtin_amdgcn_s_memtime() - t_begin;
-                tr[1] = t_bar;
-                tr[2] = t_out;
-                tr[3] = (unsigned long long)(k_item + 1);
             }
 #endif
             if (tid == 0 && p.sched) {                       // the last workgroup to leave re-arms the counters
@@ -2165,24 +1700,10 @@ extern "C" size_t erd_wino_weights_elems(int Cout, int Cin) { return (size_t)16 
 
 namespace {
 // the launch both forms share: descriptor (segments, block regions, item count) and the persistent grid
-int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* U3, int Cin, int Cout, const float* scale,
-                const float* shift, int relu, float* colsum, int colsum_copies, int* sched, hipStream_t stream) {
-    ERD_REQUIRE(segs && (U || U3) && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
-    ERD_REQUIRE(Cin % KS == 0 && Cin >= 4 * KS && Cout > 0, "wino: Cin=%d must be a multiple of %d and at least %d", Cin, KS, 4 * KS);
-    WinoDesc d;
+// segments -> descriptor (block regions, blocks per cout block) and the choice between 64 and 128 couts per item; 0 on success
+int wino_plan(WinoDesc& d, const erd_conv_seg* segs, int nseg, bool x3, int Cout, int& ncu, bool& phased) {
+    ERD_REQUIRE(segs && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
     d.nseg = nseg;
-    d.U = U;
-    d.U3 = U3;
-    d.Cin = Cin;
-    d.Cout = Cout;
-    d.scale = scale;
-    d.shift = shift;
-    d.relu = relu;
-    d.colsum = colsum;
-    ERD_REQUIRE(colsum_copies >= 0 && (colsum_copies & (colsum_copies - 1)) == 0, "wino: colsum_copies must be a power of two");
-    d.colsum_copies = colsum_copies;
-    d.sched = sched;
-    ERD_REQUIRE(!colsum || Cout % 4 == 0, "wino: colsum needs Cout %% 4 == 0");
     static const int shapes = getenv("ERD_WINO_SHAPES") ? atoi(getenv("ERD_WINO_SHAPES")) : 1;   // 0: plain 4x8 cover (A/B aid)
     int blocks = 0, nreg = 0;
     auto add_region = [&](int s, int N, int ty0, int tx0, int nby, int nbx, int lbw, int ty1, int tx1) {
@@ -2231,8 +1752,6 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     }
     d.nreg = nreg;
     d.blocks_per_nb = blocks;
-    if (blocks == 0) return 0;
-    int ncu = 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -2241,15 +1760,40 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
             cached = prop.multiProcessorCount;
         ncu = cached > 0 ? cached : 256;
     }
-    // 128 couts per item (wino_x3p_kernel) where the cout count allows it and the launch still has enough items to balance over
-    // the persistent grid; ERD_WINO_P=0: never, 2: whenever Cout % 128 == 0 (A/B aids), ERD_WINO_P_MIN: items per CU x 100
-    // (read per launch, not cached: tests/test_gpu_wino_x3.py flips it inside one process to compare the two kernels bit for bit)
+    // 128 couts per item (wino_x3p_kernel) where the cout count allows it and it needs fewer dispatch rounds: an item of 128 couts
+    // costs ~1.6 items of 64 (head towers: 2 800 / 1 400 items, 1.22x faster; 50 x 84 maps: 560 / 280 items on 256 CUs = 3 against 2
+    // rounds, 0.97x -- stays on wino_x3_kernel).  ERD_WINO_P=0: never, 2: whenever Cout % 128 == 0 (A/B aids; read per launch, not
+    // cached: tests/test_gpu_wino_x3.py flips it inside one process to compare the two kernels bit for bit)
     const char* const e_mode = getenv("ERD_WINO_P");
-    const char* const e_min = getenv("ERD_WINO_P_MIN");
     const int p_mode = e_mode ? atoi(e_mode) : 1;
-    const int p_min = e_min ? atoi(e_min) : 200;
-    const bool phased = U3 && p_mode != 0 && Cout % BNP == 0 &&
-                        (p_mode >= 2 || (int64_t)blocks * (Cout / BNP) * 100 >= (int64_t)p_min * ncu);
+    const int64_t i64 = (int64_t)blocks * ((Cout + BN - 1) / BN), i128 = (int64_t)blocks * (Cout / BNP);
+    phased = x3 && p_mode != 0 && Cout % BNP == 0 && blocks > 0 &&
+             (p_mode >= 2 || 16 * ((i128 + ncu - 1) / ncu) <= 10 * ((i64 + ncu - 1) / ncu));
+    return 0;
+}
+
+int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* U3, int Cin, int Cout, const float* scale,
+                const float* shift, int relu, float* colsum, int colsum_copies, int* sched, hipStream_t stream) {
+    ERD_REQUIRE(segs && (U || U3) && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
+    ERD_REQUIRE(Cin % KS == 0 && Cin >= 4 * KS && Cout > 0, "wino: Cin=%d must be a multiple of %d and at least %d", Cin, KS, 4 * KS);
+    WinoDesc d;
+    d.U = U;
+    d.U3 = U3;
+    d.Cin = Cin;
+    d.Cout = Cout;
+    d.scale = scale;
+    d.shift = shift;
+    d.relu = relu;
+    d.colsum = colsum;
+    ERD_REQUIRE(colsum_copies >= 0 && (colsum_copies & (colsum_copies - 1)) == 0, "wino: colsum_copies must be a power of two");
+    d.colsum_copies = colsum_copies;
+    d.sched = sched;
+    ERD_REQUIRE(!colsum || Cout % 4 == 0, "wino: colsum needs Cout %% 4 == 0");
+    int ncu = 0;
+    bool phased = false;
+    if (const int rc = wino_plan(d, segs, nseg, U3 != nullptr, Cout, ncu, phased)) return rc;
+    const int blocks = d.blocks_per_nb;
+    if (blocks == 0) return 0;
     const int ncb = phased ? Cout / BNP : (Cout + BN - 1) / BN;
     d.nitems = blocks * ncb;
     // persistent grid (one workgroup per CU), items claimed from `sched`; ERD_WINO_PERSIST=2: static item stride,
@@ -2257,16 +1801,6 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
     if (persist != 1) d.sched = nullptr;
-    if (phased && p_mode >= 3) {
-        const size_t lds = (size_t)2 * RAW_LDS_F4 * sizeof(float4) + 2 * VX_B + 4 * 2 * BNS * sizeof(float) + 16;
-        static bool attrs_done = false;
-        if (!attrs_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_x3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attrs_done = true;
-        }
-        hipLaunchKernelGGL(wino_x3s_kernel, dim3((unsigned)grid), dim3(256), lds, stream, d);
-        return erd::check_launch("wino_conv3x3_x3s");
-    }
     if (phased) {
         const size_t lds = (size_t)2 * HPIX * RCS * 16 + 2 * VX_B + 4 * 2 * BNP * sizeof(float) + 16;
         static bool attrp_done = false;
@@ -2314,6 +1848,14 @@ extern "C" int erd_wino_weights_x3(const float* w_ohwi, void* U3, int Cout, int 
     hipLaunchKernelGGL(wino_weight_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ohwi,
                        reinterpret_cast<unsigned short*>(U3), Cout, Cin, flip);
     return erd::check_launch("wino_weights_x3");
+}
+
+extern "C" int erd_wino_x3_couts_per_item(const erd_conv_seg* segs, int nseg, int Cout) {
+    WinoDesc d;
+    int ncu = 0;
+    bool phased = false;
+    if (wino_plan(d, segs, nseg, true, Cout, ncu, phased)) return -1;
+    return phased ? BNP : BN;
 }
 
 extern "C" int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout,

@@ -599,7 +599,10 @@ def wino_conv3x3(xs: Sequence[Tensor], U: Tensor, outs: Sequence[Tensor], Cout: 
                   None if mask is None else mask[i])
     flop = 2.0 * sum(o.shape[0] * o.shape[1] * o.shape[2] for o in outs) * Cout * 9 * Cin
     nbytes = (4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs)) + U.numel() * U.element_size()) if _TIMING is not None else 0.0
-    # (the form is the weight image's: a bf16 image is the three-limb one)
+    # (the form is the weight image's: a bf16 image is the three-limb one).  Timed runs name the kernel SYMBOL the launch runs on:
+    # erd_wino_conv3x3_x3 picks wino_x3p_kernel (128 couts per item) or wino_x3_kernel (64) by itself
+    if _TIMING is not None and U.dtype == torch.bfloat16 and int(_lib.load().erd_wino_x3_couts_per_item(segs, len(xs), Cout)) == 128:
+        kname += "_p"
     _timed_call(kname, flop, "erd_wino_conv3x3_x3" if U.dtype == torch.bfloat16 else "erd_wino_conv3x3", segs, len(xs), _p(U), Cin, Cout, _p(scale), _p(shift),
                 1 if relu else 0, _p(colsum), (colsum.numel() // Cout if colsum is not None else 0),
                 _p(_wino_sched(U.device)), _stream(), nbytes=nbytes,

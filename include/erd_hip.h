@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERD_ABI_VERSION 4
+#define ERD_ABI_VERSION 5
 #define ERD_MAX_SEG 5   /* FPN levels batched in one launch */
 #define ERD_MAX_TAPS 9
 
@@ -155,6 +155,11 @@ size_t erd_wino_weights_x3_elems(int Cout, int Cin);
 int erd_wino_weights_x3(const float* w_ohwi, void* U3, int Cout, int Cin, int flip, erd_stream_t stream);
 int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout, const float* scale,
                         const float* shift, int relu, float* colsum, int colsum_copies, int* sched, erd_stream_t stream);
+/* ABI v5.  erd_wino_conv3x3_x3 runs an item of 32 tiles x 128 output channels (wino_x3p_kernel: every tile block is transformed once
+ * per 128 couts, eight waves that each multiply and transform) where Cout % 128 == 0 and that needs fewer dispatch rounds of the
+ * persistent grid, 32 tiles x 64 couts (wino_x3_kernel) otherwise; results are bit-identical either way.
+ * erd_wino_x3_couts_per_item tells the caller which (128 / 64; a profiler sees two kernel symbols), < 0 on bad segments. */
+int erd_wino_x3_couts_per_item(const erd_conv_seg* segs, int nseg, int Cout);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).

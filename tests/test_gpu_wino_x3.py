@@ -110,3 +110,93 @@ def test_wino_x3_full_size_head_tower_launch_runs_twice_identically(K):
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0] - outs[2]).norm() / outs[2].norm()) < 2e-6
+
+
+@pytest.fixture()
+def wino_p_mode():
+    """ERD_WINO_P (read per launch by erd_wino_conv3x3_x3): 0 = items of 64 output channels (wino_x3_kernel), 2 = items of 128
+    wherever Cout % 128 == 0 (wino_x3p_kernel), unset = the launch's own choice"""
+    import os
+    old = os.environ.get("ERD_WINO_P")
+
+    def set_mode(m):
+        if m is None:
+            os.environ.pop("ERD_WINO_P", None)
+        else:
+            os.environ["ERD_WINO_P"] = str(m)
+    yield set_mode
+    set_mode(old)
+
+
+P_SHAPES = [(2, 256, 256, [(26, 30)]), (1, 64, 128, [(20, 28)]), (2, 128, 128, [(25, 42)]), (1, 512, 512, [(7, 11)]), (1, 64, 256, [(34, 66)]),
+            (2, 256, 256, [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]), (1, 128, 384, [(9, 12)]), (1, 256, 256, [(100, 168)])]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,sizes", P_SHAPES)
+def test_wino_x3p_items_of_128_couts_equal_items_of_64_bit_for_bit(K, wino_p_mode, N, Cin, Cout, sizes):
+    """wino_x3p_kernel (round 5: a tile block is transformed once per 128 output channels; eight waves that each multiply and
+    transform; bulk output exchange) forms the same V values, the same MFMA sequence per accumulator and the same output sums as
+    wino_x3_kernel: every epilogue form -- plain, folded BN + ReLU, residual aliasing the output + mask + fused column sums --, every
+    block shape of the cover, several levels in one launch must come out BIT-identical (gfl_head.py:219-229, fpn.py:215,
+    resnet.py:270-274 run on whichever the launch picks)."""
+    from erd_amd.kernels import level_views
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(71, N, A, Cin).cuda()
+    w = G.randn(72, Cout, Cin, 3, 3, scale=(2.0 / (Cin * 9)) ** 0.5).permute(0, 2, 3, 1).contiguous().cuda()
+    scale, shift = (0.5 + G.rand(73, Cout)).cuda(), G.randn(74, Cout, scale=0.1).cuda()
+    base, mask = G.randn(75, N, A, Cout).cuda(), G.randn(76, N, A, Cout).cuda()
+    U = K.wino_weights(w, x3=True)
+    xs = level_views(x, sizes)
+    got = {}
+    for mode in (0, 2):
+        wino_p_mode(mode)
+        y1 = torch.full((N, A, Cout), float("nan"), device="cuda")
+        K.wino_conv3x3(xs, U, level_views(y1, sizes), Cout)
+        y2 = torch.full((N, A, Cout), float("nan"), device="cuda")
+        K.wino_conv3x3(xs, U, level_views(y2, sizes), Cout, scale=scale, shift=shift, relu=True)
+        y3 = base.clone()
+        cs = torch.zeros(8, Cout, device="cuda")
+        v3 = level_views(y3, sizes)
+        K.wino_conv3x3(xs, U, v3, Cout, res=v3, mask=level_views(mask, sizes), colsum=cs)
+        torch.cuda.synchronize()
+        got[mode] = (y1, y2, y3, cs.sum(0))
+    for a, b in zip(got[0][:3], got[2][:3]):
+        assert not torch.isnan(b).any()
+        assert torch.equal(a, b)
+    # (the column sums are atomic adds into eight rows picked by workgroup index: same addends, another order)
+    assert float((got[0][3] - got[2][3]).abs().max() / got[0][3].abs().max()) < 1e-5
+    # ... and against fp64, once, so that "identical" cannot mean "identically wrong"
+    off = 0
+    for (h, ww) in sizes[:1]:
+        ref = F.conv2d(x[:, off:off + h * ww].reshape(N, h, ww, Cin).permute(0, 3, 1, 2).double().cpu(),
+                       w.permute(0, 3, 1, 2).double().cpu(), None, 1, 1)
+        assert rel64(got[2][0][:, off:off + h * ww].reshape(N, h, ww, Cout).permute(0, 3, 1, 2).cpu(), ref) < 2e-6
+
+
+def test_wino_x3_launch_picks_the_item_size_by_dispatch_rounds(K, wino_p_mode):
+    """erd_wino_x3_couts_per_item (ABI v5) = the choice erd_wino_conv3x3_x3 makes: 128 output channels per item where Cout % 128 == 0
+    and ceil(items128 / CUs) * 1.6 <= ceil(items64 / CUs) -- the head-tower launch (1 400 against 2 800 items) and a 100 x 168 FPN output,
+    not a 50 x 84 map (280 against 560 items on 256 CUs), never Cout = 80."""
+    from erd_amd import _lib
+    from erd_amd.kernels import level_views, _fill_seg
+    from erd_amd._lib import ConvSeg
+    lib = _lib.load()
+
+    def choice(N, sizes, Cout, Cin=256):
+        A = sum(h * w for h, w in sizes)
+        x, y = torch.empty(N, A, Cin, device="cuda"), torch.empty(N, A, Cout, device="cuda")
+        xs, ys = level_views(x, sizes), level_views(y, sizes)
+        segs = (ConvSeg * len(xs))()
+        for i, (a, b) in enumerate(zip(xs, ys)):
+            _fill_seg(segs[i], a, b, a.shape[1], a.shape[2], None, None, None)
+        return int(lib.erd_wino_x3_couts_per_item(segs, len(xs), Cout))
+    wino_p_mode(None)
+    head = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    assert choice(4, head, 256) == 128
+    assert choice(4, [(100, 168)], 256) == 128
+    assert choice(4, [(50, 84)], 256) == 64
+    assert choice(4, head, 80) == 64
+    wino_p_mode(0)
+    assert choice(4, head, 256) == 64
+    wino_p_mode(2)
+    assert choice(4, [(50, 84)], 256) == 128 and choice(4, head, 80) == 64
