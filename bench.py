@@ -429,7 +429,7 @@ def main():
         finally:
             K.set_compute(args.compute)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    devices = [f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
+    devices = [f"rank {rank}: cuda:{dev_index} {torch.cuda.get_device_name(dev_index)}"]
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         gathered = [None] * world

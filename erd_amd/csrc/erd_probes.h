@@ -11,7 +11,7 @@
 //                     ERD_IG_NOMFMA  ERD_IG_NOLOAD  ERD_IG_NOFRAG   ERD_IG_NOSYNC                      bf16-mode implicit GEMM K loop
 //     winograd.hip    ERD_WX3_NOMFMA ERD_WX3_NOSPLIT ERD_WX3_NOLOAD ERD_WX3_VREAD1 ERD_WX3_VWRITE1 ERD_WX3_NORAW ERD_WINO_GNPROBE                   three-limb / fp32 Winograd
 //     conv_mfma.hip   ERD_WG3_NOSLAB                                                                    three-limb weight gradient without its partial-slab stores
-//     conv_thin.hip   ERD_THIN_NOSTORE ERD_THIN_NOMFMA ERD_THIN_NORES                                     thin-K kernel: no output stores / no MFMAs / no residual + mask reads
+//     conv_thin.hip   ERD_THIN_NOSTORE ERD_THIN_NOMFMA                                                    thin-K kernel: no output stores / no MFMAs
 //     elementwise.hip ERD_GN_NOSTATS                                                                    GroupNorm without its statistics pass
 //   accuracy probe (results differ in the last bits)
 //     conv_mfma.hip, conv_thin.hip   ERD_X3_NINE      all nine limb products instead of six
@@ -23,7 +23,7 @@
 
 #if defined(ERD_X3_NOMFMA) || defined(ERD_X3_NOLOAD) || defined(ERD_X3_NOBREAD) || defined(ERD_X3_NOVALU) || defined(ERD_X3_NOSYNC) || \
     defined(ERD_IG_NOMFMA) || defined(ERD_IG_NOLOAD) || defined(ERD_IG_NOFRAG) || defined(ERD_IG_NOSYNC) || defined(ERD_WX3_NOMFMA) ||    \
-    defined(ERD_WX3_NOSPLIT) || defined(ERD_WX3_NOLOAD) || defined(ERD_WX3_VREAD1) || defined(ERD_WX3_VWRITE1) || defined(ERD_THIN_NOSTORE) || defined(ERD_WG3_NOSLAB) || defined(ERD_THIN_NOMFMA) || defined(ERD_THIN_NORES) || defined(ERD_WX3_NORAW) || defined(ERD_WINO_GNPROBE) || defined(ERD_GN_NOSTATS) || defined(ERD_X3_NINE) || \
+    defined(ERD_WX3_NOSPLIT) || defined(ERD_WX3_NOLOAD) || defined(ERD_WX3_VREAD1) || defined(ERD_WX3_VWRITE1) || defined(ERD_THIN_NOSTORE) || defined(ERD_WG3_NOSLAB) || defined(ERD_THIN_NOMFMA) || defined(ERD_WX3_NORAW) || defined(ERD_WINO_GNPROBE) || defined(ERD_GN_NOSTATS) || defined(ERD_X3_NINE) || \
     defined(ERD_IGEMM_TRACE) || defined(ERD_WINO_TRACE)
 #define ERD_PROBE_BUILD 1
 extern "C" __attribute__((weak, visibility("default"))) int erd_probe_build_marker = 1;

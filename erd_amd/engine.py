@@ -142,9 +142,14 @@ class BucketedGradSync:
     producing streams hold at that moment; the producing streams are never made to wait.  `reduce=False`: a single rank --
     the hooks only drive the update."""
 
-    def __init__(self, flat: FlatParams, streams: Sequence = (), reduce: bool = True, on_bucket=None, stream=None):
+    def __init__(self, flat: FlatParams, streams: Sequence = (), reduce: bool = True, on_bucket=None, stream=None, live_streams=None):
         self.flat = flat
         self.streams = list(streams)     # HIP streams that may hold gradient-producing kernels of one backward pass
+        # ... as known at construction.  A step may run under ANOTHER current stream (`with torch.cuda.stream(s)`, a capture's
+        # warm-up stream, a caller-owned stream): `live_streams()` names the producers of the moment a bucket is released (the
+        # current stream and the auxiliary streams keyed on it), and both sets are joined -- the update must never overtake a
+        # gradient kernel, nor rewrite weights an input-gradient launch still reads (ADVICE r4)
+        self.live_streams = live_streams
         self.reduce = reduce
         self.on_bucket = on_bucket
         self.stream = stream
@@ -173,14 +178,26 @@ class BucketedGradSync:
         """the coming backward is not this sync's business (a captured whole-step graph): hooks do nothing until arm()"""
         self._remaining = []
 
+    def _producers(self) -> List:
+        dev = self.flat.grad.device
+        if dev.type != "cuda":
+            return []
+        sts, seen = [], set()
+        for st in list(self.streams) + [torch.cuda.current_stream(dev)] + (list(self.live_streams()) if self.live_streams else []):
+            if st.cuda_stream not in seen:
+                seen.add(st.cuda_stream)
+                sts.append(st)
+        return sts
+
     def _issue(self, b: int) -> None:
         s, e, _ = self.flat.buckets[b]
         g = self.flat.grad[s:e]
         if self.stream is not None:
             # behind every kernel the producing streams hold now (a bucket's gradients come from kernels on several streams:
             # the two head towers run their backward on two, the backbone's weight gradients trail on a third)
-            for st in self.streams:
-                self.stream.wait_stream(st)
+            for st in self._producers():
+                if st.cuda_stream != self.stream.cuda_stream:
+                    self.stream.wait_stream(st)
             with torch.cuda.stream(self.stream):
                 if self.reduce:
                     w = all_reduce_sum_(g, async_op=True)
@@ -191,8 +208,8 @@ class BucketedGradSync:
             return
         if self.streams:
             cs = torch.cuda.current_stream(self.flat.grad.device)
-            for st in self.streams:
-                if st != cs:
+            for st in self._producers():
+                if st.cuda_stream != cs.cuda_stream:
                     cs.wait_stream(st)
         w = all_reduce_sum_(g, async_op=True) if self.reduce else None
         if self.on_bucket is not None:
@@ -343,14 +360,15 @@ class ERDTrainer:
         self.sync = None
         if self.distributed or self.bucket_update:
             producers = [torch.cuda.current_stream(dev), Fn.aux_stream(dev), Fn.trail_stream(dev)]
+            live = lambda: [Fn.aux_stream(dev), Fn.trail_stream(dev)]      # (keyed on the stream that is current when a bucket is released)
             if self.bucket_update:
                 bucket_of = {id(p): self.flat.bucket_of[i] for i, p in enumerate(self.flat.params)}
                 self.prefold.set_groups(lambda p: bucket_of.get(id(p)))
                 self.prep.group_of = lambda p: bucket_of.get(id(p))
                 self.sync = BucketedGradSync(self.flat, streams=producers, reduce=self.distributed, on_bucket=self._update_bucket,
-                                             stream=torch.cuda.Stream(device=dev))
+                                             stream=torch.cuda.Stream(device=dev), live_streams=live)
             else:
-                self.sync = BucketedGradSync(self.flat, streams=producers)
+                self.sync = BucketedGradSync(self.flat, streams=producers, live_streams=live)
         self.side = torch.cuda.Stream(device=dev) if self.overlap_teacher else None
         # whole-step hipGraph (one per input shape): everything between two SGD updates -- teacher, ERS, NMS, targets,
         # student forward, losses, backward on all streams -- is recorded once and replayed as ONE launch; the step is

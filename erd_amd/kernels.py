@@ -403,7 +403,8 @@ def _igemm_class(d, form: str) -> str:
     (csrc/conv_thin.hip, erd::conv_thin_x3_ok -- the same test; only consulted while timing is on)"""
     if _TIMING is None:
         return "conv_igemm_" + form
-    thin = (THIN and d.w_x3 and not d.w_bf16 and d.ntaps == 1 and d.Cin in (64, 128) and d.Cout % 32 == 0 and d.wrow % 8 == 0 and
+    thin = (THIN and d.w_x3 and not d.w_bf16 and not d.in_bf16 and not d.out_bf16 and d.ntaps == 1 and d.Cin in (64, 128) and
+            d.Cout % 32 == 0 and d.wrow % 8 == 0 and d.wk[0] % 8 == 0 and
             all(d.seg[i].ntaps == 0 for i in range(d.nseg)) and _lib.load().erd_conv_thin_enable(-1))
     return ("conv_thin_" if thin else "conv_igemm_") + form
 
