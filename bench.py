@@ -191,6 +191,20 @@ def _pmc_file(suffix: str, compute: str):
     return os.path.join(pdir, files[-1]) if files else None
 
 
+def pmc_provenance(compute: str = "f32") -> dict:
+    """The committed PMC summaries are STATIC (counters cannot be read from inside this process): each records the sha256 of the
+    kernel sources of the library it was taken on (tools/pmc_traffic.py / pmc_mfma.py `_meta.csrc_sha256` = erd_csrc_sha()); next to
+    it the live library's -- `pmc_stale` says the counters describe other code than the one benched."""
+    from erd_amd import _lib
+    live = _lib.load().erd_csrc_sha().decode()
+    shas = {}
+    for suffix in ("pmc_traffic.json", "pmc_mfma_busy.json"):
+        f = _pmc_file(suffix, compute)
+        if f is not None:
+            shas["profiles/" + os.path.basename(f)] = json.load(open(f)).get("_meta", {}).get("csrc_sha256")
+    return {"pmc_source_sha": shas, "library_csrc_sha": live, "pmc_stale": (not shas) or any(v != live for v in shas.values())}
+
+
 def pmc_traffic_per_launch(symbol_prefix: str, compute: str = "f32"):
     """HBM-side bytes per launch of the kernels whose symbol starts with `symbol_prefix`, from the committed PMC
     summary (two separate rocprofv3 --pmc passes, tools/pmc_traffic.py; FETCH_SIZE doubled as the gfx950 note in
@@ -291,6 +305,10 @@ def main():
                          "stream-K by default, so the N = 1 point of a scaling curve is the sibling of the N > 1 points)")
     ap.add_argument("--serial", action="store_true",
                     help="no stream concurrency in the timed region either (the rocprofv3 companion run)")
+    ap.add_argument("--occupy-cus", type=int, default=0,
+                    help="A/B aid, never the headline: a spin kernel (tools/occupy_cus.hip, compiled into /tmp) holds this many CUs on a side "
+                         "stream for the whole timed region -- a single-GPU stand-in for RCCL channels resident beside the backward pass "
+                         "(no N > 1 hardware reaches the builder: tools/cu_theft_step.sh, profiles/r05_cu_theft_step.txt)")
     ap.add_argument("--launcher", choices=["auto", "spawn", "none"], default="auto",
                     help="auto: --gpus N > 1 without a torchrun environment starts its own N ranks (torch.distributed.run as a child "
                          "process).  spawn: do that at any N (the world-1 test of the path).  none: never")
@@ -375,12 +393,29 @@ def main():
         log = trainer.train_step(*seq(j), next_batch=nb(j))
     trainer.flush()
     barrier()
+    occupier = None
+    if args.occupy_cus > 0:
+        import ctypes
+        import subprocess
+        so = f"/tmp/occupy_cus_{os.getpid()}.so"
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tools", "occupy_cus.hip"),
+                        "-o", so], check=True)
+        occ = ctypes.CDLL(so)
+        occ.occupy_cus.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+        occupier = (torch.cuda.Stream(device=device), torch.zeros(1, dtype=torch.int64, device=device))
+        torch.cuda.synchronize()
+        # two workgroups of 1024 threads + 64 KB of LDS fill a CU; long enough for the timed region at half the usual rate
+        occ.occupy_cus(2 * args.occupy_cus, int(args.steps * 0.09 * 2.4e9), occupier[1].data_ptr(), occupier[0].cuda_stream)
+        barrier = lambda: torch.cuda.current_stream(device).synchronize()      # (a device-wide wait would sit out the spin kernel)
     t0 = time.perf_counter()
     for j in range(warm, warm + args.steps):
         log = trainer.train_step(*seq(j), next_batch=nb(j))
     trainer.flush()                   # the deferred SGD of the last step belongs to the timed region
     barrier()
     dt = time.perf_counter() - t0
+    if occupier is not None:
+        still_held = not occupier[0].query()            # must be True: the spin kernel outlived the timed region
+        torch.cuda.synchronize()
     rel_area = sum(area(j) for j in range(warm, warm + args.steps)) / args.steps     # mean padded area of the timed steps / 800x1344
     # roofline leg: the same steps again with HIP events around every GEMM-shaped launch, streams serialized
     # (overlapping kernels have no well-defined individual duration).  Not part of `value`.
@@ -468,6 +503,9 @@ def main():
             "teacher": "hipGraph replay (one graph per padded shape and buffer parity)" if args.teacher_graph else "eager launches",
             "step_graph": bool(trainer.step_graph),
         }
+        if occupier is not None:
+            out["occupied_cus"] = {"cus": args.occupy_cus, "held_for_the_whole_timed_region": bool(still_held),
+                                   "note": "A/B aid (tools/occupy_cus.hip): NOT the headline configuration"}
         out["collectives"] = {"backend": ({"nccl": "nccl (RCCL)", "gloo": "gloo (host-staged: correctness vehicle, not a performance path)"}[dist.get_backend()]
                                           if dist.is_initialized() else None),
                               "world_size": dist.get_world_size() if dist.is_initialized() else 1, "devices": devices,
@@ -478,7 +516,7 @@ def main():
         shared = bool(getattr(model, "shares_trunk", lambda: False)())
         # student and teacher hold the same frozen stem + layer1: computed once per step and fed to both.  The skipped
         # launches are the student's copy (2.53 + 14.31 GMAC per image, BASELINE.md section 3 / SURVEY Appendix A);
-        # `roofline.step_frac` keeps counting the ALGORITHMIC work of the reference's step (both copies)
+        # `roofline.x_fp32_mfma_ceiling` keeps counting the ALGORITHMIC work of the reference's step (both copies)
         out["shared_frozen_trunk"] = {"enabled": shared, "skipped_gflop_per_image": TRUNK_GFLOP_PER_IMAGE if shared else 0.0}
         if ktime:
             peak_tf = BF16_MFMA_PEAK_TFLOPS if args.compute == "bf16" else FP32_MFMA_PEAK_TFLOPS   # every GEMM class follows --compute
@@ -529,6 +567,7 @@ def main():
                                "algorithmic_bytes_per_launch": int(dom["min_bytes"] / dom["launches"])}
             out["roofline"]["mfma_busy_pmc"], out["roofline"]["mfma_busy_source"] = pmc_mfma_busy(pmc_sym, args.compute)
             out["roofline"]["mfma_busy_static"] = True
+            out["roofline"].update(pmc_provenance(args.compute))
             # ---- every GEMM-shaped kernel symbol against BOTH of its bounds, on the pipe it runs on: live HIP-event
             # numbers of this run + the committed PMC passes (static, labelled); everything needed to recompute a fraction is in the row
             per_kernel = {}
@@ -559,12 +598,15 @@ def main():
                     "pmc_mfma_busy": k_busy, "pmc_static": True, "pmc_source": k_src}
             out["roofline"]["per_kernel"] = per_kernel
             out["roofline"]["sustained_peaks_source"] = "profiles/r04_mfma_peak_random.txt (tools/mfma_peak.hip, random operands)"
-            # ---- step level, three ways, all over the un-instrumented step time of the timed region and the same peak:
-            #  step_frac           the ALGORITHMIC work of the reference's step (both copies of the frozen trunk)
-            #  step_frac_executed  minus the student's copy of the shared frozen trunk, which this build does not execute
-            #  mfma_executed_frac  the flops the matrix cores actually run: additionally Winograd launches at 16/36
-            #                      = the share of the step the matrix pipes MUST be busy: sum over the launch classes of executed flops /
-            #                      the peak of the pipe they run on (three-limb launches: 6 x their flops on the bf16 pipe), over the step time
+            # ---- step level, over the un-instrumented step time of the timed region.  The ROOFLINE FRACTION of the step is
+            #  mfma_executed_frac  the share of the step the matrix pipes MUST be busy: sum over the launch classes of the flops they
+            #                      execute (Winograd launches at 16/36, three-limb launches 6 x their flops) / the peak of the pipe they
+            #                      run on, over the step time.
+            # The two other numbers are NOT fractions of a roofline: in the default "f32x3" mode no GEMM-shaped
+            # launch runs on the fp32 matrix cores any more, so the step can -- and does -- exceed what they could deliver at peak:
+            #  x_fp32_mfma_ceiling           the ALGORITHMIC work of the reference's step (both copies of the frozen
+            #                                trunk) per second, as a MULTIPLE of the fp32-MFMA peak (bf16 mode: of the bf16 peak)
+            #  x_fp32_mfma_ceiling_executed  the same minus the student's copy of the shared frozen trunk, which this build does not execute
             step_peak = BF16_MFMA_PEAK_TFLOPS if args.compute == "bf16" else FP32_MFMA_PEAK_TFLOPS
             g_img = STEP_GFLOP_PER_IMAGE[args.arch] * rel_area
             step_s = dt / args.steps
@@ -580,8 +622,9 @@ def main():
                 pipe_s = ((exec_gflop_step - igemm_alg) / step_peak + igemm_alg * 6.0 / BF16_MFMA_PEAK_TFLOPS) * 1e-3
             out["roofline"]["step_gflop_per_image"] = round(g_img, 1)
             out["roofline"]["step_tflops"] = round(args.batch * g_img / step_s / 1e3, 2)
-            out["roofline"]["step_frac"] = round(out["roofline"]["step_tflops"] / step_peak, 4)
-            out["roofline"]["step_frac_executed"] = round(args.batch * (g_img - skipped) / step_s / 1e3 / step_peak, 4)
+            out["roofline"]["x_fp32_mfma_ceiling"] = round(out["roofline"]["step_tflops"] / step_peak, 4)
+            out["roofline"]["x_fp32_mfma_ceiling_executed"] = round(args.batch * (g_img - skipped) / step_s / 1e3 / step_peak, 4)
+            out["roofline"]["x_ceiling_note"] = "multiples of the fp32-MFMA peak, not roofline fractions: the step's roofline fraction is mfma_executed_frac"
             out["roofline"]["mfma_executed_frac"] = round(pipe_s / step_s, 4)
             out["roofline"]["mfma_executed_gflop_per_step"] = round(exec_gflop_step, 1)
             if x3:

@@ -137,7 +137,7 @@ _SIGNATURES = {
     "erd_atss_result": [P, P, i64, P, P, P, P],
 }
 
-EXPORTS = ["erd_abi_version", "erd_probe_build", "erd_last_error"] + sorted(_SIGNATURES)
+EXPORTS = ["erd_abi_version", "erd_probe_build", "erd_last_error", "erd_csrc_sha"] + sorted(_SIGNATURES)
 
 _lib = None
 
@@ -158,6 +158,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.erd_abi_version.restype = C.c_int
     lib.erd_last_error.restype = C.c_char_p
+    lib.erd_csrc_sha.restype = C.c_char_p
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args

@@ -14,6 +14,10 @@ void set_error(const char* fmt, ...) {
 }  // namespace erd
 
 extern "C" int erd_abi_version(void) { return ERD_ABI_VERSION; }
+#ifndef ERD_CSRC_SHA
+#define ERD_CSRC_SHA "unknown"
+#endif
+extern "C" const char* erd_csrc_sha(void) { return ERD_CSRC_SHA; }
 // 1 when any translation unit of this library was compiled with a probe of erd_probes.h (a timing / accuracy / trace variant)
 extern "C" __attribute__((weak)) int erd_probe_build_marker;
 extern "C" int erd_probe_build(void) { return &erd_probe_build_marker != nullptr ? erd_probe_build_marker : 0; }

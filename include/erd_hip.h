@@ -48,6 +48,9 @@ int erd_abi_version(void);
  * such builds exist for same-box A/B measurements only and must never be the library a training run loads */
 int erd_probe_build(void);
 const char* erd_last_error(void);
+/* ABI v5.  sha256 (hex) over the sources this library was built from (csrc/Makefile: every .hip / .h of csrc/, the Makefile and this
+ * header, concatenated in sorted path order; tools/csrc_sha.py computes the same value from a checkout): ties measurements to code */
+const char* erd_csrc_sha(void);
 
 /* ---- convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) --------------------
  * One "segment" = one feature map (level); a launch may batch up to ERD_MAX_SEG

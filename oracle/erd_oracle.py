@@ -180,6 +180,42 @@ class bf16_multiplicands:
         _BF16_MULTIPLICANDS = self.prev
 
 
+# `with bf16_stored_maps():` additionally rounds every STORED feature map to bf16 where the HIP path's bf16 mode stores one (DESIGN 8.0c:
+# maps and their gradients live in HBM as bf16, what the reference's AMP switch does to conv outputs, tools/train.py:85-97) -- the stem's
+# and every conv + BN (+ ReLU) block's output, the residual sum behind its ReLU, the projection shortcut, FPN laterals / top-down sums /
+# outputs, the raw tower convolutions (the GroupNorm INPUT) and the GroupNorm + ReLU outputs; head outputs, statistics, losses and
+# parameters stay fp32.  The gradient that flows back through a stored map is rounded too (gradient maps are bf16 maps).  With the
+# rounding points shared, the discrete decisions of the step (ReLU masks, ERS thresholds, ATSS candidates) fall the same way on both
+# sides, which "multiplicands only" cannot promise: tests/test_gpu_e2e.py holds the HIP bf16 step to a FRACTION of the bf16-vs-fp32 noise.
+_BF16_STORED = False
+
+
+class bf16_stored_maps:
+    def __enter__(self):
+        global _BF16_MULTIPLICANDS, _BF16_STORED
+        self.prev = (_BF16_MULTIPLICANDS, _BF16_STORED)
+        _BF16_MULTIPLICANDS = _BF16_STORED = True
+
+    def __exit__(self, *exc):
+        global _BF16_MULTIPLICANDS, _BF16_STORED
+        _BF16_MULTIPLICANDS, _BF16_STORED = self.prev
+
+
+class _StoreBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _store(x):
+    """a feature map as the bf16 mode keeps it in memory (identity outside `bf16_stored_maps`)"""
+    return _StoreBF16.apply(x) if _BF16_STORED else x
+
+
 def _conv2d(x, w, b=None, stride=1, padding=0):
     if _BF16_MULTIPLICANDS:
         x, w = x.to(torch.bfloat16).to(torch.float32), w.to(torch.bfloat16).to(torch.float32)
@@ -192,26 +228,40 @@ def _bn_eval(x, sd, p):
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
 
 
+def resnet_stem(sub: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """resnet.py:631-640: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2 (`sub`: the backbone's state dict without its prefix)"""
+    x = F.conv2d(x, sub["conv1.weight"], None, 2, 3)
+    x = _store(F.relu(_bn_eval(x, sub, "bn1")))
+    return F.max_pool2d(x, 3, 2, 1)
+
+
+def resnet_block(sub: Dict[str, Tensor], x: Tensor, li: int, b: int) -> Tensor:
+    """Bottleneck.forward, resnet.py:263-302 (style='pytorch': stride on conv2; block 0 of a stage carries the projection shortcut)"""
+    p = f"layer{li + 1}.{b}"
+    stride = 2 if (b == 0 and li > 0) else 1
+    identity = x
+    out = _store(F.relu(_bn_eval(_conv2d(x, sub[p + ".conv1.weight"]), sub, p + ".bn1")))
+    out = _store(F.relu(_bn_eval(_conv2d(out, sub[p + ".conv2.weight"], None, stride, 1), sub, p + ".bn2")))
+    out = _bn_eval(_conv2d(out, sub[p + ".conv3.weight"]), sub, p + ".bn3")
+    if b == 0:
+        identity = _store(_bn_eval(_conv2d(x, sub[p + ".downsample.0.weight"], None, stride), sub, p + ".downsample.1"))
+    return _store(F.relu(out + identity))
+
+
+def resnet_layer(sub: Dict[str, Tensor], x: Tensor, li: int, depth: int = 50) -> Tensor:
+    """one stage (`layer{li+1}`) of Bottleneck blocks, res_layer.py:57-63"""
+    for b in range(RESNET_BLOCKS[depth][li]):
+        x = resnet_block(sub, x, li, b)
+    return x
+
+
 def resnet_forward(sd: Dict[str, Tensor], x: Tensor, depth: int = 50, prefix: str = "backbone.") -> List[Tensor]:
-    """resnet.py:631-646 + Bottleneck.forward :263-302 (style='pytorch': stride on conv2)."""
-    g = lambda k: sd[prefix + k]
+    """resnet.py:631-646 + Bottleneck.forward :263-302."""
     sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-    x = F.conv2d(x, g("conv1.weight"), None, 2, 3)
-    x = F.relu(_bn_eval(x, sub, "bn1"))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = resnet_stem(sub, x)
     outs = []
-    for li, nblk in enumerate(RESNET_BLOCKS[depth]):
-        for b in range(nblk):
-            p = f"layer{li + 1}.{b}"
-            stride = 2 if (b == 0 and li > 0) else 1
-            identity = x
-            out = F.relu(_bn_eval(_conv2d(x, sub[p + ".conv1.weight"]), sub, p + ".bn1"))
-            out = F.relu(_bn_eval(_conv2d(out, sub[p + ".conv2.weight"], None, stride, 1), sub, p + ".bn2"))
-            out = _bn_eval(_conv2d(out, sub[p + ".conv3.weight"]), sub, p + ".bn3")
-            if b == 0:
-                identity = _bn_eval(_conv2d(x, sub[p + ".downsample.0.weight"], None, stride), sub,
-                                    p + ".downsample.1")
-            x = F.relu(out + identity)
+    for li in range(len(RESNET_BLOCKS[depth])):
+        x = resnet_layer(sub, x, li, depth)
         outs.append(x)
     return outs
 
@@ -221,14 +271,14 @@ def fpn_forward(sd: Dict[str, Tensor], feats: Sequence[Tensor], prefix: str = "n
     no norm / no activation, nearest top-down with size= (fpn.py:181-191)."""
     g = lambda k: sd[prefix + k]
     ins = feats[1:]
-    lats = [_conv2d(ins[i], g(f"lateral_convs.{i}.conv.weight"), g(f"lateral_convs.{i}.conv.bias"))
+    lats = [_store(_conv2d(ins[i], g(f"lateral_convs.{i}.conv.weight"), g(f"lateral_convs.{i}.conv.bias")))
             for i in range(3)]
     for i in range(2, 0, -1):
-        lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode="nearest")
-    outs = [_conv2d(lats[i], g(f"fpn_convs.{i}.conv.weight"), g(f"fpn_convs.{i}.conv.bias"), 1, 1)
+        lats[i - 1] = _store(lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode="nearest"))
+    outs = [_store(_conv2d(lats[i], g(f"fpn_convs.{i}.conv.weight"), g(f"fpn_convs.{i}.conv.bias"), 1, 1))
             for i in range(3)]
-    outs.append(_conv2d(outs[-1], g("fpn_convs.3.conv.weight"), g("fpn_convs.3.conv.bias"), 2, 1))
-    outs.append(_conv2d(outs[-1], g("fpn_convs.4.conv.weight"), g("fpn_convs.4.conv.bias"), 2, 1))
+    outs.append(_store(_conv2d(outs[-1], g("fpn_convs.3.conv.weight"), g("fpn_convs.3.conv.bias"), 2, 1)))
+    outs.append(_store(_conv2d(outs[-1], g("fpn_convs.4.conv.weight"), g("fpn_convs.4.conv.bias"), 2, 1)))
     return outs
 
 
@@ -241,14 +291,19 @@ def gfl_head_forward(sd: Dict[str, Tensor], feats: Sequence[Tensor], prefix: str
     for l, x in enumerate(feats):
         c, r = x, x
         for i in range(4):
-            c = F.relu(F.group_norm(_conv2d(c, g(f"cls_convs.{i}.conv.weight"), None, 1, 1), 32,
-                                    g(f"cls_convs.{i}.gn.weight"), g(f"cls_convs.{i}.gn.bias"), 1e-5))
-            r = F.relu(F.group_norm(_conv2d(r, g(f"reg_convs.{i}.conv.weight"), None, 1, 1), 32,
-                                    g(f"reg_convs.{i}.gn.weight"), g(f"reg_convs.{i}.gn.bias"), 1e-5))
+            c = head_tower_layer(sd, c, "cls", i, prefix)
+            r = head_tower_layer(sd, r, "reg", i, prefix)
         cls_scores.append(_conv2d(c, g("gfl_cls.weight"), g("gfl_cls.bias"), 1, 1))
         bbox_preds.append((_conv2d(r, g("gfl_reg.weight"), g("gfl_reg.bias"), 1, 1)
                            * g(f"scales.{l}.scale")).float())
     return cls_scores, bbox_preds
+
+
+def head_tower_layer(sd: Dict[str, Tensor], x: Tensor, branch: str, i: int, prefix: str = "bbox_head.") -> Tensor:
+    """one ConvModule of a tower on one level: conv3x3 (no bias) -> GroupNorm(32) -> ReLU, gfl_head.py:158-177, 219-222"""
+    g = lambda k: sd[prefix + k]
+    return _store(F.relu(F.group_norm(_store(_conv2d(x, g(f"{branch}_convs.{i}.conv.weight"), None, 1, 1)), 32,
+                                      g(f"{branch}_convs.{i}.gn.weight"), g(f"{branch}_convs.{i}.gn.bias"), 1e-5)))
 
 
 def gfl_forward(sd: Dict[str, Tensor], x: Tensor, depth: int = 50) -> Tuple[List[Tensor], List[Tensor]]:

@@ -49,3 +49,25 @@ def test_gpus_2_on_a_cpu_box_fails_in_the_children_not_in_the_parent():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "needs an MI355X" in r.stderr and "launch with torch.distributed.run" not in r.stderr.split("needs an MI355X")[0]
+
+
+def test_committed_pmc_summaries_describe_the_kernel_sources_at_head():
+    """bench.py's `roofline.traffic` / `mfma_busy_pmc` / `per_kernel.pmc_*` are static reads of the newest profiles/*_pmc_*.json
+    (chosen by file name): each summary records the sha256 of the kernel sources of the library it was taken on, and the newest one of
+    each kind must be the sha of erd_amd/csrc/ as committed -- a kernel change without a fresh `tools/profile_round.sh` fails here
+    instead of shipping counters of other code; the library carries the same sha (erd_csrc_sha())."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    from csrc_sha import csrc_sha256
+    from erd_amd import _lib
+    head = csrc_sha256(ROOT)
+    assert _lib.load().erd_csrc_sha().decode() == head, "liberd_hip.so was not built from the sources in the tree: make -C erd_amd/csrc"
+    for compute in ("f32", "bf16"):
+        for suffix in ("pmc_traffic.json", "pmc_mfma_busy.json"):
+            f = bench._pmc_file(suffix, compute)
+            assert f is not None, (compute, suffix)
+            got = json.load(open(f)).get("_meta", {}).get("csrc_sha256")
+            assert got == head, f"{os.path.relpath(f, ROOT)} was taken on other kernel sources ({got}): rerun tools/profile_round.sh"
+    prov = bench.pmc_provenance("f32")
+    assert prov["pmc_stale"] is False and prov["library_csrc_sha"] == head

@@ -34,7 +34,9 @@ def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path, H, W, bucket_
     from e2e_util import f7_state_dicts
     from oracle import erd_oracle as O
     import world2_worker as Wk
-    WORLD, STEPS = 2, 3
+    # (three steps; the full-size case two in the default run -- ERD_TEST_FULL=1: three -- the second step already runs on weights both
+    #  ranks updated from the summed gradient, and the oracle's two-rank trajectory on the host is the test's time)
+    WORLD, STEPS = 2, (3 if (H < 800 or os.environ.get("ERD_TEST_FULL", "0") == "1") else 2)
     port = str(_free_port())
     env = dict(os.environ, ERD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD2_BUCKET_MB=str(bucket_mb))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):

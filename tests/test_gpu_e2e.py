@@ -664,10 +664,14 @@ def test_bf16_full_size_step_against_the_fp32_path():
 def test_bf16_full_size_step_against_the_oracle_bf16_mode():
     """The same bf16 step against the ORACLE in its bf16 mode (`O.bf16_multiplicands()`: both multiplicands of every 1x1 / 3x3
     convolution rounded to bf16, fp32 accumulation -- what the reference's AMP switch does to the convolutions, tools/train.py:85-97)
-    at BASELINE size, not against this package's own fp32 path ("a bound a bug would trip").  Both sides round at
-    the same places (the HIP path additionally stores maps as bf16, i.e. its residual adds and GroupNorm inputs see rounded values
-    too), so they must agree with each other MUCH better than either agrees with fp32: the oracle's bf16 mode is itself only
-    cos ~0.99 from the oracle's fp32 gradients.  Asserted relative to that measured noise floor."""
+    at BASELINE size, not against this package's own fp32 path.  END TO END this can only be a SANITY bound at the bf16 noise floor:
+    a network whose maps are rounded to bf16 is chaotic at the 4e-3 level (a 1e-7 difference in summation order lands on the other
+    side of a rounding boundary now and then, every flip is a full bf16 ulp, and flips multiply from layer to layer), so that ANY two
+    bf16 implementations -- this path against the oracle's `bf16_stored_maps` mode with identical rounding points included
+    (tools/dbg/bf16_parity_probe.py: 1 - cos 0.0092 against 0.0118 for `bf16_multiplicands`, the floor 0.0104-0.0109) -- are as far
+    from each other as each is from fp32, and a 1 % defect in one kernel does not move these numbers (measured 0.98824
+    against 0.98956).  The bound that CAN fail on such a defect is unit-wise and teacher-forced: tests/test_gpu_bf16_stagewise.py.
+    Asserted here, relative to the measured floor: direction, norm, losses and ERS overlap no worse than the oracle's own bf16-vs-fp32."""
     from erd_amd import kernels as K, parse_losses
     tsd, ssd = f7_state_dicts()
     names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]

@@ -10,6 +10,8 @@
     near-zero pre-activations flip under any fp32 re-ordering and one flip moves every gradient tensor by ~1e-3 ON EITHER
     SIDE, so the distance to the fp32 CPU reference alone says nothing about who is right (the test's docstring has the
     measured table and the assertions it supports)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,17 +22,23 @@ from e2e_util import build_erd, f7_state_dicts, make_samples
 from oracle import erd_oracle as O
 
 
+# The driver runs `pytest -m gpu` under a 1 200 s limit (<= 600 s asked): the default run takes the PINNED half of
+# each sample below; ERD_TEST_FULL=1 runs the full ones (12 fp64 seeds, 32 ERS images) -- once per round by the builder
+# (profiles/r05_gpu_suite_full.txt); the 144-seed statistics live in profiles/r04_parity_seeds.json either way.
+FULL = os.environ.get("ERD_TEST_FULL", "0") == "1"
+
+
 @pytest.fixture(scope="module")
 def nets():
     tsd, ssd = f7_state_dicts()
     return tsd, ssd, build_erd(tsd, ssd)
 
 
-def test_ers_index_sets_over_32_full_size_images(nets):
+def test_ers_index_sets_over_full_size_images(nets):
     from erd_amd import kernels as K
     tsd, ssd, model = nets
     model.eval()
-    nimg, bs = 32, 4
+    nimg, bs = (32 if FULL else 16), 4          # (the oracle's teacher pass on the host is 2.5 s per image)
     # teacher on Winograd (True) / direct (False) kernels, in the default fp32 form ("f32x3": direct launches on the bf16 matrix
     # cores through exact three-limb splits) and with the direct launches on the native fp32 MFMA ("f32"):
     # [images with a differing set, differing anchors]
@@ -70,7 +78,7 @@ def test_ers_index_sets_over_32_full_size_images(nets):
     print("ERS sets vs the CPU oracle over %d full-size images, images (anchors) that differ: %s"
           % (nimg, ", ".join("%s teacher / %s: %d (%d)" % ("Winograd" if w else "direct", m, v[0], v[1]) for (w, m), v in stats.items())))
     # north_star: "ERS index masks bit-exact".  The DEFAULT configuration (Winograd teacher, three-limb direct launches) must match
-    # the oracle on every one of the 32 images (measured: 0 differing in all four configurations since round 2); the three A/B
+    # the oracle on every one of the images (measured: 0 of 32 differing in all four configurations since round 2); the three A/B
     # configurations may each own at most one image with a single anchor ON the threshold (checked above: margin < 1e-5)
     assert stats[(True, K.DEFAULT_COMPUTE)] == [0, 0], stats
     assert all(v[0] <= 1 for v in stats.values()), stats
@@ -97,11 +105,13 @@ def test_benched_batch_of_four_losses_and_ers_vs_oracle(nets):
         assert torch.equal(t.ers["idx_bbox"][i, :int(cnt[i, 1])].cpu(), aux["ers_bbox"][i]), i
 
 
-SEEDS_FP64 = (7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)
+WORST_TENSOR_F32X3 = 6e-3      # pinned-seed tripwire of the three-limb form (a systematic layer error read 1.1e-2 on three seeds in a row)
+SEEDS_FP64 = (7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18) if FULL else (7, 8, 9, 10, 11, 12)
 
 
 def test_full_size_gradients_anchored_to_fp64(nets):
-    """Twelve full-size steps (seeds 7-18), each evaluated three times: the oracle in fp64 (the truth), the oracle in fp32 (the
+    """Six full-size steps (seeds 7-12; ERD_TEST_FULL=1: the twelve seeds 7-18 the bounds below were first written for -- every one of
+    them also holds on seeds 7-12, checked on profiles/r04_parity_seeds.json), each evaluated three times: the oracle in fp64 (the truth), the oracle in fp32 (the
     reference's own arithmetic) and the HIP path in both fp32 forms of its direct launches.  Relative L2 distance to fp64 as
     median over the 175 gradient tensors / all elements (= the whole gradient) / worst tensor.
 
@@ -203,9 +213,10 @@ def test_full_size_gradients_anchored_to_fp64(nets):
         else:                                                                                        # A, the three-limb form's own
             assert above <= above_cpu + 1 and (hip[:, 1] <= 2.5e-3).all() and float(np.median(hip[:, 1])) <= 1e-3, (mode, hip[:, 1], cpu[:, 1])
         assert (hip.mean(0) <= 1.25 * cpu.mean(0)).all(), (mode, hip.mean(0), cpu.mean(0))          # B
-        assert (hip[:, 2] <= 6e-3).all(), (mode, hip[:, 2])                                         # C
+        # C: 5e-3 for the native form as in round 3 [3.5e-3]; the three-limb form keeps its own, named bound [4.98e-3 on seed 13]
+        assert (hip[:, 2] <= (5e-3 if mode == "f32" else WORST_TENSOR_F32X3)).all(), (mode, hip[:, 2])
     x3, f32 = np.array(hip_rows["f32x3"]), np.array(hip_rows["f32"])
-    print("three-limb / native means over the 12 seeds (median, whole gradient, worst tensor): %s" % (x3.mean(0) / f32.mean(0),))
+    print("three-limb / native means over the pinned seeds (median, whole gradient, worst tensor): %s" % (x3.mean(0) / f32.mean(0),))
     assert x3[:, 1].mean() <= 1.5 * f32[:, 1].mean(), (x3[:, 1].mean(), f32[:, 1].mean())             # B, between the two forms
 
 

@@ -26,4 +26,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))
     if a > 0 and b > 0:
         out[k] = dict(launches=cnt[k], mfma_busy_fraction=round(b / (a / 8 * 1024), 4),
                       gui_active_cycles_per_launch=round(a / 8 / cnt[k], 1))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from erd_amd import _lib
+out["_meta"] = {"csrc_sha256": _lib.load().erd_csrc_sha().decode()}     # the library the counters were taken on
 json.dump(out, sys.stdout, indent=1)

@@ -33,6 +33,13 @@ def load(d, counter):
     return agg
 
 
+def meta():
+    """which library the counters were taken on: the sha of its sources (erd_csrc_sha(); bench.py flags a summary whose sha is not the live library's)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from erd_amd import _lib
+    return {"csrc_sha256": _lib.load().erd_csrc_sha().decode()}
+
+
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {}
@@ -46,6 +53,7 @@ def main():
         out[k] = dict(launches=n, fetch_MB_raw=round(f_mb, 3), fetch_MB_corrected=round(2 * f_mb, 3),
                       write_MB=None if w_mb is None else round(w_mb, 3),
                       traffic_MB=None if w_mb is None else round(2 * f_mb + w_mb, 3))
+    out["_meta"] = meta()
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -31,7 +31,7 @@ for f in default f32native forcedist plain20 bf16 r101 mixed bf16_mixed serial b
 import json
 try:
     d = json.load(open("$O/${f}_bench.json")); r = d.get("roofline", {})
-    print("$f", d["value"], d["ms_per_step"], r.get("kernel"), r.get("frac"), r.get("step_frac"), r.get("step_frac_executed"), r.get("mfma_executed_frac"))
+    print("$f", d["value"], d["ms_per_step"], r.get("kernel"), r.get("frac"), r.get("mfma_executed_frac"), r.get("x_fp32_mfma_ceiling"), r.get("x_fp32_mfma_ceiling_executed"))
 except Exception as e:
     print("$f", "ERR", e)
 PY
