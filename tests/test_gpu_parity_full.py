@@ -331,8 +331,10 @@ def test_benched_trainer_configuration_follows_the_oracle_trajectory_at_full_siz
     for ahead, share in ((False, True), (True, False), (False, False)):
         other, oparams, _ = hip_run(ahead, share)
         for it, (a, b) in enumerate(zip(logs, other)):
-            for k in a:      # (without the shared trunk the teacher's trunk runs on the Winograd kernels: 1e-6-level logit changes)
-                assert b[k] == pytest.approx(a[k], rel=(5e-6 if share else 1e-4) if it == 0 else 5e-4, abs=1e-6), (ahead, share, it, k, a[k], b[k])
+            for k in a:      # (without the shared trunk the teacher's trunk runs on the Winograd kernels: 1e-6-level logit changes;
+                # from the second step on such a change now and then moves ONE anchor across an ERS threshold or an ATSS tie -- round 5
+                # read 5.5e-4 in loss_cls at step 1 on one box in two runs -- so later steps get the 1e-3 of the oracle comparison above)
+                assert b[k] == pytest.approx(a[k], rel=(5e-6 if share else 1e-4) if it == 0 else 1e-3, abs=1e-6), (ahead, share, it, k, a[k], b[k])
         n2 = sum(float((oparams[k].double() - params[k].double()).pow(2).sum()) for k in names)
         d2 = sum(float((params[k].double() - ssd[k].double()).pow(2).sum()) for k in names)
         assert (n2 / d2) ** 0.5 < 5e-3, (ahead, share, (n2 / d2) ** 0.5)
