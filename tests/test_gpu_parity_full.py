@@ -299,13 +299,15 @@ def test_benched_trainer_configuration_follows_the_oracle_trajectory_at_full_siz
 
     try:
         ref, sd = oracle_run(0.0)
-        ref_eps, _ = oracle_run(1e-6)
+        # (the oracle's own 1e-6 sensitivity: a second trajectory on the host, 25 s -- ERD_TEST_FULL=1; the default run uses the value
+        #  it has read since round 3, 1.7e-3 at the third step)
+        ref_eps = oracle_run(1e-6)[0] if FULL else None
     finally:
         torch.set_num_threads(threads)
     rel = lambda a, b: abs(a - b) / max(abs(b), 1e-7)
     for it in range(STEPS):
         print("step %d, relative deviation from the oracle's trajectory, hip | the oracle itself from weights x (1 + 1e-6 noise): %s"
-              % (it, "  ".join("%s %.1e | %.1e" % (k, rel(logs[it][k], v), rel(ref_eps[it][k], v)) for k, v in ref[it].items())))
+              % (it, "  ".join("%s %.1e | %s" % (k, rel(logs[it][k], v), "%.1e" % rel(ref_eps[it][k], v) if ref_eps else "-") for k, v in ref[it].items())))
     # Measured (lr 0.0025): every entry within 2.4e-5 / 2.2e-4 of the oracle at steps 0 / 1, the TOTAL within 7e-5 at step 2;
     # single entries at step 2 up to 1.4e-3 (loss_dist_cls) -- where the oracle's OWN trajectory from weights perturbed by
     # 1e-6 is 1.7e-3 away: after two updates the per-image distillation terms (a few hundred ERS anchors each) are conditioned
@@ -313,9 +315,9 @@ def test_benched_trainer_configuration_follows_the_oracle_trajectory_at_full_siz
     # steps 0 and 1; at step 2 within the larger of 1e-3 and twice the oracle's own 1e-6 sensitivity of its WORST entry at that
     # step (round 4: with the rounding limb split the deviation moved to loss_dist_bbox, 1.3e-3, where this noise realisation of
     # the oracle happened to move little -- which entry a perturbation lands on is chance, the step's conditioning is not).
-    for it, (g, r, e) in enumerate(zip(logs, ref, ref_eps)):
+    for it, (g, r) in enumerate(zip(logs, ref)):
         assert g["loss"] == pytest.approx(r["loss"], rel=1e-3), (it, g["loss"], r["loss"])
-        own = max(rel(e[k], v) for k, v in r.items())
+        own = max(rel(ref_eps[it][k], v) for k, v in r.items()) if ref_eps else 1.7e-3
         for k, v in r.items():
             tol = 1e-3 if it < 2 else max(1e-3, 2.0 * own)
             assert rel(g[k], v) <= tol, (it, k, g[k], v, tol)
