@@ -231,3 +231,42 @@ def test_f10_head_losses_with_empty_ground_truth(golden, case):
         close(s_bbox[l].grad, g[f"c{case}_g_bbox{l}"], rtol=1e-4, atol=1e-8)
     if case == 1:
         assert all(float(v) == 0 for v in losses["loss_bbox"]) and all(float(v) == 0 for v in losses["loss_dfl"])
+
+
+def test_bf16_modes_of_the_oracle_round_where_they_say():
+    """`bf16_multiplicands` rounds the operands of the 1x1 / 3x3 convolutions only; `bf16_stored_maps` (round 5: the mode the unit-wise
+    GPU test of BASELINE configs[2] compares against, tests/test_gpu_bf16_stagewise.py) additionally rounds every stored map and the
+    gradient that flows back through it.  Outside the contexts the stage pieces (`resnet_stem` / `resnet_block` / `resnet_layer`,
+    `head_tower_layer`) compose to exactly `gfl_forward` -- which the reference fixtures pin."""
+    from e2e_util import f7_state_dicts
+    tsd, ssd = f7_state_dicts()
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(3))
+    sub = {k[len("backbone."):]: v for k, v in ssd.items() if k.startswith("backbone.")}
+    rep = lambda t: torch.equal(t, t.to(torch.bfloat16).to(torch.float32))
+    with torch.no_grad():
+        ref = O.resnet_forward(ssd, x)
+        h = O.resnet_stem(sub, x)
+        for li in range(4):
+            for b in range(O.RESNET_BLOCKS[50][li]):
+                h = O.resnet_block(sub, h, li, b)
+            assert torch.equal(h, ref[li])                                  # composition == the pinned forward, bit for bit
+        assert not rep(ref[1])
+        with O.bf16_multiplicands():
+            m = O.resnet_forward(ssd, x)
+        with O.bf16_stored_maps():
+            s = O.resnet_forward(ssd, x)
+            p = O.fpn_forward(ssd, s)
+            c, r = O.gfl_head_forward(ssd, p)
+        assert not rep(m[1]) and all(rep(t) for t in s) and all(rep(t) for t in p)     # maps are stored rounded ...
+        assert not rep(c[0]) and not rep(r[0])                                          # ... head outputs stay fp32
+        assert 1e-4 < float((m[3] - ref[3]).norm() / ref[3].norm()) < 3e-2
+        assert 1e-4 < float((s[3] - ref[3]).norm() / ref[3].norm()) < 3e-2
+    # the gradient through a stored map is rounded as well; outside the context `_store` is the identity
+    t = torch.randn(4, 8, requires_grad=True)
+    g = torch.randn(4, 8)
+    with O.bf16_stored_maps():
+        O._store(t * 1.0).backward(g)
+    assert torch.equal(t.grad, g.to(torch.bfloat16).to(torch.float32))
+    t.grad = None
+    O._store(t * 1.0).backward(g)
+    assert torch.equal(t.grad, g) and not O._BF16_STORED and not O._BF16_MULTIPLICANDS
