@@ -387,8 +387,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
             auto rest = [&](const float (&v)[8], const u4v& P, float (&r)[8]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    r[2 * e] = v[2 * e] - erd::bf16_lo(P[e]);
-                    r[2 * e + 1] = v[2 * e + 1] - erd::bf16_hi(P[e]);
+                    r[2 * e] = erd::scalar_op(v[2 * e] - erd::bf16_lo(P[e]));
+                    r[2 * e + 1] = erd::scalar_op(v[2 * e + 1] - erd::bf16_hi(P[e]));
                 }
             };
             auto read_a = [&](int kk, float (&x)[8]) {

@@ -91,11 +91,18 @@ __device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_read
 // three-limb GEMM drops (a_mid b_lo + a_lo b_mid + a_lo b_lo) were a bias towards zero of up to 2^-21 |a b| per product; here
 // they are zero-mean and below 2^-23 |a b|.  Two values per call: v_cvt_pk_bf16_f32 rounds and packs a pair in one instruction.
 // limb words: value 0 in bits 0..15, value 1 in bits 16..31 (the order the bf16 MFMA fragments and LDS rows want).
+// (`scalar_op`: the value passes through an empty asm, so clang's SLP vectorizer cannot pair the subtraction that produced it with its
+//  neighbour into a v_pk_add_f32 -- a packed fp32 instruction costs ~13 cycles over its issue slot beside an MFMA stream on gfx950, and the
+//  limb split always runs beside one: profiles/r05_noslp_ab.txt.  No instruction is emitted.)
+__device__ __forceinline__ float scalar_op(float v) {
+    asm("" : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ void limbs3_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
     hi = pack2_bf16(x0, x1);
-    const float r0 = x0 - bf16_lo(hi), r1 = x1 - bf16_hi(hi);
+    const float r0 = scalar_op(x0 - bf16_lo(hi)), r1 = scalar_op(x1 - bf16_hi(hi));
     mid = pack2_bf16(r0, r1);
-    lo = pack2_bf16(r0 - bf16_lo(mid), r1 - bf16_hi(mid));
+    lo = pack2_bf16(scalar_op(r0 - bf16_lo(mid)), scalar_op(r1 - bf16_hi(mid)));
 }
 __device__ __forceinline__ void limbs3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
     unsigned h, m, l;
