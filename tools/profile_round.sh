@@ -27,7 +27,12 @@ prof serial --serial --steps 6 --warmup 2 --no-cpu-baseline
 prof bf16_serial --serial --steps 6 --warmup 2 --no-cpu-baseline --compute bf16
 pmc f32
 pmc bf16 --compute bf16
-for f in default f32native forcedist plain20 bf16 r101 mixed bf16_mixed serial bf16_serial; do python - <<PY
+# the default line once more with THIS run's PMC summaries in place (bench.py reads the newest profiles/*_pmc_*.json: the first line above
+# was taken before they existed and carries `pmc_stale`)
+cp $O/f32_pmc_traffic.json profiles/${T}_f32_pmc_traffic.json; cp $O/f32_pmc_mfma_busy.json profiles/${T}_f32_pmc_mfma_busy.json
+cp $O/bf16_pmc_traffic.json profiles/${T}_bf16_pmc_traffic.json; cp $O/bf16_pmc_mfma_busy.json profiles/${T}_bf16_pmc_mfma_busy.json
+python bench.py > $O/default_final_bench.log 2>&1; line $O/default_final_bench.log > $O/default_final_bench.json
+for f in default default_final f32native forcedist plain20 bf16 r101 mixed bf16_mixed serial bf16_serial; do python - <<PY
 import json
 try:
     d = json.load(open("$O/${f}_bench.json")); r = d.get("roofline", {})
