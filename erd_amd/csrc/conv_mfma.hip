@@ -105,7 +105,7 @@ int xcd_order_enabled() {
 // owns 32 pixel rows x all BN couts) so that every activation value is split by exactly one wave: 44 VALU operations per 24
 // MFMAs.  One K-slice = 32 channels = two k16 steps.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false,
-          bool OB = false, bool X3 = false>
+          bool OB = false, bool X3 = false, bool RES = false, bool MSK = false>     // RES / MSK (f32x3 only): some segment has a residual / a mask
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
                                                                      const SkWs ws) {
     constexpr int NT = WAVES_M * WAVES_N * 64;   // threads: four waves, or eight on the 256-row tiles of the bf16 mode
@@ -658,50 +658,85 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
                 const int c4 = lane % C4N, rsub = lane / C4N;
                 const int co = n0 + c4 * 4;
                 const bool cvalid = co < p.Cout;
-                // residual / mask rows of the first half are requested before the accumulators are staged
-                const OutT* pf_src = res ? res : msk;
-                constexpr int NPH = NIT >= 16 ? 4 : 2, NPQ = NIT / NPH;      // phases, rows per lane and phase (register budget)
-                float4 pf[NPQ];
-                auto prefetch = [&](int it0) {
-                    if (pf_src && cvalid) {
-#pragma unroll
-                        for (int q = 0; q < NPQ; ++q) {
-                            const int oo = rows_epi[wave * 32 + (it0 + q) * RPW + rsub].out_off;
-                            if (oo >= 0) pf[q] = erd::ld4(pf_src + oo + co);
-                        }
-                    }
+                // gfx950 counts loads AND stores in vmcnt, in issue order: a wait for a load that was issued behind a store also waits
+                // for that store's acknowledgement (~650 cycles under load), and a store under `if (row valid)` is not counted as
+                // "younger" by the compiler, which then waits vmcnt(0) in front of every store (16 serialized acknowledgements per
+                // tile until round 5).  So: every residual / mask / scale / shift load of the tile is issued BEFORE its first
+                // store, the stores are unconditional buffer stores (rows / columns past the end carry the offset OOB and are
+                // dropped), and nothing but arithmetic sits between them.
+                const int out_bytes = erd::uniform_int((int)((long long)sg.N * sg.out_nstride * 4));
+                const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(erd::uniform_ptr(sg.out), 0, out_bytes, 0x00020000);
+                // (a segment without the residual / mask the launch's other segments have gets an EMPTY buffer: its loads return zeros)
+                const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+                    erd::uniform_ptr(const_cast<float*>(sg.res ? sg.res : sg.out)), 0, erd::uniform_int(sg.res ? out_bytes : 0), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(
+                    erd::uniform_ptr(const_cast<float*>(sg.mask ? sg.mask : sg.out)), 0, erd::uniform_int(sg.mask ? out_bytes : 0), 0x00020000);
+                const bool no_msk = sg.mask == nullptr;
+                auto row_off = [&](int q) -> unsigned {
+                    const int oo = rows_epi[wave * 32 + q * RPW + rsub].out_off;
+                    return (oo < 0 || !cvalid) ? OOB : (unsigned)(oo + co) * 4u;
                 };
-                prefetch(0);
+                // The wave's rows go out in phases of NP rows; a phase's residual / mask rows (NP x 16 B per lane and map) are requested
+                // in front of the previous phase's stores at the earliest -- phase 0's before the accumulators are staged (they hold
+                // 128 of the 256 registers: NPQ rows only, the rest once they are in LDS).  A later phase's loads sit behind the
+                // previous phase's stores, so their wait covers one round of store acknowledgements: one per tile with a residual OR
+                // a mask, three with both, none without.
+                constexpr int NP = (RES && MSK) ? NIT / 4 : NIT / 2, NPQ = NP < 4 ? NP : 4;
+                float4 pr[RES ? NP : 1], pm[MSK ? NP : 1];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int q = 0; q < NPQ; ++q) pr[q] = buf_load16(rs_res, row_off(q));
+                } else if constexpr (MSK) {
+#pragma unroll
+                    for (int q = 0; q < NPQ; ++q) pm[q] = buf_load16(rs_msk, row_off(q));
+                }
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) wst[((r & 3) + 8 * (r >> 2) + 4 * h) * SLD + j * 32 + li] = acc[0][j][r];
-                __builtin_amdgcn_wave_barrier();                // (LDS operations of one wave execute in order)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (RES) {
+#pragma unroll
+                    for (int q = NPQ; q < NP; ++q) pr[q] = buf_load16(rs_res, row_off(q));
+                }
+                if constexpr (MSK) {
+#pragma unroll
+                    for (int q = RES ? 0 : NPQ; q < NP; ++q) pm[q] = buf_load16(rs_msk, row_off(q));
+                }
                 float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (cvalid && p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
                 if (cvalid && p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
+                __builtin_amdgcn_wave_barrier();                // (LDS operations of one wave execute in order)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int hf = 0; hf < NPH; ++hf) {
-                    if (hf > 0) prefetch(hf * NPQ);
+                for (int ph = 0; ph < NIT / NP; ++ph) {
+                    if (ph > 0) {
+                        if constexpr (RES) {
 #pragma unroll
-                    for (int q = 0; q < NPQ; ++q) {
-                        const int rr = (hf * NPQ + q) * RPW + rsub;
-                        const int oo = rows_epi[wave * 32 + rr].out_off;
-                        if (oo < 0 || !cvalid) continue;
+                            for (int q = 0; q < NP; ++q) pr[q] = buf_load16(rs_res, row_off(ph * NP + q));
+                        }
+                        if constexpr (MSK) {
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) pm[q] = buf_load16(rs_msk, row_off(ph * NP + q));
+                        }
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < NP; ++qq) {
+                        const int q = ph * NP + qq;
+                        const int rr = q * RPW + rsub;
                         float4 v = *reinterpret_cast<const float4*>(wst + rr * SLD + c4 * 4);
                         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                         if (has_alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
-                        if (res) { const float4 rv = pf[q]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                        if constexpr (RES) { const float4 rv = pr[qq]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
                         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                        if (msk) {
-                            const float4 mv = res ? erd::ld4(msk + oo + co) : pf[q];
-                            v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
-                            v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                        if constexpr (MSK) {
+                            const float4 mv = pm[qq];
+                            v.x = (mv.x > 0.f || no_msk) ? v.x : 0.f; v.y = (mv.y > 0.f || no_msk) ? v.y : 0.f;
+                            v.z = (mv.z > 0.f || no_msk) ? v.z : 0.f; v.w = (mv.w > 0.f || no_msk) ? v.w : 0.f;
                         }
-                        erd::st4(out + oo + co, v);
-                        csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+                        const unsigned o = row_off(q);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, o, 0, 0);
+                        if (o != OOB) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
                     }
                 }
                 if (p.colsum) {      // lanes that share a column group, then the four waves through LDS, one atomic per channel
@@ -1824,7 +1859,7 @@ int num_cus() {
 }
 
 template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false, bool OB = false,
-          bool X3 = false>
+          bool X3 = false, bool RES = false, bool MSK = false>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     constexpr int NT = WM * WN * 64;
     constexpr int BK = (BKT / 4) * (BF ? 8 : 4);
@@ -1842,7 +1877,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     // (f32x3: the row table and the fix-up's broadcast word live inside the operand region -- see the kernel)
     static const size_t lds_pad = getenv("ERD_IG_LDS_PAD") ? (size_t)atoi(getenv("ERD_IG_LDS_PAD")) : 0;   // occupancy experiments
     const size_t lds = (X3 ? oper : (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16) + lds_pad;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB, X3>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB, X3, RES, MSK>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1944,9 +1979,18 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     if (d->w_x3 && d->Cin % 4 == 0 && d->wrow % 2 == 0 && (d->Cout % 4 == 0 || !d->w) && (d->ntaps * d->Cin >= x3_min_k || !d->w)) {
         ERD_REQUIRE(d->Cout % 4 == 0, "conv: the three-limb kernel stores 16-byte rows (Cout %% 4 == 0); pass `w` for Cout=%d", d->Cout);
         // "f32x3": fp32 maps and results, products on the bf16 matrix cores through exact three-limb splits (see the kernel)
-        if (seg_taps_any) return launch_igemm<128, 128, 4, 1, 32, 2, false, true, false, false, true>(d, st);
-        if (d->Cout <= 64) return launch_igemm<128, 64, 4, 1, 32, 2, false, false, false, false, true>(d, st);
-        return launch_igemm<128, 128, 4, 1, 32, 2, false, false, false, false, true>(d, st);
+        // the epilogue is instantiated per (residual, mask) presence: its loads are unconditional and sit in front of its stores
+        bool any_res = false, any_msk = false;
+        for (int s = 0; s < d->nseg; ++s) { any_res |= d->seg[s].res != nullptr; any_msk |= d->seg[s].mask != nullptr; }
+#define ERD_X3_EPI(BN_, ST_)                                                                                                  \
+        (any_res ? (any_msk ? launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, true, true>(d, st)         \
+                            : launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, true, false>(d, st))       \
+                 : (any_msk ? launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, true>(d, st)        \
+                            : launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, false>(d, st)))
+        if (seg_taps_any) return ERD_X3_EPI(128, true);
+        if (d->Cout <= 64) return ERD_X3_EPI(64, false);
+        return ERD_X3_EPI(128, false);
+#undef ERD_X3_EPI
     }
     ERD_REQUIRE(d->w, "conv: this launch needs the fp32 weights (w_x3 serves Cin %% 4 == 0 only)");
     if (seg_taps_any)   // per-segment tap sets (merged parity classes of a stride-2 input gradient): a dedicated instantiation

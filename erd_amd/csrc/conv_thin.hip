@@ -48,7 +48,21 @@ struct TRow {
 
 constexpr int SLD = 36;                    // floats per staged row (32 couts + 4: rows land on different banks)
 
-template <int KS>                          // K / 16: MFMA k-steps of the whole reduction (4: Cin = 64, 8: Cin = 128)
+#ifdef ERD_THIN_TRACE      // phase trace (wave 0 of every workgroup): cycles summed per phase over the workgroup's blocks
+__device__ unsigned long long g_thin_trace[1024 * 8];
+#define THIN_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define THIN_TACC(acc, v) acc += __builtin_amdgcn_s_memtime() - v
+#else
+#define THIN_T0(v)
+#define THIN_TACC(acc, v)
+#endif
+
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, byte_off, 0, 0);
+}
+
+// K / 16: MFMA k-steps of the whole reduction (4: Cin = 64, 8: Cin = 128); 32-row groups per wave; residual / mask rows present
+template <int KS, int RG, bool RES, bool MSK>
 __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_desc p, const int mtiles, const int nb, const int xcd_order) {
     constexpr int K = KS * 16;
     constexpr int CPR = K / 8;                         // 16-byte chunks (8 bf16) per weight row
@@ -56,9 +70,10 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
     constexpr int NQ = UNIT_B / 16 / 256;              // 16-byte loads per thread and block (6 at K = 128, 3 at K = 64)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                                     // [2][UNIT_B]
+    constexpr int TR = 128 * RG;                       // pixel rows of a tile (wave w: rows 32 RG w .. + 32 RG - 1)
     float* stage = reinterpret_cast<float*>(smem + 2 * UNIT_B);            // [4 waves][32][SLD]
-    TRow* rows = reinterpret_cast<TRow*>(smem + 2 * UNIT_B + 4 * 32 * SLD * 4);   // [128]
-    float* red = reinterpret_cast<float*>(rows + 128);                    // [2][4 waves][32]: column sums on their way to one atomic per channel
+    TRow* rows = reinterpret_cast<TRow*>(smem + 2 * UNIT_B + 4 * 32 * SLD * 4);   // [TR]
+    float* red = reinterpret_cast<float*>(rows + TR);                    // [2][4 waves][32]: column sums on their way to one atomic per channel
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int G = gridDim.x;
@@ -85,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
         l_off[q] = ((pl * 32 + row) * CPR + sw) * 16;
     }
     u4v rb[NQ];
-    auto load_unit = [&](long long t) {
-        const unsigned cb_off = (unsigned)((int)(t % nb) * 32 * p.wrow) * 2u;
+    auto load_unit = [&](int cbn) {        // cout block cbn's planes
+        const unsigned cb_off = (unsigned)(cbn * 32 * p.wrow) * 2u;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) rb[q] = buf_load16(rs_w, w_off[q] + cb_off);
     };
@@ -95,29 +110,33 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
         for (int q = 0; q < NQ; ++q) *reinterpret_cast<u4v*>(ring + buf * UNIT_B + l_off[q]) = rb[q];
     };
 
-    u4v ah[KS], am[KS], al[KS];            // the wave's activation rows: limb fragments of every k16 step
+    u4v ah[RG][KS], am[RG][KS], al[RG][KS];    // the wave's activation rows: limb fragments of every k16 step
     int pend_cb = -1;                      // cout block whose column sums wait in `red` for their atomics
     float* const cs_row = p.colsum ? p.colsum + (p.colsum_copies > 1 ? (int64_t)(blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) : nullptr;
-    const float alpha_dummy = 1.f;
 
-    load_unit(t_begin);
+#ifdef ERD_THIN_TRACE
+    unsigned long long t_tile = 0, t_ring = 0, t_pre = 0, t_mma = 0, t_stage = 0, t_out = 0;
+    const unsigned long long t_begin_clk = __builtin_amdgcn_s_memtime();
+#endif
+    load_unit((int)(t_begin % nb));
     int it = 0;                            // blocks done by this workgroup: parity of the LDS ring / of `red`
 #pragma unroll 1
     for (int mt = (int)(t_begin / nb); (long long)mt * nb < t_end; ++mt) {
         // ---- a pixel tile: row table, then this wave's activation rows -> limb fragments ------------------------------------
         int seg_i = 0, mt_in_seg = mt;
         {
+            THIN_T0(tt);
 #pragma unroll 1
             for (; seg_i < p.nseg - 1; ++seg_i) {
                 const int M = p.seg[seg_i].N * p.seg[seg_i].GH * p.seg[seg_i].GW;
-                const int tiles = (M + 127) / 128;
+                const int tiles = (M + TR - 1) / TR;
                 if (mt_in_seg < tiles) break;
                 mt_in_seg -= tiles;
             }
             const erd_conv_seg& sg = p.seg[seg_i];
             __syncthreads();               // the previous tile's epilogues are done with the row table
-            if (tid < 128) {
-                const int GHW = sg.GH * sg.GW, M = sg.N * GHW, m = mt_in_seg * 128 + tid;
+            if (tid < TR) {
+                const int GHW = sg.GH * sg.GW, M = sg.N * GHW, m = mt_in_seg * TR + tid;
                 TRow ri;
                 ri.in_off = -1;
                 ri.out_off = -1;
@@ -133,36 +152,53 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
             __syncthreads();
             const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
                 erd::uniform_ptr(const_cast<float*>(sg.in)), 0, erd::uniform_int((int)((long long)sg.N * sg.in_nstride * 4)), 0x00020000);
-            const int ibase = rows[wave * 32 + li].in_off;
             // lane (li, h) holds channels 16 s + 8 h .. + 7 of pixel row li for every step s: two 16-byte loads per step
-            u4v xa[KS], xb[KS];
+            u4v xa[RG][KS], xb[RG][KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const unsigned o = ibase < 0 ? OOB : (unsigned)(ibase + 16 * s + 8 * h) * 4u;
-                xa[s] = buf_load16(rs_in, o);
-                xb[s] = buf_load16(rs_in, ibase < 0 ? OOB : o + 16u);
+            for (int g = 0; g < RG; ++g) {
+                const int ibase = rows[(wave * RG + g) * 32 + li].in_off;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const unsigned o = ibase < 0 ? OOB : (unsigned)(ibase + 16 * s + 8 * h) * 4u;
+                    xa[g][s] = buf_load16(rs_in, o);
+                    xb[g][s] = buf_load16(rs_in, ibase < 0 ? OOB : o + 16u);
+                }
             }
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {      // value pair e of the step: words (2 e, 2 e + 1) of the eight fp32 values
-                    const u4v& x = e < 2 ? xa[s] : xb[s];
+                    const u4v& x = e < 2 ? xa[g][s] : xb[g][s];
                     unsigned hi, mid, lo;
                     erd::limbs3_pair(__uint_as_float(x[(e & 1) * 2]), __uint_as_float(x[(e & 1) * 2 + 1]), hi, mid, lo);
-                    ah[s][e] = hi; am[s][e] = mid; al[s][e] = lo;
+                    ah[g][s][e] = hi; am[g][s][e] = mid; al[g][s][e] = lo;
                 }
             }
+            THIN_TACC(t_tile, tt);
         }
         const erd_conv_seg& sg = p.seg[seg_i];
+        // the segment's output-side maps as buffers: rows past the end carry the offset OOB -- their loads return zeros, their stores
+        // are dropped, and the block's body below is straight-line code (see the note on s_waitcnt at the stores)
+        const int out_bytes = erd::uniform_int((int)((long long)sg.N * sg.out_nstride * 4));
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(erd::uniform_ptr(sg.out), 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(erd::uniform_ptr(const_cast<float*>(RES ? sg.res : sg.out)), 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(erd::uniform_ptr(const_cast<float*>(MSK ? sg.mask : sg.out)), 0, out_bytes, 0x00020000);
+        const bool has_alpha = sg.alpha != nullptr;
+        const float alpha = has_alpha ? *sg.alpha : 1.f;      // (read once per tile: a load inside the block would order itself behind the block's stores)
         const long long tile_t0 = (long long)mt * nb;
         const int cb_begin = (int)(t_begin > tile_t0 ? t_begin - tile_t0 : 0), cb_end = (int)(t_end < tile_t0 + nb ? t_end - tile_t0 : nb);
 #pragma unroll 1
         for (int cb = cb_begin; cb < cb_end; ++cb, ++it) {
         const long long t = tile_t0 + cb;
         const int buf = it & 1;
+        THIN_T0(tr);
         store_unit(buf);                   // this block's planes: registers -> LDS (the buffer was last read two blocks ago)
-        if (t + 1 < t_end) load_unit(t + 1);
+        if (t + 1 < t_end) load_unit(cb + 1 == nb ? 0 : cb + 1);       // (tile-major order: the next unit is the next block, or block 0 of the next tile)
         __syncthreads();
+        THIN_TACC(t_ring, tr);
+        THIN_T0(tp);
         // ---- column sums of the PREVIOUS block: four waves' partial rows -> one atomic per channel ------------------------
         if (pend_cb >= 0 && tid < 32) {
             const float* rp = red + ((it - 1) & 1) * 128;
@@ -171,24 +207,28 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
         // ---- residual / mask rows of this block are requested before its MFMAs ---------------------------------------------
         const int c4 = lane & 7, rsub = lane >> 3;
         const int co = cb * 32 + c4 * 4;
-        const float* res = sg.res;
-        const float* msk = sg.mask;
-        const float* pf_src = res ? res : msk;
-        int oo[4];
-        float4 pf[4];
+        unsigned off[RG][4];
+        u4v pfr[RG][4], pfm[RG][4];
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            oo[q] = rows[wave * 32 + q * 8 + rsub].out_off;
-            if (pf_src && oo[q] >= 0) pf[q] = *reinterpret_cast<const float4*>(pf_src + oo[q] + co);
+            const int o = rows[(wave * RG + g) * 32 + q * 8 + rsub].out_off;
+            off[g][q] = o < 0 ? OOB : (unsigned)(o + co) * 4u;
+            if constexpr (RES) pfr[g][q] = buf_load16(rs_res, off[g][q]);
+            if constexpr (MSK) pfm[g][q] = buf_load16(rs_msk, off[g][q]);
         }
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
         if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
-        const float alpha = *(sg.alpha ? sg.alpha : &alpha_dummy);
-        // ---- the block's products: 6 MFMAs per k16 step, the stream-K kernel's order -----------------------------------------
-        f32x16 acc;
+        // ---- the block's products: 6 MFMAs per k16 step and row group, the stream-K kernel's order -----------------------------
+        f32x16 acc[RG];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        THIN_TACC(t_pre, tp);
+        THIN_T0(tm);
         const char* Bb = ring + buf * UNIT_B;
         // (weight fragments are read ONE step ahead by hand and the schedule is pinned per step: left alone the compiler hoists
         //  every step's LDS reads to the top of the block -- 96 more live registers -- and spills the limb fragments)
@@ -203,52 +243,68 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) read_w(s + 1, (s + 1) & 1);
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[s]), a1 = __builtin_bit_cast(bf16x8, am[s]), a2 = __builtin_bit_cast(bf16x8, al[s]);
             const bf16x8 w0 = wf[s & 1][0], w1 = wf[s & 1][1], w2 = wf[s & 1][2];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[g][s]), a1 = __builtin_bit_cast(bf16x8, am[g][s]), a2 = __builtin_bit_cast(bf16x8, al[g][s]);
 #ifdef ERD_THIN_NOMFMA     // timing probe: everything but the matrix instructions (results are wrong)
-            acc[0] += __builtin_bit_cast(float4, a0).x * __builtin_bit_cast(float4, w2).x + __builtin_bit_cast(float4, a1).x * __builtin_bit_cast(float4, w1).x +
-                      __builtin_bit_cast(float4, a2).x * __builtin_bit_cast(float4, w0).x;
+                acc[g][0] += __builtin_bit_cast(float4, a0).x * __builtin_bit_cast(float4, w2).x + __builtin_bit_cast(float4, a1).x * __builtin_bit_cast(float4, w1).x +
+                             __builtin_bit_cast(float4, a2).x * __builtin_bit_cast(float4, w0).x;
 #else
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc, 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc[g], 0, 0, 0);
 #endif
 #ifdef ERD_X3_NINE        // accuracy probe, as in conv_igemm_kernel: the three dropped limb products
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w2, acc, 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w2, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w1, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w2, acc[g], 0, 0, 0);
 #endif
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+        THIN_TACC(t_mma, tm);
         // ---- epilogue of the block, wave-private: accumulators -> LDS -> 128-byte row segments ------------------------------
         float* wst = stage + wave * 32 * SLD;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) wst[((r & 3) + 8 * (r >> 2) + 4 * h) * SLD + li] = acc[r];
-        __builtin_amdgcn_wave_barrier();               // (LDS operations of one wave execute in order)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (oo[q] < 0) continue;
-            float4 v = *reinterpret_cast<const float4*>(wst + (q * 8 + rsub) * SLD + c4 * 4);
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            if (sg.alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
-            if (res) { const float4 rv = pf[q]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (msk) {
-                const float4 mv = res ? *reinterpret_cast<const float4*>(msk + oo[q] + co) : pf[q];
-                v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
-                v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
-            }
+        for (int g = 0; g < RG; ++g) {
+            THIN_T0(tg);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wst[((r & 3) + 8 * (r >> 2) + 4 * h) * SLD + li] = acc[g][r];
+            __builtin_amdgcn_wave_barrier();               // (LDS operations of one wave execute in order)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            THIN_TACC(t_stage, tg);
+            THIN_T0(to);
+            // (straight-line on purpose: gfx950 counts loads AND stores in vmcnt, in order.  With the stores under `if (row valid)`
+            //  and the residual / mask / alpha loads under branches the compiler had to put `s_waitcnt vmcnt(0)` in front of every
+            //  one of the four stores and in front of the next block's ring store -- each store waited for the previous one's
+            //  acknowledgement, 2.6-2.9 k of a block's 7.4 k cycles in the phase trace.  Now: every load of the block before its
+            //  first store, the stores back to back, and the next block's ring wait leaves them in flight.)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = *reinterpret_cast<const float4*>(wst + (q * 8 + rsub) * SLD + c4 * 4);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (has_alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
+                if constexpr (RES) { const float4 rv = __builtin_bit_cast(float4, pfr[g][q]); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if constexpr (MSK) {
+                    const float4 mv = __builtin_bit_cast(float4, pfm[g][q]);
+                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                    v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                }
 #ifdef ERD_THIN_NOSTORE    // timing probe: nothing is written (results are wrong)
-            asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 #else
-            *reinterpret_cast<float4*>(sg.out + oo[q] + co) = v;
+                buf_store16(rs_out, off[g][q], v);
 #endif
-            csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+                if (off[g][q] != OOB) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+            }
+            __builtin_amdgcn_wave_barrier();               // the staging block is re-used by the next accumulators
+            THIN_TACC(t_out, to);
         }
         if (cs_row) {      // lanes that share a column group (lane bits 3..5), then the wave's row of `red`
 #pragma unroll
@@ -259,9 +315,15 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
             if (lane < 8) *reinterpret_cast<float4*>(red + (it & 1) * 128 + wave * 32 + lane * 4) = csum;
             pend_cb = cb;
         }
-        __builtin_amdgcn_wave_barrier();               // the staging block is re-used by the next block's accumulators
         }
     }
+#ifdef ERD_THIN_TRACE
+    if (tid == 0 && blockIdx.x < 1024) {
+        unsigned long long* tr = g_thin_trace + blockIdx.x * 8;
+        tr[0] = __builtin_amdgcn_s_memtime() - t_begin_clk; tr[1] = t_tile; tr[2] = t_ring; tr[3] = t_pre; tr[4] = t_mma; tr[5] = t_stage; tr[6] = t_out;
+        tr[7] = (unsigned long long)it;
+    }
+#endif
     if (pend_cb >= 0) {
         __syncthreads();
         if (tid < 32) {
@@ -282,15 +344,15 @@ int num_cus_thin() {
     return n;
 }
 
-template <int KS>
+template <int KS, int RG, bool RES, bool MSK>
 int launch_thin(const erd_conv_desc* d, hipStream_t st) {
-    constexpr int K = KS * 16;
+    constexpr int K = KS * 16, TR = 128 * RG;
     int mtiles = 0;
-    for (int s = 0; s < d->nseg; ++s) mtiles += (int)(((int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW + 127) / 128);
+    for (int s = 0; s < d->nseg; ++s) mtiles += (int)(((int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW + TR - 1) / TR);
     const int nb = d->Cout / 32;
     if (mtiles == 0) return 0;
-    const size_t lds = (size_t)2 * (3 * 32 * K * 2) + 4 * 32 * SLD * 4 + 128 * sizeof(TRow) + 2 * 4 * 32 * 4;
-    auto kern = conv_thin_x3_kernel<KS>;
+    const size_t lds = (size_t)2 * (3 * 32 * K * 2) + 4 * 32 * SLD * 4 + TR * sizeof(TRow) + 2 * 4 * 32 * 4;
+    auto kern = conv_thin_x3_kernel<KS, RG, RES, MSK>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -300,7 +362,7 @@ int launch_thin(const erd_conv_desc* d, hipStream_t st) {
     const long long T = (long long)mtiles * nb;
     // two workgroups per CU at K = 128 (226 registers, 68 KB of LDS); three at K = 64 (154 registers, 45 KB).  ERD_THIN_WGS: A/B aid
     static const int wgs_env = getenv("ERD_THIN_WGS") ? atoi(getenv("ERD_THIN_WGS")) : 0;
-    const int per_cu = wgs_env > 0 ? wgs_env : (KS == 4 ? 3 : 2);
+    const int per_cu = wgs_env > 0 ? wgs_env : (KS == 4 && RG == 1 ? 3 : 2);
     const int G = (int)std::min<long long>(T, (long long)per_cu * num_cus_thin());
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, *d, mtiles, nb, xcd ? 1 : 0);
     return erd::check_launch("conv_thin_x3");
@@ -324,15 +386,30 @@ bool conv_thin_x3_ok(const erd_conv_desc* d) {
     const int on = conv_thin_enable(-1);
     if (!on || !d->w_x3 || d->w_bf16 || d->in_bf16 || d->out_bf16 || d->ntaps != 1) return false;
     if (!(d->Cin == 64 || d->Cin == 128) || d->Cout % 32 != 0 || d->wrow % 8 != 0 || d->wk[0] % 8 != 0) return false;
-    for (int s = 0; s < d->nseg; ++s)
-        if (d->seg[s].ntaps > 0) return false;
+    for (int s = 0; s < d->nseg; ++s) {
+        const erd_conv_seg& g = d->seg[s];
+        if (g.ntaps > 0) return false;
+        // the kernel is instantiated per (residual, mask) presence and addresses both through the output's row offsets
+        if ((g.res != nullptr) != (d->seg[0].res != nullptr) || (g.mask != nullptr) != (d->seg[0].mask != nullptr)) return false;
+        if (g.res && g.res_nstride != g.out_nstride) return false;
+        if ((long long)g.N * g.out_nstride * 4 >= 0x7fffffffLL || (long long)g.N * g.in_nstride * 4 >= 0x7fffffffLL) return false;
+    }
     return true;
 }
 
 int conv_thin_x3(const erd_conv_desc* d, hipStream_t st) {
-    return d->Cin == 64 ? launch_thin<4>(d, st) : launch_thin<8>(d, st);
+    const bool r = d->seg[0].res != nullptr, m = d->seg[0].mask != nullptr;
+    if (d->Cin == 64) return r ? (m ? launch_thin<4, 1, true, true>(d, st) : launch_thin<4, 1, true, false>(d, st))
+                               : (m ? launch_thin<4, 1, false, true>(d, st) : launch_thin<4, 1, false, false>(d, st));
+    return r ? (m ? launch_thin<8, 1, true, true>(d, st) : launch_thin<8, 1, true, false>(d, st))
+             : (m ? launch_thin<8, 1, false, true>(d, st) : launch_thin<8, 1, false, false>(d, st));
 }
 
 }  // namespace erd
 
 extern "C" int erd_conv_thin_enable(int on) { return erd::conv_thin_enable(on); }
+#ifdef ERD_THIN_TRACE
+extern "C" int erd_thin_trace(unsigned long long* out) {       // trace builds only
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_thin_trace), sizeof(g_thin_trace));
+}
+#endif

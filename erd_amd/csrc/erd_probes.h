@@ -17,6 +17,7 @@
 //     conv_mfma.hip, conv_thin.hip   ERD_X3_NINE      all nine limb products instead of six
 //   tracing (results unchanged; s_memtime stamps + a device-side trace buffer)
 //     conv_mfma.hip   ERD_IGEMM_TRACE  (erd_igemm_trace)          winograd.hip   ERD_WINO_TRACE  (erd_wino_trace)
+//     conv_thin.hip   ERD_THIN_TRACE   (erd_thin_trace)
 //   tuning parameters (results unchanged; defaults are the shipped values)
 //     ERD_SGB  ERD_W3X3_MINW  ERD_WINO_NCH  ERD_WINO_DATA_PRIO  ERD_WINO_MMA_PRIO  ERD_WX3_RD
 #pragma once
@@ -24,7 +25,7 @@
 #if defined(ERD_X3_NOMFMA) || defined(ERD_X3_NOLOAD) || defined(ERD_X3_NOBREAD) || defined(ERD_X3_NOVALU) || defined(ERD_X3_NOSYNC) || \
     defined(ERD_IG_NOMFMA) || defined(ERD_IG_NOLOAD) || defined(ERD_IG_NOFRAG) || defined(ERD_IG_NOSYNC) || defined(ERD_WX3_NOMFMA) ||    \
     defined(ERD_WX3_NOSPLIT) || defined(ERD_WX3_NOLOAD) || defined(ERD_WX3_VREAD1) || defined(ERD_WX3_VWRITE1) || defined(ERD_THIN_NOSTORE) || defined(ERD_WG3_NOSLAB) || defined(ERD_THIN_NOMFMA) || defined(ERD_WX3_NORAW) || defined(ERD_WINO_GNPROBE) || defined(ERD_GN_NOSTATS) || defined(ERD_X3_NINE) || \
-    defined(ERD_IGEMM_TRACE) || defined(ERD_WINO_TRACE)
+    defined(ERD_IGEMM_TRACE) || defined(ERD_WINO_TRACE) || defined(ERD_THIN_TRACE)
 #define ERD_PROBE_BUILD 1
 extern "C" __attribute__((weak, visibility("default"))) int erd_probe_build_marker = 1;
 #endif

@@ -1505,6 +1505,17 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
         const int w1 = ri == 0 ? 3 : ri == 1 ? 5 : ri == 2 ? 4 : -1;
         const int rA = ri == 0 ? 0 : ri == 1 ? 3 : ri == 2 ? 0 : 5;
         const int rB = ri == 0 ? 1 : ri == 1 ? 4 : ri == 2 ? 2 : 4;
+        // residual / mask values of BOTH rounds are requested before the first round's stores: gfx950 retires loads and stores through one
+        // in-order counter (vmcnt), so a load issued behind a store cannot be waited for without waiting for that store's
+        // acknowledgement too -- the per-channel-group "load, wait, store" order of rounds 1-4 serialized eight acknowledgements per
+        // item (the masked input-gradient launches ran 1.2-1.7x their forward twins).  Pixels outside the map carry the offset OOBV.
+        const int map_bytes = (int)((long long)sg.N * sg.out_nstride * 4);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.res ? sg.res : sg.out), 0, sg.res ? map_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.mask ? sg.mask : sg.out), 0, sg.mask ? map_bytes : 0, 0x00020000);
+        float4 pr[2][4], pm[2][4];
+        auto out_off = [&](int b, int gq) -> unsigned {
+            return pix_ok ? (unsigned)((opix + cur.cout0 + 32 * (2 * cp + b) + 8 * gq + 4 * h) * 4) : OOBV;
+        };
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             // z[c] = (M A)[row][c] of cout block b: the accumulators die here
@@ -1535,6 +1546,15 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
             else if (ri == 1) yv = (sa + z1) + sb;       // sa = z0[1], own = z1[1], sb = z2[1]
             else if (ri == 2) yv = (sa - z0) - sb;       // sa = z1[0], own = z2[0], sb = z3[0]
             else yv = (sa - sb) - z1;                    // sa = z1[1], sb = z2[1], own = z3[1]
+            if (!simple && b == 0) {                     // (here, not earlier: until now the accumulators of both rounds were live)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        if (sg.res) pr[bb][gq] = buf_load16_s(rs_res, out_off(bb, gq), 0);
+                        if (sg.mask) pm[bb][gq] = buf_load16_s(rs_msk, out_off(bb, gq), 0);
+                    }
+            }
             float4 cs[4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {                          // registers 4 gq .. 4 gq + 3: couts 8 gq + 4 h + {0..3} of the block
@@ -1550,17 +1570,18 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
                     o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
                     o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix_ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
-                } else if (pix_ok) {
-                    const int64_t o = opix + co0;
-                    if (sg.res) v = f4add(v, *reinterpret_cast<const float4*>(sg.res + o));
+                } else {
+                    if (sg.res) v = f4add(v, pr[b][gq]);
                     if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                     if (sg.mask) {
-                        const float4 mk = *reinterpret_cast<const float4*>(sg.mask + o);
+                        const float4 mk = pm[b][gq];
                         v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
                                         mk.w > 0.f ? v.w : 0.f);
                     }
-                    *reinterpret_cast<float4*>(sg.out + o) = v;
-                    cs[gq] = v;
+                    u32x4 o;
+                    o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, out_off(b, gq), 0, 0);
+                    if (pix_ok) cs[gq] = v;
                 }
             }
             if (p.colsum) {
