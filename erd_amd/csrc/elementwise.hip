@@ -50,7 +50,12 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const float* __restrict__ 
     constexpr int PATCH = 3 * ST_PH * ST_PWP, NLOAD = (3 * ST_PH * ST_PW + 255) / 256;
     __shared__ float wl[ST_K * WLD];           // [(kh,kw,c)][co], row 147 = 0
     __shared__ float patch[2][PATCH];
+    // scale / shift in LDS: as global loads inside the store loop each of them sat between two stores, and gfx950 retires loads and
+    // stores through one in-order counter -- every store waited for the previous one's acknowledgement (EXPERIMENTS 7f); registers
+    // do not hold them either (the kernel sits at 256)
+    __shared__ __attribute__((aligned(16))) float ssl[128];
     const int tid = threadIdx.x;
+    if (tid < 128) ssl[tid] = tid < 64 ? scale[tid] : shift[tid - 64];
     // weights arrive as [co][kh][kw][c] (OHWI); LDS wants [(kh,kw,c)][co].  Loaded ONCE: the grid is persistent.
     for (int i = tid; i < 147 * 64; i += 256) {
         const int co = i / 147, k = i - co * 147;
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ch = cb * 32 + 8 * g;
-                    const float4 sc = *reinterpret_cast<const float4*>(scale + ch + 4 * h);
-                    const float4 sh = *reinterpret_cast<const float4*>(shift + ch + 4 * h);
+                    const float4 sc = *reinterpret_cast<const float4*>(ssl + ch + 4 * h);
+                    const float4 sh = *reinterpret_cast<const float4*>(ssl + 64 + ch + 4 * h);
                     float4 v;
                     v.x = fmaxf(acc[cb][pr][4 * g + 0] * sc.x + sh.x, 0.f);
                     v.y = fmaxf(acc[cb][pr][4 * g + 1] * sc.y + sh.y, 0.f);

@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
         *reinterpret_cast<uint2*>(dst + 1024) = mid;
         *reinterpret_cast<uint2*>(dst + 2048) = lo;
     };
-    // D phase: raw(g+1) -> V(g+1) (this thread's row of four positions), raw(g+2) regs -> LDS over raw(g), request raw(g+3)
+    // D phase: raw(g+1) -> V(g+1) (this thread's row of four positions), raw(g+2) regs -> LDS over raw(g), request raw(g+3) (last)
     // row pass of B^T d B for this wave's transform row (uniform branch: a packed add or a packed subtract, no sign operand)
     auto row_pass = [&](float4 (&R)[4]) __attribute__((always_inline)) {
         if (t_row == 1) {
@@ -1420,7 +1420,6 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
         transform_read(npar);
         __builtin_amdgcn_sched_barrier(0);
         store_raw(rv, par);
-        issue_next(rv);
 #ifdef ERD_WINO_TRACE
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -1448,6 +1447,10 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
         __builtin_amdgcn_sched_barrier(0);
         load_u(2, u_tail);
         load_u(3, u_tail);
+        // raw(g+3) is requested BEHIND the ring's fragments: loads retire in issue order, so the next matrix phase's wait for slot 2
+        // would otherwise also wait for these HBM reads, which nobody needs before the next data phase (fpn P3 262 -> 251 us,
+        // head towers 324 -> 322, bit-identical: profiles/r05_thin_forms.txt section 6)
+        issue_next(rv);
         ERD_TACC(t_d3, tc3);
     };
     // M phase: this wave's four positions x two cout blocks of slice g; the ring slot of unit u is re-loaded with unit u + 4 of

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_under_torchrun_world1_matches_plain_run():
     env = dict(os.environ, ERD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "1", "--no-cpu-baseline", "--no-kernel-timing"]
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-strict-fp32"]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py")] + common,
                        capture_output=True, text=True, env=env, timeout=600)
@@ -36,7 +36,7 @@ def test_bench_starts_its_own_ranks():
     JSON line, which says who launched the ranks and that the RCCL process group was up."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launcher", "spawn", "--steps", "2", "--warmup", "1",
-                        "--batch", "1", "--no-cpu-baseline", "--no-kernel-timing"], capture_output=True, text=True, env=env, timeout=600)
+                        "--batch", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-strict-fp32"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
@@ -44,5 +44,5 @@ def test_bench_starts_its_own_ranks():
     assert d["collectives"]["launched_by"].startswith("bench.py self_launch")
     # a failing child is a failing parent (exit status relayed)
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launcher", "spawn", "--steps", "1", "--warmup", "0",
-                          "--batch", "0", "--no-cpu-baseline", "--no-kernel-timing"], capture_output=True, text=True, env=env, timeout=600)
+                          "--batch", "0", "--no-cpu-baseline", "--no-kernel-timing", "--no-strict-fp32"], capture_output=True, text=True, env=env, timeout=600)
     assert bad.returncode != 0

@@ -38,7 +38,7 @@ def test_ers_index_sets_over_full_size_images(nets):
     from erd_amd import kernels as K
     tsd, ssd, model = nets
     model.eval()
-    nimg, bs = (32 if FULL else 16), 4          # (the oracle's teacher pass on the host is 2.5 s per image)
+    nimg, bs = (32 if FULL else 12), 4          # (the oracle's teacher pass on the host is 2.5 s per image)
     # teacher on Winograd (True) / direct (False) kernels, in the default fp32 form ("f32x3": direct launches on the bf16 matrix
     # cores through exact three-limb splits) and with the direct launches on the native fp32 MFMA ("f32"):
     # [images with a differing set, differing anchors]

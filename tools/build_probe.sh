@@ -7,7 +7,7 @@ mkdir -p ../lib/abl
 n=$1; f=$2; shift 2
 base=${PROBE_BASE:-$(basename $f .hip)}
 extra=""
-case $base in losses|leaf_ops|predict) extra="-ffp-contract=off";; conv_mfma|conv_thin|winograd) extra="-fno-slp-vectorize";; esac      # (the Makefile's per-file flags)
+case $base in losses|leaf_ops|predict) extra="-ffp-contract=off";; conv_thin|winograd) extra="-fno-slp-vectorize";; esac      # (the Makefile's per-file flags)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f -o /tmp/${base}_probe_$n.o
 objs=""
 for o in conv_mfma conv_thin elementwise losses predict winograd leaf_ops prep; do

@@ -84,6 +84,12 @@ case("wino128 128->128 100x168", 4, 128, 128, [(100, 168)], 3)
 case("wino128 256->256 levels", 2, 256, 256, [(25, 42), (13, 21), (7, 11)], 3, time_it=False)
 os.environ["ERD_WINO_P"] = "0"
 case("wino64 256->256 50x84", 4, 256, 256, [(50, 84)], 3)
+# the 7x7 / 2 stem (conv + folded BN + ReLU)
+xs_ = torch.randn(4, 3, 800, 1344, device="cuda"); ws_ = torch.randn(64, 7, 7, 3, device="cuda") * 0.1
+scs, shs = 0.5 + torch.rand(64, device="cuda"), 0.1 * torch.randn(64, device="cuda")
+ys_ = K.stem(xs_, ws_, scs, shs); torch.cuda.synchronize()
+out["stem 4x800x1344"] = {"fwd": [ys_.cpu()]}
+times["stem 4x800x1344/fwd"] = timeit(lambda: K.stem(xs_, ws_, scs, shs))
 torch.save(out, sys.argv[1])
 for k_, v in times.items(): print(f"  {k_:46s} {v:8.1f} us")
 if len(sys.argv) > 2:
