@@ -1942,8 +1942,9 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
         ERD_REQUIRE(g.in && g.out, "conv: null tensor in segment %d", s);
         ERD_REQUIRE(g.ntaps >= 0 && g.tap0 >= 0 && g.tap0 + g.ntaps <= ERD_MAX_TAPS && g.ntaps <= d->ntaps,
                     "conv: segment %d tap set [%d, %d) (launch ntaps %d)", s, g.tap0, g.tap0 + g.ntaps, d->ntaps);
-        ERD_REQUIRE((int64_t)g.N * g.in_nstride < (1ll << 29) && (int64_t)g.N * g.out_nstride < (1ll << 31),
-                    "conv: segment %d too large (input must stay below 2 GiB: 32-bit buffer byte offsets)", s);
+        // (the three-limb kernels also STORE through 32-bit buffer byte offsets: their output maps must stay below 2 GiB as well)
+        ERD_REQUIRE((int64_t)g.N * g.in_nstride < (1ll << 29) && (int64_t)g.N * g.out_nstride < (d->w_x3 ? (1ll << 29) : (1ll << 31)),
+                    "conv: segment %d too large (input%s must stay below 2 GiB: 32-bit buffer byte offsets)", s, d->w_x3 ? " and output" : "");
     }
     hipStream_t st = (hipStream_t)stream;
     // Variant choice (measured, tools/bench_conv.py): long K loops are MFMA-bound and want the BK=32 / stream-K

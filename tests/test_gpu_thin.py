@@ -127,3 +127,23 @@ def test_thin_several_levels_in_one_launch(K):
     assert torch.equal(a, b)
     ref = (x.double() @ w.double().view(Cout, Cin).t())
     assert float((a.cpu().double() - ref).norm() / ref.norm()) < 3e-7
+
+
+@pytest.mark.parametrize("Cin", [128, 256])      # 128: thin-K shapes (mixed presence falls back to the stream-K kernel), 256: the stream-K kernel
+def test_segments_with_and_without_a_residual_in_one_launch(K, Cin):
+    """The three-limb epilogues are instantiated per (residual, mask) presence of the LAUNCH and request those rows unconditionally
+    (round 5: every load of a tile in front of its first store).  A launch whose segments differ -- one level with a residual, one
+    without -- gives the segment without it an empty buffer: zeros are added.  Each segment must equal its own single-segment launch."""
+    sizes = [(20, 28), (9, 13)]
+    N, Cout = 2, 160
+    xs = [G.randn(31 + i, N, h, w, Cin).cuda() for i, (h, w) in enumerate(sizes)]
+    wg = G.randn(33, Cout, 1, 1, Cin, scale=(2.0 / Cin) ** 0.5).cuda()
+    sc, sh = (0.5 + G.rand(34, Cout)).cuda(), G.randn(35, Cout, scale=0.1).cuda()
+    r0 = G.randn(36, N, *sizes[0], Cout).cuda()
+    outs = [torch.full((N, h, w, Cout), float("nan"), device="cuda") for h, w in sizes]
+    K.conv_forward(xs, wg, outs, 1, 1, 0, scale=sc, shift=sh, res=[r0, None], relu=True)
+    one = [torch.empty_like(o) for o in outs]
+    K.conv_forward(xs[:1], wg, one[:1], 1, 1, 0, scale=sc, shift=sh, res=[r0], relu=True)
+    K.conv_forward(xs[1:], wg, one[1:], 1, 1, 0, scale=sc, shift=sh, relu=True)
+    for a, b in zip(outs, one):
+        assert not bool(torch.isnan(a).any()) and torch.equal(a, b)
