@@ -3,7 +3,7 @@ Two processes, both on cuda:0, process group `gloo` (ERD_DIST_BACKEND: RCCL refu
 are staged through host memory by erd_amd/dist_utils.py -- a correctness vehicle, not a performance path).  Each rank runs
 `ERDTrainer` with every default on (three gradient-producing streams joined per bucket, teacher look-ahead, deferred update,
 fused C2 + C3 all-reduce inside the loss, 1/world folded into the SGD kernel) on ITS OWN two images of 800x1344 for three
-steps.  Checked against the oracle's two-rank evaluation of the reference's data-parallel semantics:
+steps (default run: one image per rank at the full size, two steps).  Checked against the oracle's two-rank evaluation of the reference's data-parallel semantics:
   * C2 / C3: what the loss hands to `reduce_mean` and what comes back are the reference's two rank means
     (gfl_head_increment_erd.py:390-391, 406-407; dist_utils.py:59-65), the second one clamped to >= 1 after the mean;
   * the all-reduced gradient of step 0 is the mean of the two ranks' oracle gradients (D9: each rank's distillation terms are
@@ -29,30 +29,54 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("H,W,bucket_mb", [(800, 1333, 32), (224, 288, 4)])
-def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path, H, W, bucket_mb):
-    from e2e_util import f7_state_dicts
-    from oracle import erd_oracle as O
+def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path):
+    """Two cases in ONE pair of rank processes (a rank's start is 15-40 s of box time): 224 x 288 with 4 MB buckets (three steps), then
+    the full size with the default 32 MB buckets (two steps; ERD_TEST_FULL=1: three -- the second step already runs on weights both
+    ranks updated from the summed gradient, and the oracle's two-rank trajectory on the host is the test's time)."""
     import world2_worker as Wk
-    # (three steps; the full-size case two in the default run -- ERD_TEST_FULL=1: three -- the second step already runs on weights both
-    #  ranks updated from the summed gradient, and the oracle's two-rank trajectory on the host is the test's time)
-    WORLD, STEPS = 2, (3 if (H < 800 or os.environ.get("ERD_TEST_FULL", "0") == "1") else 2)
+    WORLD = 2
+    FULL = os.environ.get("ERD_TEST_FULL", "0") == "1"
+    # (height, width, steps, bucket MB, images per rank): the full-size case with ONE image per rank in the default run (two with
+    #  ERD_TEST_FULL=1) -- the oracle's two-rank trajectory on the host is 8 s per image and pass
+    cases = [(224, 288, 3, 4, 2), (800, 1333, 3 if FULL else 2, 32, 2 if FULL else 1)]
     port = str(_free_port())
-    env = dict(os.environ, ERD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD2_BUCKET_MB=str(bucket_mb))
+    env = dict(os.environ, ERD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "world2_worker.py"), str(r), str(WORLD), port, str(tmp_path),
-                               str(H), str(W), str(STEPS)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "world2_worker.py"), str(r), str(WORLD), port, str(tmp_path)]
+                              + ["%d,%d,%d,%d,%d" % c for c in cases], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(WORLD)]
+    # ---- meanwhile, on the host: the oracle's two-rank trajectories ------------------------------------------------------------------
+    # (the two cases side by side on the host's cores: torch's CPU operators release the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))        # (oneDNN oversubscribes on a 128-core host: bench.py's thread sweep)
+    try:
+        with ThreadPoolExecutor(len(cases)) as pool:
+            refs = list(pool.map(lambda c: _oracle_two_rank_trajectory(Wk, WORLD, c[0], c[1], c[2], c[4]), cases))
+    finally:
+        torch.set_num_threads(threads)
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=1200)
+        outs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])
+    for i, ((H, W, STEPS, bucket_mb, _), ref) in enumerate(zip(cases, refs)):
+        res = [torch.load(os.path.join(tmp_path, f"case{i}_rank{r}.pt"), weights_only=False) for r in range(WORLD)]
+        _check_case(WORLD, H, W, STEPS, bucket_mb, res, *ref)
+
+
+def _oracle_two_rank_trajectory(Wk, WORLD, H, W, STEPS, BS):
+    from e2e_util import f7_state_dicts
+    from oracle import erd_oracle as O
     # ---- meanwhile, on the host: the oracle's two-rank trajectory ------------------------------------------------------------
     tsd, ssd = f7_state_dicts()
     names = [k for k, v in ssd.items() if O.trainable(k) and v.dtype == torch.float32]
-    batches = [Wk.rank_batches(r, H, W, Wk.BS) for r in range(WORLD)]
-    base_lr = Wk.LR * WORLD * Wk.BS / 16
+    batches = [Wk.rank_batches(r, H, W, BS) for r in range(WORLD)]
+    base_lr = Wk.LR * WORLD * BS / 16
     lrs = [base_lr * (Wk.WARM_START + (1 - Wk.WARM_START) * it / max(Wk.WARM - 1, 1) if it < Wk.WARM else 1.0) for it in range(STEPS)]
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(threads, 32))
-    try:
+    if True:
         sd = {k: v.clone() for k, v in ssd.items()}
         bufs, ref_rows, ref_factors, ref_grad0 = {}, [], [], None
         for it in range(STEPS):
@@ -82,15 +106,10 @@ def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path, H, W, bucket_
                 ref_grad0 = {k: v.clone() for k, v in mean.items()}
             ref_rows.append(rows)
             O.sgd_momentum_step({k: sd[k] for k in names}, mean, bufs, lrs[it], Wk.MOM, Wk.WD)
-    finally:
-        torch.set_num_threads(threads)
-    outs = []
-    for p in procs:
-        out, _ = p.communicate(timeout=1200)
-        outs.append(out)
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])
-    res = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(WORLD)]
+    return ssd, sd, names, lrs, ref_rows, ref_factors, ref_grad0
+
+
+def _check_case(WORLD, H, W, STEPS, bucket_mb, res, ssd, sd, names, lrs, ref_rows, ref_factors, ref_grad0):
     for r, d in enumerate(res):
         assert d["backend"] == "gloo" and d["device"] == 0 and d["late_buckets"] == 0, (r, d["backend"], d["device"], d["late_buckets"], d["missing"][:12], d["repeats"][:12])
         print("rank %d: %d buckets, parameters that reported a gradient more than once in a step (deduplicated by the sync): %s"
