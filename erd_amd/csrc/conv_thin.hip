@@ -17,7 +17,11 @@
 //     mid x hi, lo x hi), so results are bit-identical to it;
 //   * a block's epilogue (accumulators -> the wave's private LDS block -> 128-byte row segments with scale / shift / residual /
 //     ReLU / mask / column sums, 16-byte stores) is issued by the wave right behind the block's MFMAs and drains while the next
-//     block's MFMAs run: no tile-level phases;
+//     block's MFMAs run: no tile-level phases.  The block body is STRAIGHT-LINE (round 5): the residual / mask / scale / shift
+//     loads of a block are requested before its MFMAs, its four stores are unconditional buffer stores issued back to back (rows
+//     past the end carry an out-of-range offset), and the kernel is instantiated per (residual, mask) presence -- gfx950 retires
+//     loads and stores through one in-order counter, and with guarded stores and loads between them every store waited for the
+//     previous one's acknowledgement (35-75 % of a block in the phase trace, -DERD_THIN_TRACE; profiles/r05_thin_forms.txt);
 //   * work = (pixel tile, cout block) pairs in tile-major order, cut into G equal contiguous ranges for a persistent grid of
 //     two workgroups per CU: no ragged round, and no fix-up (an output block is owned by one workgroup).
 // Bytes per 128 rows x N couts: the activation rows once (K x 512 B) + the weight planes once (6 N K B) instead of N / 128
@@ -61,7 +65,8 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned b
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, byte_off, 0, 0);
 }
 
-// K / 16: MFMA k-steps of the whole reduction (4: Cin = 64, 8: Cin = 128); 32-row groups per wave; residual / mask rows present
+// K / 16: MFMA k-steps of the whole reduction (4: Cin = 64, 8: Cin = 128); 32-row groups per wave (1; 2 = 256-row tiles at K = 64,
+// half the weight traffic and barriers per output, measured 8 % SLOWER: two workgroups per CU instead of three); residual / mask rows present
 template <int KS, int RG, bool RES, bool MSK>
 __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_desc p, const int mtiles, const int nb, const int xcd_order) {
     constexpr int K = KS * 16;
