@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("oracle_threads")]      # (32 host threads for the oracle: tests/conftest.py)
 
 import golden_inputs as G
 from e2e_util import build_erd, f7_state_dicts, make_samples

@@ -7,7 +7,7 @@
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("oracle_threads")]      # (32 host threads for the oracle: tests/conftest.py)
 
 from e2e_util import build_erd, f7_state_dicts
 

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("oracle_threads")]      # (32 host threads for the oracle: tests/conftest.py)
 
 from e2e_util import build_erd, f7_state_dicts, make_samples
 from oracle import erd_oracle as O
@@ -181,15 +181,10 @@ def test_full_size_gradients_anchored_to_fp64(nets):
             O.parse_losses(losses).backward()
             return {k: sd[k].grad.double() for k in names}, {k: [float(v) for v in vs] for k, vs in losses.items()}
 
-        # the host evaluations (8 s in fp64, 4 s in fp32 per seed) two at a time on the host's cores, ahead of the GPU's: torch's CPU
-        # operators release the GIL, and an evaluation's result does not depend on what runs beside it (32 threads each)
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(2)
-        futs = {(seed, dt): pool.submit(oracle, seed, dt) for seed in SEEDS_FP64 for dt in (torch.float64, torch.float32)}
         for seed in SEEDS_FP64:
             x, boxes, labels, metas = sample(seed)
-            g64, l64 = futs.pop((seed, torch.float64)).result()
-            g32, l32 = futs.pop((seed, torch.float32)).result()
+            g64, l64 = oracle(seed, torch.float64)
+            g32, l32 = oracle(seed, torch.float32)
             cpu = dist(g32, g64)
             cpu_rows.append(cpu)
             for mode in MODES:
@@ -210,7 +205,6 @@ def test_full_size_gradients_anchored_to_fp64(nets):
                 print("seed %d, %d gradient tensors, rel L2 to fp64 (median / all elements / worst tensor): cpu fp32 %.2e %.2e %.2e | hip %s %.2e %.2e %.2e"
                       % ((seed, len(names)) + cpu + (mode,) + hip))
                 del model
-        pool.shutdown()
     finally:
         torch.set_num_threads(threads)
     cpu = np.array(cpu_rows)
