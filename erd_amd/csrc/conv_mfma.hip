@@ -1332,6 +1332,11 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
     const bool is_b = tid >= 128 && tid < 128 + NB && pg < NBG;
     const int col = is_a ? co0 + cg * 4 : ci0 + cg * 4;
     const bool cok = is_a ? (col < p.Cout) : (is_b && col < p.Cin);
+    // a wave loads dz OR x (NA is a multiple of 64): the descriptor is picked on the scalar side -- picked per lane (`is_a ? rs_dz : rs_x`)
+    // the compiler wraps every load of the K loop into a readfirstlane "waterfall" loop of a dozen instructions
+    static_assert(NA % 64 == 0, "staging roles are wave-uniform");
+    const bool a_wave = __builtin_amdgcn_readfirstlane(is_a ? 1 : 0) != 0;
+    const __amdgpu_buffer_rsrc_t rs_mine = a_wave ? rs_dz : rs_x;
     float4 rv[4];
     auto load_global = [&](int slot) {
         if (is_a || is_b) {
@@ -1339,7 +1344,7 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
             for (int i = 0; i < 4; ++i) {
                 const int e = pg * 4 + i;
                 const int o = is_a ? offa[slot * BK + e] : (e < BX ? offb[slot * BX + e] : -1);
-                rv[i] = buf_load16(is_a ? rs_dz : rs_x, (o >= 0 && cok) ? (unsigned)(o + col) * 4u : OOB);
+                rv[i] = buf_load16(rs_mine, (o >= 0 && cok) ? (unsigned)(o + col) * 4u : OOB);
             }
         }
     };
@@ -1387,8 +1392,11 @@ __global__ __launch_bounds__(NTHREADS, ERD_W3X3_MINW) void conv_wgrad_row3_x3_ke
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int buf = (kt - kt_begin) & 1;
             const bool more = kt + 1 < kt_end;
-            if (more) load_global(buf ^ 1);
+            // (the offset table of slice kt + 2 BEFORE the requests of slice kt + 1: at 168 registers its index arithmetic reloads a
+            //  spilled value from scratch, scratch loads retire through the same in-order counter as the global ones, and the
+            //  reload's wait would cover the four requests just issued -- the whole memory latency in front of this slice's MFMAs)
             compute_offsets(kt + 2, buf);
+            if (more) load_global(buf ^ 1);
             const char* Ab = smem + buf * BUF;
             const char* Bb = Ab + 3 * A_PL;
             // fragments: dz rows (wm * FM + i) * 32 + li, chunk h; x row wn * 32 + li, entries 8h .. 8h + 9
