@@ -75,6 +75,7 @@ _SIGNATURES = {
     "erd_to_bf16": [P, P, i64, P],
     "erd_split3": [P, P, i64, P],
     "erd_conv_thin_enable": [i32],
+    "erd_conv_thin_ok": [C.POINTER(ConvDesc)],
     "erd_weight_transpose_x3": [P, P, P, i32, i32, i32, i32, P],
     "erd_wino_weights_elems": [i32, i32],
     "erd_wino_weights": [P, P, i32, i32, i32, P],
@@ -163,7 +164,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t if name.endswith(("_ws_bytes", "_elems")) else C.c_int
-    if lib.erd_abi_version() != 5:
+    if lib.erd_abi_version() != 6:
         raise ErdHipError("liberd_hip.so ABI version mismatch")
     lib.erd_probe_build.restype = C.c_int
     if lib.erd_probe_build() and not os.environ.get("ERD_HIP_LIB"):

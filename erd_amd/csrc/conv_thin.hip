@@ -413,6 +413,7 @@ int conv_thin_x3(const erd_conv_desc* d, hipStream_t st) {
 }  // namespace erd
 
 extern "C" int erd_conv_thin_enable(int on) { return erd::conv_thin_enable(on); }
+extern "C" int erd_conv_thin_ok(const erd_conv_desc* d) { return d && erd::conv_thin_x3_ok(d) ? 1 : 0; }
 #ifdef ERD_THIN_TRACE
 extern "C" int erd_thin_trace(unsigned long long* out) {       // trace builds only
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_thin_trace), sizeof(g_thin_trace));

@@ -443,6 +443,18 @@ class ERDTrainer:
     def flush(self) -> None:
         self._apply_pending()
 
+    def join_streams(self) -> None:
+        """order every stream the trainer launches on (teacher side stream, tower / trailing weight-gradient streams, the update
+        stream) in front of the CURRENT stream: afterwards a wait on the current stream alone covers the whole step (bench.py
+        --occupy-cus cannot use a device-wide wait, which would sit out the foreign spin kernel)"""
+        cur = torch.cuda.current_stream(self.device)
+        streams = [Fn.aux_stream(self.device), Fn.trail_stream(self.device), self.side]
+        if self.sync is not None and getattr(self.sync, "stream", None) is not None:
+            streams.append(self.sync.stream)
+        for st in streams:
+            if st is not None and st != cur:
+                cur.wait_stream(st)
+
     # -- optimizer state in torch.optim.SGD's state_dict layout (what the reference's checkpoints hold) ---------
     def optimizer_state_dict(self) -> dict:
         self.flush()

@@ -394,19 +394,13 @@ def _desc_cache() -> dict:
     return c
 
 
-THIN = _os.environ.get("ERD_THIN", "1") != "0"
-
-
 def _igemm_class(d, form: str) -> str:
     """timing class of an erd_conv_igemm launch = the kernel SYMBOL it runs on (bench.py's roofline rows are per symbol, and must
-    agree with rocprofv3's): three-limb 1x1 launches with Cin in {64, 128} and Cout % 32 == 0 go to conv_thin_x3_kernel
-    (csrc/conv_thin.hip, erd::conv_thin_x3_ok -- the same test; only consulted while timing is on)"""
+    agree with rocprofv3's): the library's own dispatch predicate decides (erd_conv_thin_ok = erd::conv_thin_x3_ok,
+    csrc/conv_thin.hip; only consulted while timing is on)"""
     if _TIMING is None:
         return "conv_igemm_" + form
-    thin = (THIN and d.w_x3 and not d.w_bf16 and not d.in_bf16 and not d.out_bf16 and d.ntaps == 1 and d.Cin in (64, 128) and
-            d.Cout % 32 == 0 and d.wrow % 8 == 0 and d.wk[0] % 8 == 0 and
-            all(d.seg[i].ntaps == 0 for i in range(d.nseg)) and _lib.load().erd_conv_thin_enable(-1))
-    return ("conv_thin_" if thin else "conv_igemm_") + form
+    return ("conv_thin_" if _lib.load().erd_conv_thin_ok(C.byref(d)) else "conv_igemm_") + form
 
 
 def _geom(ts) -> tuple:

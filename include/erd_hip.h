@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ERD_ABI_VERSION 5
+#define ERD_ABI_VERSION 6
 #define ERD_MAX_SEG 5   /* FPN levels batched in one launch */
 #define ERD_MAX_TAPS 9
 
@@ -125,6 +125,10 @@ size_t erd_conv_igemm_ws_bytes(int max_tiles);
  * dispatch for the process (A/B runs and the bit-identity test), on < 0 only queries; returns the previous setting.
  * Default: on (environment ERD_THIN=0: off). */
 int erd_conv_thin_enable(int on);
+/* ABI v6.  1 when erd_conv_igemm would run THIS launch on the activation-stationary kernel (conv_thin_x3_kernel), 0 when on the stream-K
+ * kernel (conv_igemm_kernel): the dispatch predicate itself, for callers that book launches per kernel symbol (bench.py's per-kernel
+ * roofline rows must agree with what a profiler sees). */
+int erd_conv_thin_ok(const erd_conv_desc* d);
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements */
 int erd_to_bf16(const float* src, void* dst, int64_t n, erd_stream_t stream);
 /* the three bf16 limbs of every value, each rounded to nearest even: dst[0][i] + dst[1][i] + dst[2][i] == src[i] exactly; dst = [3][n] bf16

@@ -132,6 +132,50 @@ def test_mixed_resolution_winograd_equals_direct(hw):
                 (i, k, a[k], b[k])
 
 
+def test_teacher_hipgraph_replay_at_the_full_mixed_resolutions():
+    """BASELINE.json configs[4] in one piece: the captured teacher (`engine.TeacherGraphs`, one hipGraph per padded shape) REPLAYED at
+    the three full-size mixed resolutions 800x1216 / 768x1344 / 704x1088 on new pixels each time -- teacher logits, ERS counts, index lists
+    and NMS masks bit-identical to the eager teacher pass, and on one of the shapes the ERS index sets of the replay equal the CPU
+    oracle's (the small-size twin of this test is tests/test_gpu_e2e.py::test_teacher_hipgraph_replay_equals_eager_on_mixed_resolutions)."""
+    from erd_amd.engine import TeacherGraphs
+    from oracle import erd_oracle as O
+    tsd, ssd = f7_state_dicts()
+    model = build_erd(tsd, ssd).eval()
+    tg = TeacherGraphs(model)
+    side = torch.cuda.Stream()
+    g = torch.Generator().manual_seed(61)
+    shapes = [(800, 1216), (768, 1344), (704, 1088)]
+    for rep in range(2):            # the second visit of a shape is a pure replay of the graph captured on the first
+        for hw in shapes:
+            x = torch.randn((2, 3) + hw, generator=g).cuda()
+            with torch.no_grad():
+                ref = model.teacher_pass(x)
+            want = [t.clone() for t in ref.tensors()]
+            want_idx = {k: ref.ers[k].clone() for k in ("idx_cls", "idx_bbox")}
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got = tg.run(x)
+            torch.cuda.current_stream().wait_stream(side)
+            assert got.sizes == ref.sizes
+            for a, b in zip(got.tensors(), want):
+                if a.dtype == torch.int64 and a.dim() == 2:       # ERS index lists: only the first count entries are defined
+                    continue
+                assert torch.equal(a, b), (rep, hw)
+            cnt = got.ers["counts"].cpu()
+            for n in range(2):
+                for k, name in enumerate(("idx_cls", "idx_bbox")):
+                    assert torch.equal(got.ers[name][n, :int(cnt[n, k])], want_idx[name][n, :int(cnt[n, k])]), (rep, hw, n, name)
+            if rep == 1 and hw == (768, 1344):
+                with torch.no_grad():
+                    rc, rb = O.gfl_forward(tsd, x.cpu())
+                rc, rb = O.flatten_levels(rc), O.flatten_levels(rb)
+                for n in range(2):
+                    ic, ib, _, _ = O.ers_select_single(rc[n], rb[n])
+                    assert torch.equal(got.ers["idx_cls"][n, :int(cnt[n, 0])].cpu(), ic), n
+                    assert torch.equal(got.ers["idx_bbox"][n, :int(cnt[n, 1])].cpu(), ib), n
+    assert len(tg.graphs) == 3
+
+
 def test_full_size_teacher_logits_and_ers_sets_vs_oracle():
     """BASELINE size, one image: the teacher's head outputs against the CPU oracle (1e-3; observed ~1e-5) and the ERS
     index sets bit-exact -- through the Winograd + direct kernels at the real level sizes (100x168 ... 7x11)."""

@@ -117,7 +117,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.erd_abi_version() == 5
+    assert lib.erd_abi_version() == 6
     assert lib.erd_probe_build() == 0          # the shipped library contains no timing / accuracy / trace variant (csrc/erd_probes.h)
     # argument errors come back as codes + message, never as exceptions across the ABI
     assert lib.erd_conv_igemm(None, None) == -1 and b"null" in lib.erd_last_error()

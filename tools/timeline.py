@@ -19,7 +19,10 @@ def short(n):
     return re.sub(r"void ", "", n).split("(")[0][:60]
 
 
-sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
+# step boundary: a kernel that runs exactly ONCE per step (loss_avg_kernel: the cross-image normalisers of the loss; the SGD update
+# runs once per gradient bucket since round 4 and no longer marks a step)
+marker = "loss_avg_kernel" if any("loss_avg_kernel" in r[0] for r in rows) else "sgd_kernel"
+sgd = [i for i, r in enumerate(rows) if marker in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(sgd) // 2
 lo, hi = sgd[k], sgd[k + 1]
 step = rows[lo:hi]
@@ -29,11 +32,14 @@ for i, (n, s, e, wgs, q) in enumerate(step):
     ev.append((s, 1, i)); ev.append((min(e, t1), -1, i))
 ev.sort()
 active, last = set(), t0
-idle = thin = 0
+idle = thin = multi = 0
+busy_sum = sum(min(e, t1) - s for _, s, e, _, _ in step)
 owner = defaultdict(int)
 for t, d, i in ev:
     dt = t - last
     if dt > 0:
+        if len(active) > 1:
+            multi += dt
         if not active:
             idle += dt
         else:
@@ -47,7 +53,16 @@ for t, d, i in ev:
         active.add(i)
     else:
         active.discard(i)
-print(f"step {k}: {len(step)} dispatches, wall {(t1 - t0) / 1e6:.2f} ms, no kernel in flight {idle / 1e6:.2f} ms, "
+print(f"step {k} ({marker} to {marker}): {len(step)} dispatches, wall {(t1 - t0) / 1e6:.2f} ms, sum of kernel durations {busy_sum / 1e6:.2f} ms, "
+      f"two or more kernels in flight {multi / 1e6:.2f} ms, no kernel in flight {idle / 1e6:.2f} ms, "
       f"fewer than {NCU} workgroups in flight {thin / 1e6:.2f} ms; queues {sorted(set(r[4] for r in step))}")
+by_name = defaultdict(lambda: [0, 0])
+for n, s_, e_, _, _ in step:
+    by_name[short(n)][0] += 1
+    by_name[short(n)][1] += min(e_, t1) - s_
+print("kernel time inside the step by symbol (launches, ms):")
+for n, (c, v) in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:28]:
+    print(f"  {n:60s} {c:5d} {v / 1e6:8.3f}")
+print("time with fewer than 256 workgroups in flight, by kernel:")
 for n, v in sorted(owner.items(), key=lambda kv: -kv[1])[:20]:
     print(f"  {n:60s} {v / 1e3:9.1f} us")
