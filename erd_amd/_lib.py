@@ -84,6 +84,8 @@ _SIGNATURES = {
     "erd_wino_weights_x3": [P, P, i32, i32, i32, P],
     "erd_wino_conv3x3_x3": [P, i32, P, i32, i32, P, P, i32, P, i32, P, P],
     "erd_wino_x3_couts_per_item": [P, i32, i32],
+    "erd_wino_conv3x3_x3_gn": [P, i32, P, i32, i32, P, P, i32, P, P, C.c_size_t, P, f32, P],
+    "erd_wino_x3_gn_ws_bytes": [P, i32, i32],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_row3_slices": [C.POINTER(WgradDesc)],
     "erd_wgrad_reduce": [P, i32, i32, i32, P, P, P, i32, P, P],
@@ -98,6 +100,7 @@ _SIGNATURES = {
     "erd_relu_bwd_colsum": [P, P, P, i64, i32, i64, i64, P, i32, i32, P],
     "erd_bn_dgamma": [P, P, i32, P, P, f32, P, P, i32, i32, P],
     "erd_gn_relu_fwd": [P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), f32, i32, P],
+    "erd_gn_relu_apply": [P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), i32, P],
     "erd_gn_relu_bwd": [P, P, P, P, P, P, P, P, P, i32, i64, i32, i32, C.POINTER(Levels), i32, P],
     "erd_upsample2x_add": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, i32, P],
     "erd_upsample2x_add_bwd": [P, P, i32, i32, i32, i32, i32, i32, i64, i64, i32, P],

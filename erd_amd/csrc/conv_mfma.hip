@@ -76,6 +76,28 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// LDS-DMA (`buffer_load_dwordx4 ... lds`): 16 B per lane from the lane's own buffer offset to LDS address M0 + 16 * lane, no register in
+// between; out-of-range offsets arrive as zeros (tools/glds_probe.hip).  Issued through inline assembly ON PURPOSE: the compiler's own
+// builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) makes it wait `vmcnt(0)` in front of the next LDS read that might alias -- in the
+// middle of the K-slice that is supposed to hide the transfer.  An asm load is absent from the compiler's s_waitcnt bookkeeping, which
+// is safe in one direction only: loads retire in order, so the compiler's counted waits for ITS loads can only become stricter; the
+// DMA's own completion is waited for explicitly (`glds_wait_all`) in front of the barrier that publishes the buffer.  M0 is written
+// in the same statement (the compiler keeps nothing in M0 across statements); `s_nop 0`: the M0-write -> LDS-DMA hazard.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 rsrc_words(const void* ptr, int bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void glds16(const i32x4 rs, unsigned lds_byte, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 struct SkWs {
     int* cnt;        // [tiles] arrival tickets (zeroed before the launch)
     float* slabs;    // [2*G][BM*BN]
@@ -105,7 +127,8 @@ int xcd_order_enabled() {
 // owns 32 pixel rows x all BN couts) so that every activation value is split by exactly one wave: 44 VALU operations per 24
 // MFMAs.  One K-slice = 32 channels = two k16 steps.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false,
-          bool OB = false, bool X3 = false, bool RES = false, bool MSK = false>     // RES / MSK (f32x3 only): some segment has a residual / a mask
+          bool OB = false, bool X3 = false, bool RES = false, bool MSK = false,     // RES / MSK (f32x3 only): some segment has a residual / a mask
+          bool GL = false>     // GL (f32x3): operand slices travel global -> LDS by LDS-DMA (buffer_load ... lds), see below
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kernel(const erd_conv_desc p, const int total_tiles,
                                                                      const SkWs ws) {
     constexpr int NT = WAVES_M * WAVES_N * 64;   // threads: four waves, or eight on the 256-row tiles of the bf16 mode
@@ -121,6 +144,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
     static_assert(WAVES_M * WAVES_N == 4 || (WAVES_M * WAVES_N == 8 && BF && !X3), "4 waves (8: bf16 matrix cores only)");
     static_assert(BF || (!AB && !OB), "bf16 storage only with the bf16 matrix cores");
     static_assert(!X3 || (!BF && BKT == 32 && WAVES_N == 1 && FM == 1), "f32x3: fp32 maps, 32-channel slices, 4 x 1 waves");
+    static_assert(!GL || X3, "LDS-DMA staging: the three-limb kernel (both operands are stored in LDS exactly as they lie in memory)");
     constexpr unsigned ABYTES = AB ? 2u : 4u;   // bytes per stored input value
     constexpr int CHB = X3 ? 4 : CH;            // 16-B chunks per K-slice row of ONE weight plane (f32x3: 8 bf16 per chunk)
     constexpr int NPL = X3 ? 3 : 1;             // weight planes in LDS
@@ -170,6 +194,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
     const int r0 = tid / CH;
     auto swzc = [](int row, int c) { return CH == 8 ? (c ^ ((row >> 1) & 7)) : (c ^ ((row >> 2) & 3)); };
     const int wave = tid >> 6, lane = tid & 63;
+    // GL: an LDS-DMA instruction writes base + 16 * lane -- the LDS image is lane-linear, so the swizzle goes on the SOURCE side: the
+    // thread that fills position `chunk` of row r fetches the logical chunk that the swizzle keeps there (an involution; the term of
+    // the row, (r >> 1) & 7 resp. (r >> 2) & 3, is the same for all of a thread's row passes: they are 32 resp. 64 rows apart)
+    const int chunk_l = GL ? (chunk ^ ((r0 >> 1) & 7)) : chunk;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, h = lane >> 5;
 
@@ -233,16 +262,36 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
                 dst[tid] = ri;
             }
         };
-        fill_rows(rows);
-        __syncthreads();
+        if constexpr (!GL) {
+            fill_rows(rows);
+            __syncthreads();
+        }
 
         // per-row byte offset of tap (0,0) and a validity bit per tap: the K loop then needs one add + one select
         // per 16-B load, and zero padding comes from the buffer's out-of-range rule (no branches, no zero fill)
         unsigned a_base[AJ], a_mask[AJ];
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const RowInfo ri = rows[r0 + RPP * j];
-            a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk * KPC) * ABYTES;
+            RowInfo ri;
+            if constexpr (GL) {      // no table, no barriers: a thread decodes its own AJ rows (the operand region is about to be filled by DMA)
+                const int GHW = sg.GH * sg.GW;
+                const int m = mt * BM + r0 + RPP * j;
+                if (m < sg.N * GHW) {
+                    const int n = m / GHW;
+                    const int rem = m - n * GHW;
+                    const int a = rem / sg.GW;
+                    ri.in_off = (int)(n * sg.in_nstride);
+                    ri.ih0 = a * p.in_stride;
+                    ri.iw0 = (rem - a * sg.GW) * p.in_stride;
+                } else {
+                    ri.in_off = 0;
+                    ri.ih0 = -(1 << 28);
+                    ri.iw0 = -(1 << 28);
+                }
+            } else {
+                ri = rows[r0 + RPP * j];
+            }
+            a_base[j] = (unsigned)(ri.in_off + (ri.ih0 * IW + ri.iw0) * Cin + chunk_l * KPC) * ABYTES;
             unsigned m = 0;
             for (int t = 0; t < nt_s; ++t) {
                 const int ih = ri.ih0 + p.dy[tap_lo + t], iw = ri.iw0 + p.dx[tap_lo + t];
@@ -254,11 +303,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
         unsigned b_base[X3 ? 1 : BJ];
         unsigned bx_base[X3 ? BJX : 1];            // f32x3: byte offset of (cout row, 8-value chunk) inside ONE bf16 weight plane
         const int chunkb = tid % CHB, rb0 = tid / CHB;
+        const int chunkb_l = GL ? (chunkb ^ ((rb0 >> 2) & 3)) : chunkb;      // (GL: the logical chunk behind this thread's LDS position)
         if constexpr (X3) {
 #pragma unroll
             for (int j = 0; j < BJX; ++j) {
                 const int co = n0 + rb0 + RPPB * j;
-                bx_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunkb * 8) * 2u : OOB;
+                bx_base[j] = co < p.Cout ? (unsigned)(co * p.wrow + chunkb_l * 8) * 2u : OOB;
             }
         } else {
 #pragma unroll
@@ -273,7 +323,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
             X3 ? const_cast<void*>(p.w_x3) : (BF ? const_cast<void*>(p.w_bf16) : (void*)const_cast<float*>(w)), 0,
             (int)((long long)p.Cout * p.wrow * (X3 ? 6 : (BF ? 2 : 4))), 0x00020000);
-        if constexpr (X3) __syncthreads();         // the row table (start of the operand region) has been read by everybody
+        if constexpr (X3 && !GL) __syncthreads();         // the row table (start of the operand region) has been read by everybody
 
         // bf16 matrix cores: a K-slice is ~250 ns of MFMA work, far less than the latency of the global loads that
         // feed the next one -> TWO slices are kept in flight in registers (set = slice parity): slice kt+2 is requested
@@ -281,7 +331,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
         constexpr bool PD2 = BF && MINW <= 2;      // (the four-per-CU tuning variant has no registers to spare)
         constexpr int NSET = PD2 ? 2 : 1;
         constexpr int NBL = X3 ? 3 * BJX : BJ;      // 16-B weight loads per thread and K-slice
-        float4 ra[NSET][AJ], rb[NSET][NBL];
+        float4 ra[GL ? 1 : NSET][GL ? 1 : AJ], rb[GL ? 1 : NSET][GL ? 1 : NBL];      // (GL: no staging registers)
         float4 ra1[NSET][(BF && !AB) ? AJ : 1];     // bf16 mode on fp32 maps: the second half (k+4..k+7) of each 8-value chunk
         bool cokb = false;                          // f32x3: this thread's 8-value weight chunk lies inside Cin
         int tap = ks / cpt, cc = ks - tap * cpt;
@@ -293,10 +343,29 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
             ctap = tap;
             adelta = ((p.dy[tap_lo + tap] * IW + p.dx[tap_lo + tap]) * Cin + cb) * (int)ABYTES;    // bytes, relative to tap (0,0)
             bdelta = (p.wk[tap_lo + tap] + cb) * ((BF || X3) ? 2 : 4);
-            cok = cb + chunk * KPC < Cin;   // Cin % 4 == 0: a 4-value group is all-in or all-out
-            cokb = X3 && cb + chunkb * 8 < Cin;      // (a chunk that starts inside Cin may end past it: see erd_conv_igemm)
+            cok = cb + chunk_l * KPC < Cin;   // Cin % 4 == 0: a 4-value group is all-in or all-out
+            cokb = X3 && cb + chunkb_l * 8 < Cin;      // (a chunk that starts inside Cin may end past it: see erd_conv_igemm)
             cok1 = BF && !AB && cb + chunk * KPC + 4 < Cin;
             if (++cc == cpt) { cc = 0; ++tap; }
+        };
+        // GL: LDS-DMA.  `buffer_load_dwordx4 ... lds` moves 16 B per lane from the lane's own buffer offset to LDS address M0 + 16 * lane --
+        // a wave fills 1 KB: 8 activation rows of 128 B, or 16 rows of one 64-B weight plane -- without passing through registers:
+        // no staging registers (40 of them), no ds_write_b128 pass (13 LDS-port cycles each: 10 per thread and slice), and out-of-range
+        // offsets (padding taps, rows past the end, channels past Cin) arrive as ZEROS exactly as with loads to registers
+        // (tools/glds_probe.hip: source permutation, zero fill, destinations up to 160 KB).  Same LDS image, same MFMA sequence:
+        // bit-identical results.
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;      // LDS byte address of the operand region
+        const i32x4 rw_in = GL ? rsrc_words(in, (int)((long long)sg.N * sg.in_nstride * ABYTES)) : i32x4{0, 0, 0, 0};
+        const i32x4 rw_w = GL ? rsrc_words(p.w_x3, (int)((long long)p.Cout * p.wrow * 6)) : i32x4{0, 0, 0, 0};
+        auto glds_a = [&](int j, const int buf) {
+            const bool ok = cok && ((a_mask[j] >> ctap) & 1u);
+            glds16(rw_in, lds0 + (unsigned)(((buf * BM + RPP * j + 8 * wave_s) * CH) * 16), ok ? a_base[j] + (unsigned)adelta : OOB);
+        };
+        auto glds_b = [&](int j, const int buf) {      // j = plane * BJX + row pass
+            const int pl = j / BJX, jj = j - pl * BJX;
+            glds16(rw_w, lds0 + (unsigned)((2 * BM * CH + (buf * 3 + pl) * BN * CHB + (RPPB * jj + 16 * wave_s) * CHB) * 16),
+                   cokb ? bx_base[X3 ? jj : 0] + (unsigned)bdelta + (unsigned)pl * plane_b : OOB);
         };
         auto load_a = [&](int j, const int set) {
             const bool ok = cok && ((a_mask[j] >> ctap) & 1u);
@@ -348,10 +417,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         slice_begin();
+        if constexpr (GL) {
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) glds_b(j, 0);
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) glds_a(j, 0);
+        } else {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) load_a(j, 0);
 #pragma unroll
         for (int j = 0; j < NBL; ++j) load_b(j, 0);
+        }
         if (PD2 && ks + 1 < ke) {
             slice_begin();
 #pragma unroll
@@ -359,7 +435,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
 #pragma unroll
             for (int j = 0; j < NBL; ++j) load_b(j, NSET - 1);
         }
-        store_lds(0, 0);
+        if constexpr (GL) glds_wait_all(); else store_lds(0, 0);
         __syncthreads();
 
         IG_ACC(2, t_pro);
@@ -428,10 +504,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
                 if (more) {      // the next slice's global loads, half of them per k16 step, issued under this step's MFMAs
 #pragma unroll
                     for (int q = 0; q < APS; ++q)
-                        if (kk * APS + q < AJ) load_a(kk * APS + q, 0);
+                        if (kk * APS + q < AJ) { if constexpr (GL) glds_a(kk * APS + q, buf ^ 1); else load_a(kk * APS + q, 0); }
 #pragma unroll
                     for (int q = 0; q < BPS; ++q)
-                        if (kk * BPS + q < NBL) load_b(kk * BPS + q, 0);
+                        if (kk * BPS + q < NBL) { if constexpr (GL) glds_b(kk * BPS + q, buf ^ 1); else load_b(kk * BPS + q, 0); }
                 }
 #endif
                 u4v ph, pm, pl;
@@ -475,8 +551,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_igemm_kerne
             }
 #undef ERD_X3
 #ifndef ERD_X3_NOSYNC     // (timing probe, with ERD_X3_NOLOAD: no LDS refill and no barrier between slices)
-            if (more) store_lds(buf ^ 1, 0);
-            __syncthreads();
+            if constexpr (GL) glds_wait_all(); else { if (more) store_lds(buf ^ 1, 0); }
+            __syncthreads();      // (GL: everybody's DMA into the other buffer has landed, and this buffer is free)
 #endif
         };
         // one K-slice; par = (kt - ks) & 1 selects the LDS buffer (and, with two slices in flight, the register set)
@@ -1867,7 +1943,7 @@ int num_cus() {
 }
 
 template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool BF = false, bool ST = false, bool AB = false, bool OB = false,
-          bool X3 = false, bool RES = false, bool MSK = false>
+          bool X3 = false, bool RES = false, bool MSK = false, bool GL = false>
 int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     constexpr int NT = WM * WN * 64;
     constexpr int BK = (BKT / 4) * (BF ? 8 : 4);
@@ -1885,7 +1961,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     // (f32x3: the row table and the fix-up's broadcast word live inside the operand region -- see the kernel)
     static const size_t lds_pad = getenv("ERD_IG_LDS_PAD") ? (size_t)atoi(getenv("ERD_IG_LDS_PAD")) : 0;   // occupancy experiments
     const size_t lds = (X3 ? oper : (oper > stage ? oper : stage) + BM * sizeof(RowInfo) + 16) + lds_pad;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB, X3, RES, MSK>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BKT, MINW, BF, ST, AB, OB, X3, RES, MSK, GL>;
     static bool attr_done = false;  // idempotent, value never changes: benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1991,14 +2067,21 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
         // the epilogue is instantiated per (residual, mask) presence: its loads are unconditional and sit in front of its stores
         bool any_res = false, any_msk = false;
         for (int s = 0; s < d->nseg; ++s) { any_res |= d->seg[s].res != nullptr; any_msk |= d->seg[s].mask != nullptr; }
-#define ERD_X3_EPI(BN_, ST_)                                                                                                  \
-        (any_res ? (any_msk ? launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, true, true>(d, st)         \
-                            : launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, true, false>(d, st))       \
-                 : (any_msk ? launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, true>(d, st)        \
-                            : launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, false>(d, st)))
-        if (seg_taps_any) return ERD_X3_EPI(128, true);
-        if (d->Cout <= 64) return ERD_X3_EPI(64, false);
-        return ERD_X3_EPI(128, false);
+#define ERD_X3_EPI(BN_, ST_, GL_)                                                                                                  \
+        (any_res ? (any_msk ? launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, true, true, GL_>(d, st)         \
+                            : launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, true, false, GL_>(d, st))       \
+                 : (any_msk ? launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, true, GL_>(d, st)        \
+                            : launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, false, GL_>(d, st)))
+        // operand slices by LDS-DMA (GL; ERD_IG_GLDS=0: through registers + ds_write, the form of rounds 3-5; bit-identical results)
+        static const int glds = getenv("ERD_IG_GLDS") ? atoi(getenv("ERD_IG_GLDS")) : 1;
+        if (glds) {
+            if (seg_taps_any) return ERD_X3_EPI(128, true, true);
+            if (d->Cout <= 64) return ERD_X3_EPI(64, false, true);
+            return ERD_X3_EPI(128, false, true);
+        }
+        if (seg_taps_any) return ERD_X3_EPI(128, true, false);
+        if (d->Cout <= 64) return ERD_X3_EPI(64, false, false);
+        return ERD_X3_EPI(128, false, false);
 #undef ERD_X3_EPI
     }
     ERD_REQUIRE(d->w, "conv: this launch needs the fp32 weights (w_x3 serves Cin %% 4 == 0 only)");

@@ -888,6 +888,17 @@ extern "C" int erd_gn_relu_fwd(const void* c, void* y, const float* gamma, const
     return erd::check_launch("gn_relu_fwd");
 }
 
+// the normalisation pass alone: mean_rstd[N][nseg][G][2] comes from the producing convolution (erd_wino_conv3x3_x3_gn)
+extern "C" int erd_gn_relu_apply(const void* c, void* y, const float* gamma, const float* beta, const float* mean_rstd, int N,
+                                 int64_t A, int C, int G, const erd_levels* lv, int map_type, erd_stream_t stream) {
+    ERD_REQUIRE(c && y && gamma && beta && mean_rstd && lv && ERD_MAP_OK(map_type), "gn_apply: bad args");
+    ERD_REQUIRE(C == 256 && G == 32, "gn_apply: only C=256,G=32 (gfl_head.py:109-110) is built");
+    const GnChunks ch = make_chunks(lv);
+    ERD_MAP(map_type, hipLaunchKernelGGL((gn_apply_kernel<256, 32, T>), dim3(ch.start[lv->nseg], N), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)c, (T*)y, gamma, beta, mean_rstd, A, *lv, ch));
+    return erd::check_launch("gn_relu_apply");
+}
+
 extern "C" int erd_gn_relu_bwd(const void* c, const void* dy, const float* gamma, const float* beta,
                                const float* mean_rstd, double* stats_ws, void* dc, float* dgamma, float* dbeta, int N,
                                int64_t A, int C, int G, const erd_levels* lv, int map_type, erd_stream_t stream) {

@@ -47,6 +47,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The sum over the wave in every lane, on the VECTOR pipe: four DPP steps (quad swaps, half-row and row mirrors) give every lane its
+// row-of-16's sum, four v_readlane fetch the rows' sums.  wave_sum above compiles to six DEPENDENT ds_bpermute (the LDS crossbar,
+// ~100 cycles each): fine for one sum per kernel, 10 000 cycles where an output stage needs sixteen (another summation order).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define ERD_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    ERD_DPP_ADD(0xB1);      // quad_perm [1, 0, 3, 2]
+    ERD_DPP_ADD(0x4E);      // quad_perm [2, 3, 0, 1]
+    ERD_DPP_ADD(0x141);     // row_half_mirror
+    ERD_DPP_ADD(0x140);     // row_mirror
+#undef ERD_DPP_ADD
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

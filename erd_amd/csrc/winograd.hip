@@ -142,6 +142,8 @@ struct WinoDesc {
     int blocks_per_nb;       // blocks per cout block
     int nitems;              // workgroup items = blocks_per_nb * cout blocks
     int* sched;              // optional {next-item counter, finished-workgroup counter}, zero on entry and on exit
+    float* gn_part;          // optional (wino_x3p_kernel): [nitems][16][2] = (sum, sum of squares) of what the item STORED, per group of 8
+                             // channels -- the GroupNorm(32) statistics of gfl_head.py:158-177 from the producer (wino_gn_finalize_kernel)
 };
 
 // One (tile block, cout block) work item: where it lives.  All fields are wave-uniform (scalar registers).
@@ -1214,6 +1216,7 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
     constexpr unsigned RAWB = HPIX * RCS * 16, VOFF = 2 * RAWB, VB = VX_B, XOFF = VOFF + 2 * VB;
     float* sh_ss = reinterpret_cast<float*>(smem + XOFF);
     int* sh_item = reinterpret_cast<int*>(sh_ss + 4 * 2 * BNP);
+    float* sh_gn = reinterpret_cast<float*>(sh_item + 4);      // [4 transform rows][16 groups][2]: the waves' group sums of the finished item
     char* const sm = smem;
 
     const int tid = threadIdx.x;
@@ -1221,6 +1224,7 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
     const int nks = Cin / KS;
     const int nitems = p.nitems;
     const int ncb32 = (p.Cout + 31) / 32;
+    int cur_item = blockIdx.x;
 
     auto decode = [&](int item) {
         WinoItem it;
@@ -1498,7 +1502,7 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
         const int oy = cur.y0 + 2 * ty + fa, ox = cur.x0 + 2 * tx + fc;
         const bool pix_ok = oy < cur.yl && ox < cur.xl;
         const int64_t opix = cur.n * sg.out_nstride + ((int64_t)oy * sg.W + ox) * p.Cout;
-        const bool simple = !sg.res && !sg.mask && !p.colsum;
+        const bool simple = !sg.res && !sg.mask && !p.colsum;      // (gn_stats: the simple path only -- wino_launch checks)
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
             sg.out, 0, (int)((long long)sg.N * sg.out_nstride * 4), 0x00020000);
         const float lo = p.relu ? 0.f : -__builtin_inff();
@@ -1569,10 +1573,11 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
                                        yv[4 * gq + 3] * sc.w + sh.w);
                 cs[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (simple) {
+                    v = make_float4(fmaxf(v.x, lo), fmaxf(v.y, lo), fmaxf(v.z, lo), fmaxf(v.w, lo));
                     u32x4 o;
-                    o.x = __float_as_uint(fmaxf(v.x, lo)); o.y = __float_as_uint(fmaxf(v.y, lo));
-                    o.z = __float_as_uint(fmaxf(v.z, lo)); o.w = __float_as_uint(fmaxf(v.w, lo));
+                    o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, pix_ok ? (unsigned)((opix + co0) * 4) : OOBV, 0, 0);
+                    if (pix_ok) cs[gq] = v;
                 } else {
                     if (sg.res) v = f4add(v, pr[b][gq]);
                     if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
@@ -1585,6 +1590,21 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
                     o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, out_off(b, gq), 0, 0);
                     if (pix_ok) cs[gq] = v;
+                }
+            }
+            if (p.gn_part) {
+                // GroupNorm statistics from the producer: a group is 8 consecutive channels = the registers 4 gq .. + 3 of the lanes
+                // h = 0 and h = 1; this wave holds one pixel of each of its 32 tiles (every pixel of the map is stored -- and counted --
+                // exactly once: pix_ok).  Per (cout block, gq): two wave sums into LDS; behind the stage's last barrier 32 threads add
+                // the four transform rows' shares in a fixed order and write the item's 16 x 2 sums -- no atomics (a first version
+                // with f64 atomics per wave ran the head towers 1.35x SLOWER: ~500 same-address atomics per statistic, and every later
+                // load of the wave waits for them in the in-order counter), deterministic.
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 c4 = cs[gq];
+                    const float s1 = erd::wave_sum_dpp((c4.x + c4.y) + (c4.z + c4.w));
+                    const float s2 = erd::wave_sum_dpp((c4.x * c4.x + c4.y * c4.y) + (c4.z * c4.z + c4.w * c4.w));
+                    if (lane == 0) *reinterpret_cast<float2*>(sh_gn + ((ri * 16) + (2 * cp + b) * 4 + gq) * 2) = make_float2(s1, s2);
                 }
             }
             if (p.colsum) {
@@ -1603,6 +1623,10 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
                 }
             }
             __syncthreads();                              // the slots are free: next round's writes / the next slice's V stores
+        }
+        if (p.gn_part && tid < 32) {                      // (behind the last round's barrier: all 4 x 16 x 2 shares are in LDS)
+            const float t = ((sh_gn[tid] + sh_gn[32 + tid]) + sh_gn[64 + tid]) + sh_gn[96 + tid];
+            p.gn_part[(int64_t)cur_item * 32 + tid] = t;
         }
     };
 
@@ -1686,8 +1710,43 @@ __global__ __launch_bounds__(512, 2) void wino_x3p_kernel(const WinoDesc p) {
             break;
         }
         cur = nxt;
+        cur_item = nxt_item;
         u_item = u_next;
         ++k_item;
+    }
+}
+
+// GroupNorm statistics of a wino_x3p_kernel launch with gn_part: block (n, s, cout block nb) adds the (sum, sum of squares) that the items
+// of image n in every region of segment s wrote for its 16 groups -- 16 item lanes x (16 groups x 2 moments) threads, every lane a fixed
+// subsequence of the items, the lanes combined in a fixed order, all in f64: deterministic -- and folds them to (mean, 1 / std) with
+// gn_finalize_kernel's arithmetic: mean_rstd[N][nseg][G][2].  (One THREAD per group walking its ~130 items was a 45 us latency chain.)
+__global__ __launch_bounds__(512) void wino_gn_finalize_kernel(const WinoDesc p, float* __restrict__ mean_rstd, float eps) {
+    const int G = p.Cout >> 3;
+    const int nb = blockIdx.x, s = blockIdx.y, n = blockIdx.z;
+    if (n >= p.seg[s].N) return;
+    const int q = threadIdx.x & 31, il = threadIdx.x >> 5;      // q = group-in-item * 2 + moment; il: item lane (16)
+    double acc = 0.0;
+    for (int r = 0; r < p.nreg; ++r) {
+        const WinoRegion& rg = p.reg[r];
+        if (rg.seg != s) continue;
+        const int per_img = rg.nby * rg.nbx;
+        const int64_t it0 = (int64_t)nb * p.blocks_per_nb + rg.block0 + (int64_t)n * per_img;
+        for (int b = il; b < per_img; b += 16) acc += (double)p.gn_part[(it0 + b) * 32 + q];
+    }
+    __shared__ double red[16][32];
+    red[il][q] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int gi = threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int l = 0; l < 16; ++l) { s1 += red[l][2 * gi]; s2 += red[l][2 * gi + 1]; }
+        const double m = (double)p.seg[s].H * p.seg[s].W * 8.0;
+        const double mean = s1 / m;
+        double var = s2 / m - mean * mean;
+        if (var < 0) var = 0;
+        const int64_t i = ((int64_t)n * p.nseg + s) * G + nb * 16 + gi;
+        mean_rstd[i * 2] = (float)mean;
+        mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -1797,7 +1856,8 @@ int wino_plan(WinoDesc& d, const erd_conv_seg* segs, int nseg, bool x3, int Cout
 }
 
 int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* U3, int Cin, int Cout, const float* scale,
-                const float* shift, int relu, float* colsum, int colsum_copies, int* sched, hipStream_t stream) {
+                const float* shift, int relu, float* colsum, int colsum_copies, int* sched, hipStream_t stream,
+                float* gn_part = nullptr, size_t gn_part_bytes = 0, float* gn_mean_rstd = nullptr, float gn_eps = 0.f) {
     ERD_REQUIRE(segs && (U || U3) && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
     ERD_REQUIRE(Cin % KS == 0 && Cin >= 4 * KS && Cout > 0, "wino: Cin=%d must be a multiple of %d and at least %d", Cin, KS, 4 * KS);
     WinoDesc d;
@@ -1812,6 +1872,7 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     ERD_REQUIRE(colsum_copies >= 0 && (colsum_copies & (colsum_copies - 1)) == 0, "wino: colsum_copies must be a power of two");
     d.colsum_copies = colsum_copies;
     d.sched = sched;
+    d.gn_part = gn_part;
     ERD_REQUIRE(!colsum || Cout % 4 == 0, "wino: colsum needs Cout %% 4 == 0");
     int ncu = 0;
     bool phased = false;
@@ -1825,14 +1886,29 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
     if (persist != 1) d.sched = nullptr;
+    int gn_nmax = 0;
+    if (gn_part) {
+        ERD_REQUIRE(Cout % 8 == 0 && gn_mean_rstd, "wino: GroupNorm statistics need Cout %% 8 == 0 and a mean_rstd buffer");
+        ERD_REQUIRE(phased && !colsum, "wino: the fused GroupNorm statistics need the 128-couts-per-item kernel (erd_wino_x3_couts_per_item) and no column sums");
+        for (int q = 0; q < nseg; ++q) {
+            ERD_REQUIRE(!segs[q].res && !segs[q].mask, "wino: the fused GroupNorm statistics serve plain convolutions (segment %d has a residual / mask)", q);
+            gn_nmax = std::max(gn_nmax, segs[q].N);
+        }
+        ERD_REQUIRE(gn_part_bytes >= (size_t)d.nitems * 32 * sizeof(float), "wino: GroupNorm partial-sum workspace too small (%zu bytes for %d items)",
+                    gn_part_bytes, d.nitems);
+    }
     if (phased) {
-        const size_t lds = (size_t)2 * HPIX * RCS * 16 + 2 * VX_B + 4 * 2 * BNP * sizeof(float) + 16;
+        const size_t lds = (size_t)2 * HPIX * RCS * 16 + 2 * VX_B + 4 * 2 * BNP * sizeof(float) + 16 + 4 * 16 * 2 * sizeof(float);
         static bool attrp_done = false;
         if (!attrp_done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_x3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attrp_done = true;
         }
         hipLaunchKernelGGL(wino_x3p_kernel, dim3((unsigned)grid), dim3(512), lds, stream, d);
+        if (gn_part) {
+            hipLaunchKernelGGL(wino_gn_finalize_kernel, dim3((unsigned)(Cout / BNP), (unsigned)nseg, (unsigned)gn_nmax), dim3(512), 0, stream, d,
+                               gn_mean_rstd, gn_eps);
+        }
         return erd::check_launch("wino_conv3x3_x3p");
     }
     if (U3) {
@@ -1887,4 +1963,24 @@ extern "C" int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const voi
                                    int* sched, erd_stream_t stream) {
     ERD_REQUIRE(U3, "wino_x3: null U3");
     return wino_launch(segs, nseg, nullptr, U3, Cin, Cout, scale, shift, relu, colsum, colsum_copies, sched, (hipStream_t)stream);
+}
+
+/* ABI v6: erd_wino_conv3x3_x3 on a plain convolution (no residual / mask / column sums) that ALSO produces the GroupNorm statistics of its
+ * result: the output stage of every item writes its 16 groups' (sum, sum of squares) to gn_part (workspace, erd_wino_x3_gn_ws_bytes), a
+ * second tiny launch folds them to mean_rstd[N][nseg][Cout / 8][2] (float: mean, 1 / sqrt(var + eps); N = the largest segment's).
+ * Needs the 128-couts-per-item kernel (erd_wino_x3_couts_per_item == 128).  erd_gn_relu_apply consumes mean_rstd. */
+extern "C" int erd_wino_conv3x3_x3_gn(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout, const float* scale,
+                                      const float* shift, int relu, int* sched, float* gn_part, size_t gn_part_bytes,
+                                      float* mean_rstd, float eps, erd_stream_t stream) {
+    ERD_REQUIRE(U3 && gn_part && mean_rstd, "wino_x3_gn: null U3 / gn_part / mean_rstd");
+    return wino_launch(segs, nseg, nullptr, U3, Cin, Cout, scale, shift, relu, nullptr, 0, sched, (hipStream_t)stream, gn_part,
+                       gn_part_bytes, mean_rstd, eps);
+}
+
+extern "C" size_t erd_wino_x3_gn_ws_bytes(const erd_conv_seg* segs, int nseg, int Cout) {
+    WinoDesc d;
+    int ncu = 0;
+    bool phased = false;
+    if (!segs || wino_plan(d, segs, nseg, true, Cout, ncu, phased) != 0 || !phased) return 0;
+    return (size_t)d.blocks_per_nb * (Cout / BNP) * 32 * sizeof(float);
 }

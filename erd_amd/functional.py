@@ -727,10 +727,7 @@ class HeadConvGN(Function):
     @staticmethod
     def forward(ctx, x_cat, w, gamma, beta, sizes, eps: float):
         K.RECORDED = any(ctx.needs_input_grad)      # see kernels.WINO_TRAIN_FWD
-        wk = ohwi(w)
-        c = torch.empty((x_cat.shape[0], x_cat.shape[1], wk.shape[0]), dtype=x_cat.dtype, device=x_cat.device)
-        K.conv_forward(K.level_views(x_cat, sizes), wk, K.level_views(c, sizes), 3, 1, 1)
-        y, mr = K.gn_relu_forward(c, gamma.detach(), beta.detach(), sizes, 32, eps)
+        c, y, mr = K.conv3x3_gn_relu_forward(x_cat, ohwi(w), gamma.detach(), beta.detach(), sizes, 32, eps)
         ctx.sizes = sizes
         ctx.save_for_backward(x_cat, w, gamma, beta, c, mr)
         return y

@@ -1114,6 +1114,47 @@ def gn_relu_forward(c: Tensor, gamma: Tensor, beta: Tensor, sizes, G: int = 32, 
     return y, mr
 
 
+GN_FUSED = _os.environ.get("ERD_GN_FUSED", "1") != "0"      # GroupNorm statistics from the producing convolution (A/B aid: 0)
+
+
+def conv3x3_gn_relu_forward(x_cat: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, sizes, G: int = 32, eps: float = 1e-5):
+    """One tower layer of the GFL head on all levels (gfl_head.py:158-177,219-223): c = conv3x3(x) (no bias), y = ReLU(GroupNorm(c)).
+    x_cat [N,A,Cin]; w [Cout,3,3,Cin] (OHWI).  Returns (c, y, mean_rstd).
+    Where the convolution runs on the 128-couts-per-item three-limb Winograd kernel its output stage accumulates the group sums
+    of its items and a tiny launch folds them to (mean, 1 / std) (erd_wino_conv3x3_x3_gn); the normalisation is the apply pass alone
+    (erd_gn_relu_apply) -- the statistics pass over c and its zero fill disappear; everywhere else: conv_forward + gn_relu_forward."""
+    _require_gpu(x_cat, w)
+    N, A, Cin = x_cat.shape
+    Cout = w.shape[0]
+    c = torch.empty((N, A, Cout), dtype=x_cat.dtype, device=x_cat.device)
+    xs, outs = level_views(x_cat, sizes), level_views(c, sizes)
+    fused = (GN_FUSED and Cout == 256 and G == 32 and x_cat.dtype == torch.float32 and wino_ok(Cin, 3, 1, 1) and wino_x3()
+             and (WINO_TRAIN_FWD if RECORDED else WINO_NOGRAD_FWD))
+    ws_bytes = 0
+    if fused:
+        from ._lib import ConvSeg
+        segs = (ConvSeg * len(xs))()
+        for i, (x, o) in enumerate(zip(xs, outs)):
+            _fill_seg(segs[i], x, o, x.shape[1], x.shape[2], None, None, None)
+        ws_bytes = int(_lib.load().erd_wino_x3_gn_ws_bytes(segs, len(xs), Cout))      # 0: this launch runs on the 64-couts-per-item kernel
+    if ws_bytes == 0:
+        conv_forward(xs, w, outs, 3, 1, 1)
+        y, mr = gn_relu_forward(c, gamma, beta, sizes, G, eps)
+        return c, y, mr
+    U = _wino_weights_cached(w)
+    lv = make_levels(sizes)
+    part = workspace("gn_part", ws_bytes, c.device)
+    mr = torch.empty((N, lv.nseg, G, 2), dtype=torch.float32, device=c.device)
+    flop = 2.0 * N * A * Cout * 9 * Cin
+    nbytes = (4.0 * (x_cat.numel() + c.numel()) + U.numel() * U.element_size()) if _TIMING is not None else 0.0
+    _timed_call("conv_wino_fwd_p", flop, "erd_wino_conv3x3_x3_gn", segs, len(xs), _p(U), Cin, Cout, None, None, 0,
+                _p(_wino_sched(U.device)), _p(part), ws_bytes, _p(mr), eps, _stream(), nbytes=nbytes,
+                tag=f"px{N * A} {Cin}->{Cout} k3s1" if TIMING_DETAIL else "")
+    y = torch.empty_like(c)
+    call("erd_gn_relu_apply", _p(c), _p(y), _p(gamma), _p(beta), _p(mr), N, A, Cout, G, C.byref(lv), _mt(c), _stream())
+    return c, y, mr
+
+
 def gn_relu_backward(c: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mr: Tensor, sizes, G: int = 32,
                      dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None):
     """dgamma / dbeta: zero-initialised accumulators to add into (the parameters' flat gradient slots), else fresh ones"""

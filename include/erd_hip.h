@@ -167,6 +167,16 @@ int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const void* U3, int 
  * persistent grid, 32 tiles x 64 couts (wino_x3_kernel) otherwise; results are bit-identical either way.
  * erd_wino_x3_couts_per_item tells the caller which (128 / 64; a profiler sees two kernel symbols), < 0 on bad segments. */
 int erd_wino_x3_couts_per_item(const erd_conv_seg* segs, int nseg, int Cout);
+/* ABI v6.  erd_wino_conv3x3_x3 on a PLAIN convolution (no residual / mask / column sums) that also produces the GroupNorm(32)
+ * statistics of what it stores (gfl_head.py:158-177: conv -> GN -> ReLU; replaces the statistics pass over the conv output, its zero
+ * fill and the finalize launch): every item's output stage writes its 16 groups' (sum, sum of squares) to `gn_part` (a workspace of
+ * erd_wino_x3_gn_ws_bytes; no atomics, deterministic), a second tiny launch adds them in f64 and writes
+ * mean_rstd[N][nseg][Cout / 8][2] = (mean, 1 / sqrt(var + eps)).  Served by the 128-couts-per-item kernel only
+ * (erd_wino_x3_couts_per_item == 128; erd_wino_x3_gn_ws_bytes returns 0 otherwise).  erd_gn_relu_apply consumes mean_rstd. */
+int erd_wino_conv3x3_x3_gn(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout, const float* scale,
+                           const float* shift, int relu, int* sched, float* gn_part, size_t gn_part_bytes, float* mean_rstd,
+                           float eps, erd_stream_t stream);
+size_t erd_wino_x3_gn_ws_bytes(const erd_conv_seg* segs, int nseg, int Cout);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
  * pixels into `nsplit` partial slabs part[s][Cout][ntaps][Cin] (deterministic two-stage reduce).
@@ -302,6 +312,10 @@ typedef struct {
 int erd_gn_relu_fwd(const void* c, void* y, const float* gamma, const float* beta, double* stats_ws,
                     float* mean_rstd, int N, int64_t A, int C, int G, const erd_levels* lv, float eps,
                     int map_type /* of c, y */, erd_stream_t stream);
+/* ABI v6.  The normalisation pass of erd_gn_relu_fwd alone, for statistics that came from the producing convolution
+ * (erd_wino_conv3x3_x3_gn writes mean_rstd[N][nseg][G][2]): one launch, y = ReLU((c - mean) * rstd * gamma + beta). */
+int erd_gn_relu_apply(const void* c, void* y, const float* gamma, const float* beta, const float* mean_rstd, int N,
+                      int64_t A, int C, int G, const erd_levels* lv, int map_type /* of c, y */, erd_stream_t stream);
 int erd_gn_relu_bwd(const void* c, const void* dy, const float* gamma, const float* beta,
                     const float* mean_rstd, double* stats_ws, void* dc, float* dgamma, float* dbeta,
                     int N, int64_t A, int C, int G, const erd_levels* lv, int map_type /* of c, dy, dc */,

@@ -177,6 +177,41 @@ def test_groupnorm_relu_fwd_bwd(K):
     assert relerr(dg.cpu(), dg_ref) < 1e-4 and relerr(db.cpu(), db_ref) < 1e-4
 
 
+@pytest.mark.parametrize("sizes,N", [([(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)], 2), ([(25, 38), (13, 19), (7, 10), (4, 5), (2, 3)], 3)])
+def test_tower_layer_with_groupnorm_statistics_from_the_producer(K, sizes, N):
+    """gfl_head.py:158-177 as ONE fused unit (kernels.conv3x3_gn_relu_forward): the three-limb Winograd kernel's output stage accumulates
+    the (sum, sum of squares) of every item's 16 groups, a tiny launch folds them to (mean, 1 / std) -- erd_wino_conv3x3_x3_gn -- and
+    erd_gn_relu_apply normalises.  Against the three-pass form (conv, statistics pass, finalize, apply) on the same input: the convolution output bit for bit,
+    mean / rstd and the normalised output to 1e-6 (another summation order of the same fp32 values, f64 accumulation on both sides),
+    and the statistics against an fp64 evaluation of the convolution output itself."""
+    Cc = 256
+    A = sum(h * w for h, w in sizes)
+    x = G.randn(81, N, A, Cc).cuda()
+    w = (G.randn(82, Cc, 3, 3, Cc) * (2.0 / (9 * Cc)) ** 0.5).cuda()
+    gamma, beta = (0.5 + G.rand(83, Cc)).cuda(), G.randn(84, Cc, scale=0.3).cuda()
+    keep = K.GN_FUSED
+    try:
+        K.GN_FUSED = True
+        c1, y1, mr1 = K.conv3x3_gn_relu_forward(x, w, gamma, beta, sizes)
+        K.GN_FUSED = False
+        c0, y0, mr0 = K.conv3x3_gn_relu_forward(x, w, gamma, beta, sizes)
+    finally:
+        K.GN_FUSED = keep
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c0)
+    assert relerr(mr1.cpu(), mr0.cpu()) < 1e-6, relerr(mr1.cpu(), mr0.cpu())
+    assert float((y1 - y0).abs().max()) < 1e-5 * float(y0.abs().max())
+    off = 0
+    cd = c0.double().cpu()
+    for l, (h, ww) in enumerate(sizes):
+        blk = cd[:, off:off + h * ww].reshape(N, h * ww, 32, 8)
+        mean = blk.mean(dim=(1, 3))
+        var = blk.var(dim=(1, 3), unbiased=False)
+        assert relerr(mr1[:, l, :, 0].double().cpu(), mean) < 1e-5
+        assert relerr(mr1[:, l, :, 1].double().cpu(), 1.0 / torch.sqrt(var + 1e-5)) < 1e-5
+        off += h * ww
+
+
 def test_upsample_add_and_adjoint(K):
     N, Cc = 2, 256
     fine, coarse = G.randn(61, N, 10, 14, Cc), G.randn(62, N, 5, 7, Cc)

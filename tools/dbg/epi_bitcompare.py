@@ -69,7 +69,30 @@ def case(name, N, Cin, Cout, sizes, k, time_it=True):
     out[name] = res
 
 
+def case_s2(name, N, Cin, Cout, H, W, k):
+    """a stride-2 convolution through the implicit GEMM: forward (padding taps) and the merged-parity-class input gradient"""
+    p = k // 2
+    OH, OW = K.conv_out_size(H, k, 2, p), K.conv_out_size(W, k, 2, p)
+    x = torch.randn(N, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, k, k, Cin, device="cuda") * (2.0 / (k * k * Cin)) ** 0.5
+    wt = K.weight_transpose(w)
+    sc, sh = 0.5 + torch.rand(Cout, device="cuda"), 0.1 * torch.randn(Cout, device="cuda")
+    y = torch.full((N, OH, OW, Cout), float("nan"), device="cuda")
+    K.conv_forward([x], w, [y], k, 2, p, scale=sc, shift=sh, relu=True); torch.cuda.synchronize()
+    dy = torch.randn_like(y)
+    dx = torch.full_like(x, float("nan"))
+    K.conv_dgrad([dy], wt, [dx], k, 2, p); torch.cuda.synchronize()
+    out[name] = {"fwd": [y.cpu()], "dgrad": [dx.cpu()]}
+    times[name + "/fwd"] = timeit(lambda: K.conv_forward([x], w, [y], k, 2, p, scale=sc, shift=sh, relu=True))
+    times[name + "/dgrad"] = timeit(lambda: K.conv_dgrad([dy], wt, [dx], k, 2, p))
+
+
 case("igemm 256->128 37x53", 2, 256, 128, [(37, 53)], 1)
+case("igemm 64->64 3x3 57x75", 2, 64, 64, [(57, 75)], 3)
+case("igemm 68->256 3x3 levels", 2, 68, 256, [(25, 42), (13, 21)], 3, time_it=False)
+case_s2("igemm 128->128 3x3 s2 100x168", 4, 128, 128, 100, 168, 3)
+case_s2("igemm 256->256 3x3 s2 25x42", 4, 256, 256, 25, 42, 3)
+case_s2("igemm 256->512 1x1 s2 100x168", 4, 256, 512, 100, 168, 1)
 case("igemm 256->1024 50x84", 4, 256, 1024, [(50, 84)], 1)
 case("igemm 1024->256 50x84", 4, 1024, 256, [(50, 84)], 1)
 case("igemm 512->128 100x168", 4, 512, 128, [(100, 168)], 1)
