@@ -398,6 +398,16 @@ def main():
     seq = lambda j: batches[j % len(batches)]                    # one batch sequence across warm-up and timed steps, so that
     nb = lambda j: seq(j + 1) if ahead else None                 # the batch announced by the last warm-up step IS the first timed one
     warm = max(args.warmup, len(batches)) if args.mixed_res else args.warmup     # (every shape's graph is captured before the clock starts)
+    # data parallel: how many CUs do the whole-chip grids leave to RCCL's resident kernels?  Probed with the process group live, all ranks
+    # adopt one value (ERDTrainer.tune_cu_reserve); N = 1 is untouched (no probe, reserve 0).  ERD_CU_RESERVE=<n> pins it.
+    cu_reserve = {"cu_reserve": 0, "probed": False}
+    if dist.is_initialized() and dist.get_world_size() > 1 and not args.mixed_res:
+        if os.environ.get("ERD_CU_RESERVE"):
+            K.set_cu_reserve(int(os.environ["ERD_CU_RESERVE"]))
+            trainer.cu_reserve = int(os.environ["ERD_CU_RESERVE"])
+            cu_reserve = {"cu_reserve": trainer.cu_reserve, "probed": False, "note": "pinned by ERD_CU_RESERVE"}
+        else:
+            cu_reserve = trainer.tune_cu_reserve(batches)
     for j in range(warm):
         log = trainer.train_step(*seq(j), next_batch=nb(j))
     trainer.flush()
@@ -527,6 +537,7 @@ def main():
         out["collectives"] = {"backend": ({"nccl": "nccl (RCCL)", "gloo": "gloo (host-staged: correctness vehicle, not a performance path)"}[dist.get_backend()]
                                           if dist.is_initialized() else None),
                               "world_size": dist.get_world_size() if dist.is_initialized() else 1, "devices": devices,
+                              "cu_reserve": cu_reserve,
                               "launched_by": "bench.py self_launch -> torch.distributed.run" if os.environ.get("ERD_BENCH_CHILD") == "1"
                               else ("torch.distributed.run" if in_torchrun else "single process")}
         out["kernel_config"] = "stream-K implicit GEMM" if (K.STREAMK and (K.STREAMK_MULTIRANK or not K._multi_rank())) \

@@ -70,6 +70,8 @@ class Levels(C.Structure):
 P = C.c_void_p
 _SIGNATURES = {
     # name: argtypes (restype is always int unless noted)
+    "erd_set_cu_reserve": [i32],
+    "erd_usable_cus": [],
     "erd_conv_igemm": [C.POINTER(ConvDesc), P],
     "erd_conv_igemm_ws_bytes": [i32],
     "erd_to_bf16": [P, P, i64, P],

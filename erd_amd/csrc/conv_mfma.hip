@@ -1969,7 +1969,7 @@ int launch_igemm(const erd_conv_desc* d, hipStream_t st) {
     }
     // persistent stream-K grid when a workspace is supplied and tile-granular dispatch would leave a
     // ragged last round; otherwise one workgroup per tile.
-    const int slots = MINW * num_cus();
+    const int slots = MINW * erd::usable_cus(num_cus());
     int G = tiles;
     SkWs ws{nullptr, nullptr, xcd_order_enabled(), 0};
     // workspace layout (fixed, independent of this launch's tile count): [slabs: 2*slots*128*128 floats][tickets]
@@ -2115,7 +2115,7 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
         // Tile-parallel launches finish in whole dispatch rounds: pick the co-residency whose LAST round is fullest.
         // cost = rounds x (workgroups per CU / steady-state efficiency at that co-residency: 0.83 / 0.85 / 0.87 measured)
         static const int pick = getenv("ERD_IGEMM_PICK") ? atoi(getenv("ERD_IGEMM_PICK")) : 1;   // 0: always four per CU
-        const int64_t cus = num_cus();
+        const int64_t cus = erd::usable_cus(num_cus());
         const double c2 = (double)((tiles + 2 * cus - 1) / (2 * cus)) * (2.0 / 0.83);
         const double c3 = (double)((tiles + 3 * cus - 1) / (3 * cus)) * (3.0 / 0.85);
         const double c4 = (double)((tiles + 4 * cus - 1) / (4 * cus)) * (4.0 / 0.87);

@@ -368,7 +368,7 @@ int launch_thin(const erd_conv_desc* d, hipStream_t st) {
     // two workgroups per CU at K = 128 (226 registers, 68 KB of LDS); three at K = 64 (154 registers, 45 KB).  ERD_THIN_WGS: A/B aid
     static const int wgs_env = getenv("ERD_THIN_WGS") ? atoi(getenv("ERD_THIN_WGS")) : 0;
     const int per_cu = wgs_env > 0 ? wgs_env : (KS == 4 && RG == 1 ? 3 : 2);
-    const int G = (int)std::min<long long>(T, (long long)per_cu * num_cus_thin());
+    const int G = (int)std::min<long long>(T, (long long)per_cu * erd::usable_cus(num_cus_thin()));
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, *d, mtiles, nb, xcd ? 1 : 0);
     return erd::check_launch("conv_thin_x3");
 }

@@ -22,6 +22,23 @@ extern "C" const char* erd_csrc_sha(void) { return ERD_CSRC_SHA; }
 extern "C" __attribute__((weak)) int erd_probe_build_marker;
 extern "C" int erd_probe_build(void) { return &erd_probe_build_marker != nullptr ? erd_probe_build_marker : 0; }
 extern "C" const char* erd_last_error(void) { return erd::g_err; }
+namespace erd {
+static int g_cu_reserve = 0;
+int usable_cus(int physical) { return physical - g_cu_reserve >= 8 ? physical - g_cu_reserve : (physical < 8 ? physical : 8); }
+}  // namespace erd
+// ABI v6: CUs every later launch leaves free (persistent Winograd grids, stream-K grids, the activation-stationary kernel's grid, and --
+// through erd_usable_cus -- the caller's one-round weight-gradient splits); n < 0 only queries.  Returns the previous reserve.
+extern "C" int erd_set_cu_reserve(int n) {
+    const int prev = erd::g_cu_reserve;
+    if (n >= 0) erd::g_cu_reserve = n;
+    return prev;
+}
+extern "C" int erd_usable_cus(void) {
+    int dev = 0, n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    return erd::usable_cus(n);
+}
 
 namespace {
 

@@ -10,6 +10,10 @@
 namespace erd {
 
 void set_error(const char* fmt, ...);
+// CUs the persistent / one-round grids are sized for: the device's count minus erd_set_cu_reserve()'s reserve (0 by default).  Data
+// parallel ranks leave a few CUs to RCCL's resident kernels: a whole-chip static grid loses a dispatch round to any foreign workgroup
+// (profiles/r05_cu_theft_step.txt).  Workspace LAYOUTS keep using the physical count.
+int usable_cus(int physical);
 
 // conv_thin.hip: the activation-stationary three-limb kernel for 1x1 convolutions with Cin <= 128 (erd_conv_igemm dispatches to it)
 bool conv_thin_x3_ok(const erd_conv_desc* d);

@@ -1841,7 +1841,7 @@ int wino_plan(WinoDesc& d, const erd_conv_seg* segs, int nseg, bool x3, int Cout
         static int cached = 0;
         if (cached == 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cached = prop.multiProcessorCount;
-        ncu = cached > 0 ? cached : 256;
+        ncu = erd::usable_cus(cached > 0 ? cached : 256);
     }
     // 128 couts per item (wino_x3p_kernel) where the cout count allows it and it needs fewer dispatch rounds: an item of 128 couts
     // costs ~1.6 items of 64 (head towers: 2 800 / 1 400 items, 1.22x faster; 50 x 84 maps: 560 / 280 items on 256 CUs = 3 against 2

@@ -6,6 +6,7 @@ build's gloo is not relied upon to take device tensors); it blocks the host and 
 from __future__ import annotations
 
 import os
+from typing import Sequence
 
 import torch
 import torch.distributed as dist
@@ -64,3 +65,21 @@ def reduce_mean(tensor: torch.Tensor) -> torch.Tensor:
     out.div_(world_size())
     all_reduce_sum_(out)
     return out
+
+
+def agree_on_fastest(local_seconds: Sequence[float], group=None) -> int:
+    """Every rank timed the same candidates (ERDTrainer.tune_cu_reserve: warm-up steps at each CU reserve); all ranks must adopt the SAME
+    one or their grids differ for the rest of the run.  A step ends when the slowest rank ends, so a candidate is worth the MAX over the
+    ranks of its time; the index of the smallest maximum wins, the first one on ties.  Identical on all ranks by construction (one
+    all-reduce, then local arithmetic on identical numbers).  Without a process group: argmin of the local times."""
+    t = torch.tensor([float(v) for v in local_seconds], dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized():
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = t.to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        t = t.cpu()
+    best = 0
+    for i in range(1, t.numel()):
+        if float(t[i]) < float(t[best]):
+            best = i
+    return best

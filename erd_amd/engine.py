@@ -18,6 +18,7 @@ import math
 from typing import Dict, List, Optional, Sequence
 
 import os
+import time
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -324,6 +325,7 @@ class ERDTrainer:
         self.model = model
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
+        self.cu_reserve = 0                  # CUs the grids leave to RCCL's resident kernels (tune_cu_reserve; 0 at one rank)
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("ERDTrainer needs the model on the GPU (erd_amd has no CPU path)")
@@ -355,7 +357,13 @@ class ERDTrainer:
         # the update per gradient bucket, next to the rest of the backward pass (BucketedGradSync): SGD on the bucket's slice
         # of the flat buffers, then its BN folds and its prepared weight buffers, on a side stream; what is left at the step
         # boundary is the tail bucket (<= 4 MB).  At one rank too: the ~0.5 ms of update launches leave the critical path
-        self.bucket_update = (os.environ.get("ERD_BUCKET_UPDATE", "1") != "0" and not step_graph and self.prefold is not None
+        # Default: on in the fp32 modes (level at one rank: 113.35 against 113.23 img/s, three alternating pairs), OFF in the bf16 mode:
+        # there the step is close to host-bound (14.6 ms of issue work under a 19.1 ms step, profiles/r06_bf16_host_breakdown.txt) and
+        # the per-bucket launches issued from the autograd thread's hooks delay the backward pass's own launches -- 208.7 img/s with,
+        # 216.4 without, three alternating pairs on one box (profiles/r06_bf16_bucket_update_ab.txt; this is the "unexplained" 215 -> 208
+        # of round 5).  The bucket ALL-REDUCES stay asynchronous either way; ERD_BUCKET_UPDATE=0 / 1 overrides.
+        bu_default = "0" if K.COMPUTE == "bf16" else "1"
+        self.bucket_update = (os.environ.get("ERD_BUCKET_UPDATE", bu_default) != "0" and not step_graph and self.prefold is not None
                               and self.prep is not None)
         self.sync = None
         if self.distributed or self.bucket_update:
@@ -442,6 +450,38 @@ class ERDTrainer:
 
     def flush(self) -> None:
         self._apply_pending()
+
+    def tune_cu_reserve(self, batches, candidates: Sequence[int] = (0, 4, 8), steps: int = 3, timer=None) -> dict:
+        """Data parallel only (a no-op report at one rank): the kernels' persistent / stream-K / one-round grids are whole-chip static
+        grids, and RCCL's resident kernels take CUs away from them -- any resident foreign workgroup cost a whole dispatch round (-14 %,
+        profiles/r05_cu_theft_step.txt).  With the process group live, run `steps` real training steps at every candidate reserve
+        (kernels.set_cu_reserve: grids sized for CUs - reserve), time them, let all ranks agree on the candidate whose SLOWEST rank was
+        fastest (dist_utils.agree_on_fastest) and keep it.  `batches`: a sequence of (inputs, data_samples) to cycle through;
+        `timer(reserve) -> seconds` replaces the measurement (tests).  The steps are ordinary optimisation steps (warm-up iterations)."""
+        if self.world == 1:
+            return {"cu_reserve": 0, "probed": False, "note": "one rank: no resident collective kernels, the grids keep the whole chip"}
+        from .dist_utils import agree_on_fastest
+        secs = []
+        for r in candidates:
+            K.set_cu_reserve(int(r))
+            if timer is not None:
+                secs.append(float(timer(int(r))))
+                continue
+            self.train_step(*batches[0])         # descriptors / workspaces of this grid size
+            self.flush()
+            torch.cuda.synchronize(self.device)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.train_step(*batches[i % len(batches)])
+            self.flush()
+            torch.cuda.synchronize(self.device)
+            secs.append(time.perf_counter() - t0)
+        best = agree_on_fastest(secs)
+        K.set_cu_reserve(int(candidates[best]))
+        self.cu_reserve = int(candidates[best])
+        return {"cu_reserve": self.cu_reserve, "probed": True, "candidates": [int(c) for c in candidates],
+                "local_seconds_per_step": [round(t / max(steps, 1), 5) for t in secs], "steps_per_candidate": steps}
 
     def join_streams(self) -> None:
         """order every stream the trainer launches on (teacher side stream, tower / trailing weight-gradient streams, the update
@@ -540,6 +580,24 @@ class ERDTrainer:
                 with torch.cuda.stream(s):   # eager warm-up on the capture stream: workspaces, caches, auxiliary streams
                     for _ in range(2):
                         self._graph_body(st)
+                    # The warm-up has REGISTERED the step's derived-weight recipes (folded BN scales, transposed / limb-split weights,
+                    # Winograd weight images) but they only vouch for the parameters once the batched preparation has run -- until round
+                    # 6 the capture therefore recorded the ~250 per-use preparation launches of a step (42 bn_fold, 45 wino_weight_x3,
+                    # 58 weight_transpose, 73 split3, ...: `profiles/r06_graph_timelines.txt`) and replayed them every step, which is
+                    # most of why the replay was slower than eager.  Prepare now, as _apply_pending does after every update: the
+                    # captured step reads the prepared buffers by address.
+                    # Twice, with a warm-up pass in between: the input-gradient convolutions' Winograd / limb images are derived from
+                    # the PREPARED transposed weights, so their recipes can only be registered by a pass that already found those.
+                    for rnd in range(2):
+                        if self.prefold is not None:
+                            self.prefold.run()
+                        if self.prep is not None:
+                            if self.prefold is not None and self.prefold.valid[0]:
+                                self.prep.run()
+                            else:
+                                self.prep.invalidate()
+                        if rnd == 0:
+                            self._graph_body(st)
                 s.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=s):

@@ -912,10 +912,31 @@ WGRAD_X3_GENERIC = _os.environ.get("ERD_WGRAD_X3_GENERIC", "1") != "0"      # ..
 WGRAD_X3 = _os.environ.get("ERD_WGRAD_X3", "1") != "0"      # three-limb form of the three-tap weight gradient in the f32x3 mode (A/B aid)
 
 
+# CUs left to somebody else's resident kernels (RCCL under data parallelism): the library sizes its persistent / stream-K grids for the
+# rest (erd_set_cu_reserve), the one-round weight-gradient splits below follow (erd_usable_cus).  0 = the whole chip (every N = 1 run).
+CU_RESERVE = 0
+
+
+def set_cu_reserve(n: int) -> int:
+    """returns the previous reserve; cached launch descriptors are keyed on it"""
+    global CU_RESERVE
+    prev = int(_lib.load().erd_set_cu_reserve(int(n)))
+    CU_RESERVE = int(n)
+    return prev
+
+
+def _one_round(target: int) -> int:
+    """a split target that means `k workgroups per CU on every CU` (768 = 3 x 256, ...), scaled to the CUs in use"""
+    if CU_RESERVE == 0:
+        return target
+    usable = int(_lib.load().erd_usable_cus())
+    return max(1, target * usable // (usable + CU_RESERVE))
+
+
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * ntaps
     kt = (npix + 31) // 32
-    target = 1024 if _os.environ.get("ERD_WGRAD_VARIANT", "1") == "0" else int(_os.environ.get("ERD_WGRAD_TARGET", "1024"))
+    target = _one_round(1024 if _os.environ.get("ERD_WGRAD_VARIANT", "1") == "0" else int(_os.environ.get("ERD_WGRAD_TARGET", "1024")))
     want = max(1, target // tiles)          # ONE whole dispatch round of 4 workgroups per CU (measured: two rounds pay more partial-slab traffic than they gain; never a ragged extra round)
     return int(max(1, min(want, kt // 8 if kt >= 8 else 1, 512)))
 
@@ -935,7 +956,8 @@ def conv_wgrad_partials(xs: Sequence[Tensor], dzs: Sequence[Tensor], k: int, str
     xoff = tuple((x.data_ptr() - xb) // x.element_size() for x in xs)
     zoff = tuple((z.data_ptr() - zb) // z.element_size() for z in dzs)
     cache = _desc_cache()
-    key = ("wgrad", k, stride, pad, _geom(xs), _geom(dzs), xoff, zoff, COMPUTE, _os.environ.get("ERD_WGRAD_ROW3", "1"), WGRAD_X3, WGRAD_X3_GENERIC)
+    key = ("wgrad", k, stride, pad, _geom(xs), _geom(dzs), xoff, zoff, COMPUTE, _os.environ.get("ERD_WGRAD_ROW3", "1"), WGRAD_X3, WGRAD_X3_GENERIC,
+           CU_RESERVE)
     ent = cache.get(key)
     if ent is None:
         ent = cache[key] = _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff)
@@ -980,18 +1002,18 @@ def _wgrad_desc(xs, dzs, k, stride, pad, xoff, zoff):
     if row3 and d.limbs3:      # three-limb form: (128 | 64) output channels x 64 input channels x 3 taps per workgroup, one dispatch round
         bmr = 128 if Cout > 64 else 64
         groups = ((Cout + bmr - 1) // bmr) * ((Cin + 63) // 64) * 3
-        target = int(_os.environ.get("ERD_WGRAD_ROW3_X3_TARGET", "768"))      # three workgroups per CU: one dispatch round
+        target = _one_round(int(_os.environ.get("ERD_WGRAD_ROW3_X3_TARGET", "768")))      # three workgroups per CU: one dispatch round
         S = int(max(1, min(target // groups, row3 // 16 if row3 >= 16 else 1, 512)))
     elif row3:      # three taps per workgroup, two workgroups per CU: ONE whole dispatch round of (cout, cin, ky, split) workgroups
         # (measured best: 2 or 3 rounds pay more partial-slab traffic than they gain; a ragged extra round costs 15-40 %)
         bme = 64 if Cout <= 64 else (96 if Cout <= 96 else 128)        # rows of the kernel's output tile (erd_conv_wgrad)
         groups = ((Cout + bme - 1) // bme) * ((Cin + 127) // 128) * 3
-        target = int(_os.environ.get("ERD_WGRAD_ROW3_TARGET", "512"))
+        target = _one_round(int(_os.environ.get("ERD_WGRAD_ROW3_TARGET", "512")))
         S = int(max(1, min(target // groups, row3 // 16 if row3 >= 16 else 1, 512)))     # floor: whole dispatch rounds
     elif d.limbs3:      # three-limb form of the other layers: 128 x 128 channels, one tap per workgroup, one dispatch round of three per CU
         tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * k * k
         kt = (npix + 15) // 16
-        S = int(max(1, min(int(_os.environ.get("ERD_WGRAD_X3_TARGET", "768")) // tiles, kt // 8 if kt >= 8 else 1, 512)))
+        S = int(max(1, min(_one_round(int(_os.environ.get("ERD_WGRAD_X3_TARGET", "768"))) // tiles, kt // 8 if kt >= 8 else 1, 512)))
     else:
         S = _pick_nsplit(npix, Cout, Cin, k * k)
     d.nsplit = S

@@ -44,6 +44,13 @@ typedef void* erd_stream_t; /* hipStream_t */
 enum { ERD_F32 = 0, ERD_BF16 = 1 };
 
 int erd_abi_version(void);
+/* ABI v6.  CUs that every later launch leaves free: the persistent Winograd grids, the stream-K grids and the activation-stationary
+ * kernel's grid are sized for (device CUs - reserve) -- data-parallel ranks leave room for RCCL's resident kernels, which otherwise cost
+ * a whole-chip static grid a dispatch round (ERDTrainer.tune_cu_reserve picks the value with a short probe when a process group exists;
+ * default 0).  n < 0 only queries; returns the previous reserve.  erd_usable_cus: device CUs - reserve (the caller sizes its one-round
+ * weight-gradient splits with it). */
+int erd_set_cu_reserve(int n);
+int erd_usable_cus(void);
 /* 0 for the product build; 1 when the library contains a timing / accuracy / trace probe variant of a kernel (csrc/erd_probes.h):
  * such builds exist for same-box A/B measurements only and must never be the library a training run loads */
 int erd_probe_build(void);

@@ -69,6 +69,17 @@ def _worker(rank, world, port, q):
             ok = ok and sync.late_buckets >= 1 and any("issued late" in str(m.message) for m in wrn)
         else:
             ok = ok and sync.late_buckets == 0
+        # the CU reserve of the whole-chip grids (ERDTrainer.tune_cu_reserve): every rank times the candidates itself, all ranks must
+        # adopt the SAME one -- the candidate whose SLOWEST rank was fastest, not each rank's own favourite
+        from erd_amd.dist_utils import agree_on_fastest
+        cases = [([1.0, 0.9, 1.2], [1.0, 1.1, 0.8], 0),      # rank 0 alone would pick 1, rank 1 alone 2: max over ranks says 0
+                 ([1.3, 1.0, 1.1], [1.2, 1.05, 1.0], 1),
+                 ([1.0, 1.0, 1.0], [1.0, 1.0, 1.0], 0)]      # a tie keeps the first candidate (reserve 0)
+        for t0, t1, want in cases:
+            pick = agree_on_fastest(t0 if rank == 0 else t1)
+            both = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(both, torch.tensor([pick]))
+            ok = ok and pick == want and all(int(b) == want for b in both)
         q.put((rank, bool(ok), len(flat.buckets)))
     finally:
         dist.destroy_process_group()

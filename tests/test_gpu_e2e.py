@@ -476,7 +476,7 @@ def test_teacher_look_ahead_waits_for_the_producer_of_the_next_batch():
 
 
 @pytest.mark.parametrize("mode", ["f32x3", "bf16"])
-def test_per_bucket_update_equals_the_one_launch_update(mode):
+def test_per_bucket_update_equals_the_one_launch_update(mode, monkeypatch):
     """ERDTrainer updates per gradient bucket while the rest of the backward pass runs (engine.BucketedGradSync on_bucket: SGD on the
     bucket's slice, its BN folds, its prepared weights, on a side stream; only the tail bucket is left at the step boundary).  After
     every step the flat parameters and momenta are BIT-equal to ONE erd_sgd_momentum launch over the whole buffers applied to the
@@ -490,6 +490,7 @@ def test_per_bucket_update_equals_the_one_launch_update(mode):
         imgs, boxes, labels = O.synthetic_batch(2, 123, 153, 40, seed=seed)
         x, metas = O.preprocess(imgs)
         batches.append((x.cuda(), make_samples(boxes, labels, metas)))
+    monkeypatch.setenv("ERD_BUCKET_UPDATE", "1")      # (the bf16 mode's default is the update at the step boundary since round 6)
     K.set_compute(mode)
     try:
         model = build_erd(tsd, ssd)

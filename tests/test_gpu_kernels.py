@@ -212,6 +212,41 @@ def test_tower_layer_with_groupnorm_statistics_from_the_producer(K, sizes, N):
         off += h * ww
 
 
+def test_cu_reserve_resizes_the_grids_and_keeps_the_results(K):
+    """erd_set_cu_reserve (ERDTrainer.tune_cu_reserve under data parallelism): the persistent Winograd grid, the stream-K grid and the
+    one-round weight-gradient split are sized for (CUs - reserve).  Results: the tile-parallel and Winograd launches bit for bit (the
+    items are the same, only who runs them changes), stream-K and split-K launches to fp32 rounding (another partition of the K axis)."""
+    from erd_amd import _lib
+    lib = _lib.load()
+    full = int(lib.erd_usable_cus())
+    x = G.randn(91, 2, 50, 84, 256).cuda()
+    w3 = (G.randn(92, 256, 3, 3, 256) * 0.02).cuda()
+    w1 = (G.randn(93, 256, 1, 1, 1024) * 0.03).cuda()
+    x1 = G.randn(94, 2, 50, 84, 1024).cuda()
+    dy = G.randn(95, 2, 50, 84, 256).cuda()
+
+    def run():
+        y3 = torch.empty(2, 50, 84, 256, device="cuda")
+        K.conv_forward([x], w3, [y3], 3, 1, 1)                      # Winograd, persistent grid
+        y1 = torch.empty(2, 50, 84, 256, device="cuda")
+        K.conv_forward([x1], w1, [y1], 1, 1, 0)                     # K = 1024: stream-K
+        part, S = K.conv_wgrad_partials([x], [dy], 3, 1, 1)
+        dW = torch.empty_like(w3)
+        K.wgrad_reduce(part, S, w3, None, dW, False, None)
+        torch.cuda.synchronize()
+        return y3, y1, dW, S
+    try:
+        a = run()
+        assert K.set_cu_reserve(8) == 0 and int(lib.erd_usable_cus()) == full - 8
+        b = run()
+    finally:
+        K.set_cu_reserve(0)
+    assert int(lib.erd_usable_cus()) == full
+    assert torch.equal(a[0], b[0])
+    assert relerr(b[1].cpu(), a[1].cpu()) < 1e-6 and relerr(b[2].cpu(), a[2].cpu()) < 1e-6
+    assert b[3] <= a[3]                                              # fewer CUs: no more split-K siblings than before
+
+
 def test_upsample_add_and_adjoint(K):
     N, Cc = 2, 256
     fine, coarse = G.randn(61, N, 10, 14, Cc), G.randn(62, N, 5, 7, Cc)
