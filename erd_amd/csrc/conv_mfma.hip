@@ -40,7 +40,7 @@ __device__ __forceinline__ float pack_bf16(float a, float b) {
 
 constexpr int NTHREADS = 256;
 
-#ifdef ERD_IGEMM_TRACE      // debug builds only: per-workgroup phase cycles (tools/_igemm_trace.py)
+#ifdef ERD_IGEMM_TRACE      // debug builds only: per-workgroup phase cycles (tools/dbg/igemm_trace.py)
 __device__ unsigned long long g_igemm_trace[1024 * 8];
 #define IG_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define IG_ACC(slot, v) if (threadIdx.x == 0 && blockIdx.x < 1024) g_igemm_trace[blockIdx.x * 8 + slot] += __builtin_amdgcn_s_memtime() - v

@@ -65,6 +65,11 @@ def test_real_trainer_world2_follows_the_two_rank_oracle(tmp_path):
     for i, ((H, W, STEPS, bucket_mb, _), ref) in enumerate(zip(cases, refs)):
         res = [torch.load(os.path.join(tmp_path, f"case{i}_rank{r}.pt"), weights_only=False) for r in range(WORLD)]
         _check_case(WORLD, H, W, STEPS, bucket_mb, res, *ref)
+    # the CU reserve of the whole-chip grids (ERDTrainer.tune_cu_reserve, probed with the group live): one value on both ranks, set in
+    # the library, one of the candidates
+    rv = [torch.load(os.path.join(tmp_path, f"reserve_rank{r}.pt"), weights_only=False) for r in range(WORLD)]
+    assert all(v["probed"] for v in rv) and rv[0]["cu_reserve"] == rv[1]["cu_reserve"] and rv[0]["cu_reserve"] in (0, 8), rv
+    assert all(v["library_reserve"] == v["cu_reserve"] for v in rv), rv
 
 
 def _oracle_two_rank_trajectory(Wk, WORLD, H, W, STEPS, BS):

@@ -70,6 +70,26 @@ def run_case(rank, world, outdir, tag, H, W, steps, bucket_mb, BS):
     torch.cuda.empty_cache()
 
 
+def run_reserve_probe(rank, world, outdir):
+    """ERDTrainer.tune_cu_reserve with the process group live (the REAL path: real steps at every candidate, timed, one MAX all-reduce):
+    both ranks must come out with the same reserve, whatever their own timings said"""
+    import torch
+    from e2e_util import build_erd, f7_state_dicts, make_samples
+    from erd_amd import kernels as K
+    from erd_amd.engine import ERDTrainer
+    tsd, ssd = f7_state_dicts()
+    tr = ERDTrainer(build_erd(tsd, ssd), lr=LR, batch_size_per_gpu=1, auto_scale_lr=False, warmup_iters=0, bucket_mb=4)
+    x, b, l, m = rank_batches(rank, 224, 288, 1)[0]
+    try:
+        res = tr.tune_cu_reserve([(x.cuda(), make_samples(b, l, m))], candidates=(0, 8), steps=1)
+        res["library_reserve"] = K.CU_RESERVE
+    finally:
+        K.set_cu_reserve(0)
+    tr.flush()
+    torch.cuda.synchronize()
+    torch.save(res, os.path.join(outdir, f"reserve_rank{rank}.pt"))
+
+
 def main():
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[5:]]
@@ -82,6 +102,7 @@ def main():
     try:
         for i, (H, W, steps, bucket_mb, bs) in enumerate(cases):
             run_case(rank, world, outdir, "case%d" % i, H, W, steps, bucket_mb, bs)
+        run_reserve_probe(rank, world, outdir)
     finally:
         dist.destroy_process_group()
 

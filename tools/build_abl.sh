@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_abl.sh NAME [extra hipcc flags...]: a liberd_hip variant with the Winograd cycle trace compiled in
-# (erd_amd/lib/abl/liberd_hip_NAME.so; read back with tools/_trace.py through ERD_HIP_LIB)
+# (erd_amd/lib/abl/liberd_hip_NAME.so; read back with tools/dbg/trace.py through ERD_HIP_LIB)
 cd "$(dirname "$0")/../erd_amd/csrc"
 mkdir -p ../lib/abl
 n=$1; shift

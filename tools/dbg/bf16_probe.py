@@ -1,7 +1,7 @@
 """Scratch: forward bf16 (bf16-stored maps) implicit GEMM on five shapes, one line; run once per probe library
 (ERD_HIP_LIB=erd_amd/lib/abl/liberd_hip_NAME.so, built by tools/build_probe.sh NAME conv_mfma.hip -DERD_IG_NOMFMA ...): DESIGN 7a."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from erd_amd import kernels as K
 K.set_compute("bf16")

@@ -1,5 +1,5 @@
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import torch
 import test_gpu_fullsize as T

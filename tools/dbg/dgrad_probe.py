@@ -1,7 +1,7 @@
 """Scratch: 1x1 input-gradient launches (GEMM K = Cout of the forward conv), time + HBM rate; with a -DERD_IGEMM_TRACE library
 (tools/build_probe.sh igtrace conv_mfma.hip -DERD_IGEMM_TRACE) also the per-workgroup phase cycles: DESIGN 7a."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 from erd_amd import kernels as K, _lib
 N = 4

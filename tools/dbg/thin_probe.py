@@ -1,7 +1,7 @@
 """Scratch: forward implicit GEMM of four thin 1x1 layers, a K = 1024 one and a 3x3 one in the current compute mode
 (ERD_COMPUTE), one line; used with ERD_IG_LDS_PAD (one workgroup per CU) for the occupancy sensitivity of DESIGN 7a."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from erd_amd import kernels as K
 N = 4

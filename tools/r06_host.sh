@@ -12,7 +12,7 @@ ERD_COMPUTE=bf16 python tools/host_breakdown.py > $O/bf16_host_breakdown.txt 2>&
 for m in f32 bf16; do
   extra=""; [ $m = bf16 ] && extra="--compute bf16"
   rocprofv3 --kernel-trace -d /tmp/tl_${T}_$m -o tl -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing $extra > $O/${m}_tl_bench.log 2>&1
-  python tools/timeline.py $(find /tmp/tl_${T}_$m -name "*.db" | head -1) > $O/${m}_timeline.txt 2>&1
+  python tools/timeline.py $(find /tmp/tl_${T}_$m -name "*.db" | head -1) 5 > $O/${m}_timeline.txt 2>&1      # (step 5 of 9: a timed one)
 done
 tail -3 $O/*_host_breakdown.txt; head -20 $O/*_timeline.txt
 python - <<PY
