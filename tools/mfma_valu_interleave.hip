@@ -68,6 +68,7 @@ void run() {
 }
 int main() {
     run<0, 1, 0, 1>(); run<2, 8, 0, 1>(); run<3, 8, 0, 1>(); run<4, 8, 0, 1>(); run<6, 8, 0, 1>(); run<8, 8, 0, 1>();
+    run<5, 8, 0, 1>(); run<5, 8, 1, 1>(); run<5, 8, 1, 4>(); run<6, 8, 1, 1>();
     run<3, 1, 0, 1>(); run<3, 2, 0, 1>(); run<4, 2, 0, 1>(); run<4, 4, 0, 1>();
     run<3, 8, 1, 1>(); run<4, 8, 1, 1>();
     run<0, 1, 0, 4>(); run<3, 8, 0, 4>(); run<4, 8, 0, 4>(); run<3, 8, 1, 4>(); run<6, 8, 1, 4>();
