@@ -2073,7 +2073,8 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
                  : (any_msk ? launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, true, GL_>(d, st)        \
                             : launch_igemm<128, BN_, 4, 1, 32, 2, false, ST_, false, false, true, false, false, GL_>(d, st)))
         // operand slices by LDS-DMA (GL; ERD_IG_GLDS=0: through registers + ds_write, the form of rounds 3-5; bit-identical results)
-        static const int glds = getenv("ERD_IG_GLDS") ? atoi(getenv("ERD_IG_GLDS")) : 1;
+        const char* const e_glds = getenv("ERD_IG_GLDS");      // (read per launch: tests/test_gpu_f32x3.py flips it inside one process)
+        const int glds = e_glds ? atoi(e_glds) : 1;
         if (glds) {
             if (seg_taps_any) return ERD_X3_EPI(128, true, true);
             if (d->Cout <= 64) return ERD_X3_EPI(64, false, true);

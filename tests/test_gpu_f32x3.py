@@ -116,6 +116,54 @@ def test_f32x3_multilevel_and_streamk_launches(K):
         K.WINOGRAD = keep
 
 
+def test_f32x3_operand_slices_by_lds_dma_equal_register_staging_bit_for_bit(K, monkeypatch):
+    """Round 6: the three-limb implicit GEMM stages its K-slices by LDS-DMA (`buffer_load ... lds`, ERD_IG_GLDS=1, the default) instead of
+    global -> registers -> ds_write (ERD_IG_GLDS=0).  Same LDS image (the swizzle moves to the source address, padding taps and
+    channels past Cin arrive as zeros from out-of-range buffer offsets), same MFMA sequence: every form bit for bit -- a 3x3 / stride-2
+    convolution with padding on a ragged map, five levels in one launch (direct kernels), a stream-K launch (K = 2048), Cin = 68 (a
+    slice that ends inside a weight chunk), and a masked accumulating input gradient with column sums."""
+    K.set_compute("f32x3")
+    keep, K.WINOGRAD = K.WINOGRAD, False
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    A = sum(h * w for h, w in sizes)
+    x5 = G.randn(31, 2, A, 256).cuda()
+    w5 = (G.randn(32, 256, 3, 3, 256) * 0.02).cuda()
+    xs2 = G.randn(33, 2, 37, 53, 128).cuda()
+    ws2 = (G.randn(34, 256, 3, 3, 128) * 0.03).cuda()
+    xk = G.randn(35, 4, 25, 42, 2048).cuda()
+    wk = (G.randn(36, 512, 1, 1, 2048) * 0.02).cuda()
+    x68 = G.randn(37, 2, 13, 21, 68).cuda()
+    w68 = (G.randn(38, 256, 3, 3, 68) * 0.04).cuda()
+    dy = G.randn(39, 2, 37, 53, 512).cuda()
+    wd = (G.randn(40, 512, 1, 1, 128) * 0.05).cuda()
+    mask, base = G.randn(41, 2, 37, 53, 128).cuda(), G.randn(42, 2, 37, 53, 128).cuda()
+    sc, sh = (0.5 + G.rand(43, 256)).cuda(), G.randn(44, 256, scale=0.1).cuda()
+
+    def run():
+        o5 = torch.empty((2, A, 256), device="cuda")
+        K.conv_forward(K.level_views(x5, sizes), w5, K.level_views(o5, sizes), 3, 1, 1, scale=sc, shift=sh, relu=True)
+        o2 = torch.empty((2, 19, 27, 256), device="cuda")
+        K.conv_forward([xs2], ws2, [o2], 3, 2, 1)
+        ok = torch.empty((4, 25, 42, 512), device="cuda")
+        K.conv_forward([xk], wk, [ok], 1, 1, 0)
+        o68 = torch.empty((2, 13, 21, 256), device="cuda")
+        K.conv_forward([x68], w68, [o68], 3, 1, 1)
+        acc = base.clone()
+        cs = torch.zeros(8, 128, device="cuda")
+        K.conv_dgrad([dy], K.weight_transpose(wd), [acc], 1, 1, 0, accumulate=True, relu_mask=[mask], colsum=cs)
+        torch.cuda.synchronize()
+        return o5, o2, ok, o68, acc
+    try:
+        monkeypatch.setenv("ERD_IG_GLDS", "0")
+        ref = run()
+        monkeypatch.setenv("ERD_IG_GLDS", "1")
+        got = run()
+    finally:
+        K.WINOGRAD = keep
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert not torch.isnan(b).any() and torch.equal(a, b), i
+
+
 @pytest.mark.parametrize("Cin,Cout,sizes", [(256, 256, [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]), (128, 128, [(26, 30)]),
                                              (256, 80, [(13, 21), (7, 11)]), (256, 68, [(13, 21)]), (512, 512, [(9, 17)]),
                                              (64, 64, [(20, 36)])])
