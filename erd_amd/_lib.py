@@ -86,7 +86,8 @@ _SIGNATURES = {
     "erd_wino_weights_x3": [P, P, i32, i32, i32, P],
     "erd_wino_conv3x3_x3": [P, i32, P, i32, i32, P, P, i32, P, i32, P, P],
     "erd_wino_x3_couts_per_item": [P, i32, i32],
-    "erd_wino_conv3x3_x3_gn": [P, i32, P, i32, i32, P, P, i32, P, P, C.c_size_t, P, f32, P],
+    "erd_wino_conv3x3_x3_gn": [P, i32, P, i32, i32, P, P, i32, P, P, C.c_size_t, P],
+    "erd_wino_gn_finalize": [P, i32, i32, P, P, f32, P],
     "erd_wino_x3_gn_ws_bytes": [P, i32, i32],
     "erd_conv_wgrad": [C.POINTER(WgradDesc), P],
     "erd_wgrad_row3_slices": [C.POINTER(WgradDesc)],

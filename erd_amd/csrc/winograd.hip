@@ -1857,7 +1857,7 @@ int wino_plan(WinoDesc& d, const erd_conv_seg* segs, int nseg, bool x3, int Cout
 
 int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* U3, int Cin, int Cout, const float* scale,
                 const float* shift, int relu, float* colsum, int colsum_copies, int* sched, hipStream_t stream,
-                float* gn_part = nullptr, size_t gn_part_bytes = 0, float* gn_mean_rstd = nullptr, float gn_eps = 0.f) {
+                float* gn_part = nullptr, size_t gn_part_bytes = 0) {
     ERD_REQUIRE(segs && (U || U3) && nseg >= 1 && nseg <= ERD_MAX_SEG, "wino: bad args");
     ERD_REQUIRE(Cin % KS == 0 && Cin >= 4 * KS && Cout > 0, "wino: Cin=%d must be a multiple of %d and at least %d", Cin, KS, 4 * KS);
     WinoDesc d;
@@ -1886,13 +1886,11 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
     static const int persist = getenv("ERD_WINO_PERSIST") ? atoi(getenv("ERD_WINO_PERSIST")) : 1;
     const int grid = persist ? (d.nitems < ncu ? d.nitems : ncu) : d.nitems;
     if (persist != 1) d.sched = nullptr;
-    int gn_nmax = 0;
     if (gn_part) {
-        ERD_REQUIRE(Cout % 8 == 0 && gn_mean_rstd, "wino: GroupNorm statistics need Cout %% 8 == 0 and a mean_rstd buffer");
+        ERD_REQUIRE(Cout % 8 == 0, "wino: GroupNorm statistics need Cout %% 8 == 0");
         ERD_REQUIRE(phased && !colsum, "wino: the fused GroupNorm statistics need the 128-couts-per-item kernel (erd_wino_x3_couts_per_item) and no column sums");
         for (int q = 0; q < nseg; ++q) {
             ERD_REQUIRE(!segs[q].res && !segs[q].mask, "wino: the fused GroupNorm statistics serve plain convolutions (segment %d has a residual / mask)", q);
-            gn_nmax = std::max(gn_nmax, segs[q].N);
         }
         ERD_REQUIRE(gn_part_bytes >= (size_t)d.nitems * 32 * sizeof(float), "wino: GroupNorm partial-sum workspace too small (%zu bytes for %d items)",
                     gn_part_bytes, d.nitems);
@@ -1905,10 +1903,6 @@ int wino_launch(const erd_conv_seg* segs, int nseg, const float* U, const void* 
             attrp_done = true;
         }
         hipLaunchKernelGGL(wino_x3p_kernel, dim3((unsigned)grid), dim3(512), lds, stream, d);
-        if (gn_part) {
-            hipLaunchKernelGGL(wino_gn_finalize_kernel, dim3((unsigned)(Cout / BNP), (unsigned)nseg, (unsigned)gn_nmax), dim3(512), 0, stream, d,
-                               gn_mean_rstd, gn_eps);
-        }
         return erd::check_launch("wino_conv3x3_x3p");
     }
     if (U3) {
@@ -1965,16 +1959,32 @@ extern "C" int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const voi
     return wino_launch(segs, nseg, nullptr, U3, Cin, Cout, scale, shift, relu, colsum, colsum_copies, sched, (hipStream_t)stream);
 }
 
-/* ABI v6: erd_wino_conv3x3_x3 on a plain convolution (no residual / mask / column sums) that ALSO produces the GroupNorm statistics of its
- * result: the output stage of every item writes its 16 groups' (sum, sum of squares) to gn_part (workspace, erd_wino_x3_gn_ws_bytes), a
- * second tiny launch folds them to mean_rstd[N][nseg][Cout / 8][2] (float: mean, 1 / sqrt(var + eps); N = the largest segment's).
- * Needs the 128-couts-per-item kernel (erd_wino_x3_couts_per_item == 128).  erd_gn_relu_apply consumes mean_rstd. */
+/* ABI v6: erd_wino_conv3x3_x3 on a plain convolution (no residual / mask / column sums) that ALSO produces the raw material of the
+ * GroupNorm statistics of its result: the output stage of every item writes its 16 groups' (sum, sum of squares) to gn_part (workspace,
+ * erd_wino_x3_gn_ws_bytes).  Needs the 128-couts-per-item kernel (erd_wino_x3_couts_per_item == 128).  erd_wino_gn_finalize folds the
+ * partial sums to mean_rstd, erd_gn_relu_apply consumes that. */
 extern "C" int erd_wino_conv3x3_x3_gn(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout, const float* scale,
                                       const float* shift, int relu, int* sched, float* gn_part, size_t gn_part_bytes,
-                                      float* mean_rstd, float eps, erd_stream_t stream) {
-    ERD_REQUIRE(U3 && gn_part && mean_rstd, "wino_x3_gn: null U3 / gn_part / mean_rstd");
-    return wino_launch(segs, nseg, nullptr, U3, Cin, Cout, scale, shift, relu, nullptr, 0, sched, (hipStream_t)stream, gn_part,
-                       gn_part_bytes, mean_rstd, eps);
+                                      erd_stream_t stream) {
+    ERD_REQUIRE(U3 && gn_part, "wino_x3_gn: null U3 / gn_part");
+    return wino_launch(segs, nseg, nullptr, U3, Cin, Cout, scale, shift, relu, nullptr, 0, sched, (hipStream_t)stream, gn_part, gn_part_bytes);
+}
+
+/* the fold: mean_rstd[N][nseg][Cout / 8][2] = (mean, 1 / sqrt(var + eps)) from the items' partial sums of the launch with the same segments */
+extern "C" int erd_wino_gn_finalize(const erd_conv_seg* segs, int nseg, int Cout, const float* gn_part, float* mean_rstd, float eps,
+                                    erd_stream_t stream) {
+    ERD_REQUIRE(segs && gn_part && mean_rstd && Cout % BNP == 0, "wino_gn_finalize: bad args");
+    WinoDesc d;
+    int ncu = 0, nmax = 0;
+    bool phased = false;
+    if (const int rc = wino_plan(d, segs, nseg, true, Cout, ncu, phased)) return rc;
+    ERD_REQUIRE(phased, "wino_gn_finalize: these segments run on the 64-couts-per-item kernel (no partial sums exist)");
+    d.Cout = Cout;
+    d.gn_part = const_cast<float*>(gn_part);
+    for (int q = 0; q < nseg; ++q) nmax = std::max(nmax, segs[q].N);
+    hipLaunchKernelGGL(wino_gn_finalize_kernel, dim3((unsigned)(Cout / BNP), (unsigned)nseg, (unsigned)nmax), dim3(512), 0, (hipStream_t)stream, d,
+                       mean_rstd, eps);
+    return erd::check_launch("wino_gn_finalize");
 }
 
 extern "C" size_t erd_wino_x3_gn_ws_bytes(const erd_conv_seg* segs, int nseg, int Cout) {

