@@ -67,11 +67,13 @@ def reduce_mean(tensor: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def agree_on_fastest(local_seconds: Sequence[float], group=None) -> int:
+def agree_on_fastest(local_seconds: Sequence[float], group=None, margin: float = 0.015) -> int:
     """Every rank timed the same candidates (ERDTrainer.tune_cu_reserve: warm-up steps at each CU reserve); all ranks must adopt the SAME
     one or their grids differ for the rest of the run.  A step ends when the slowest rank ends, so a candidate is worth the MAX over the
-    ranks of its time; the index of the smallest maximum wins, the first one on ties.  Identical on all ranks by construction (one
-    all-reduce, then local arithmetic on identical numbers).  Without a process group: argmin of the local times."""
+    ranks of its time; a later candidate replaces an earlier one only when it is faster by more than `margin` (1.5 %: three-step
+    timings are that noisy, and the first candidate -- reserve 0, the configuration every N = 1 number was taken with -- is the default),
+    ties keep the earlier one.  Identical on all ranks by construction (one all-reduce, then local arithmetic on identical numbers).
+    Without a process group: the same rule on the local times."""
     t = torch.tensor([float(v) for v in local_seconds], dtype=torch.float64)
     if dist.is_available() and dist.is_initialized():
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -80,6 +82,6 @@ def agree_on_fastest(local_seconds: Sequence[float], group=None) -> int:
         t = t.cpu()
     best = 0
     for i in range(1, t.numel()):
-        if float(t[i]) < float(t[best]):
+        if float(t[i]) < (1.0 - margin) * float(t[best]):
             best = i
     return best

@@ -103,7 +103,10 @@ def test_thin_input_gradient_forms(K, N, Cin, Cout, H, W):
 
     (a, a2, ca, a3), (b, b2, cb, b3) = both(K, run)
     assert torch.equal(a, b) and torch.equal(a2, b2) and torch.equal(a3, b3)
-    assert torch.allclose(ca, cb, rtol=1e-5, atol=1e-4)                     # (float atomics: order-dependent in both kernels)
+    # (float atomics, order-dependent in both kernels: two summation orders of up to 67 200 fp32 values per channel.  Round 6 measured the
+    #  margin of the old bound -- atol 1e-4 -- on the largest case: worst |difference| / tolerance 1.07 over 40 rounds with dx bit-equal in
+    #  every one (tools/dbg/thin_margin.py): one of the round's full-suite runs failed here.  1e-3 is still a thousandth of one pixel row.)
+    assert torch.allclose(ca, cb, rtol=1e-5, atol=1e-3)
     assert float((to_nchw(a).double() - ref).norm() / ref.norm()) < 3e-7
     assert float((to_nchw(a2).double() - ref_m).norm() / ref_m.norm()) < 3e-7
     assert torch.allclose(ca.cpu().double(), ref_m.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
