@@ -230,6 +230,13 @@ class Runner:
                                   base_batch_size=asl.get("base_batch_size", 16), batch_size_per_gpu=bs,
                                   auto_scale_lr=bool(asl.get("enable", False)), warmup_iters=0)
         self.trainer.lr_factor = self.schedule.iter_factor          # warm-up comes from the config's LinearLR
+        # data parallel: CUs the whole-chip grids leave to RCCL's resident kernels.  The launcher does not PROBE (ERDTrainer.
+        # tune_cu_reserve spends optimisation steps on one batch: bench.py does that and prints `collectives.cu_reserve`); it takes
+        # the value from ERD_CU_RESERVE, the same on every rank (tools/dist_train.sh passes the environment on)
+        if self.trainer.world > 1 and os.environ.get("ERD_CU_RESERVE"):
+            from . import kernels as _K
+            _K.set_cu_reserve(int(os.environ["ERD_CU_RESERVE"]))
+            self.trainer.cu_reserve = int(os.environ["ERD_CU_RESERVE"])
         self.max_epochs = int(cfg.train_cfg.max_epochs)
         hooks = cfg.get("default_hooks") or {}
         self.log_interval = int((hooks.get("logger") or {}).get("interval", 50))
