@@ -211,7 +211,19 @@ def pmc_provenance(compute: str = "f32") -> dict:
         f = _pmc_file(suffix, compute)
         if f is not None:
             shas["profiles/" + os.path.basename(f)] = json.load(open(f)).get("_meta", {}).get("csrc_sha256")
-    return {"pmc_source_sha": shas, "library_csrc_sha": live, "pmc_stale": (not shas) or any(v != live for v in shas.values())}
+    return {"pmc_source_sha": shas, "library_csrc_sha": live, "pmc_stale": (not shas) or any(v != live for v in shas.values()),
+            "compiler": _hipcc_version()}
+
+
+def _hipcc_version() -> str:
+    """the compiler the image would build the library with (the source sha covers sources and flags -- csrc/Makefile -- not the compiler)"""
+    import subprocess
+    try:
+        out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], capture_output=True, text=True, timeout=30).stdout
+        lines = [l.strip() for l in out.splitlines() if l.strip()]
+        return "; ".join(l for l in lines if l.startswith(("HIP version", "AMD clang version")))[:200] or (lines[0][:200] if lines else "unknown")
+    except Exception:
+        return "unknown"
 
 
 def pmc_traffic_per_launch(symbol_prefix: str, compute: str = "f32"):
