@@ -32,3 +32,47 @@ def test_thin_kernel_stores_back_to_back_without_scratch_or_packed_fp32(tmp_path
     for n, v in kernels.items():
         assert v["stores"] == 4 and v["serialized"] == 0, (n, v)
         assert v["scratch"] == 0 and v["packed_f32"] == 0, (n, v)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_lds_dma_kernels_own_m0_and_keep_their_k_loop_free_of_full_waits(tmp_path):
+    """Round 6: the three-limb implicit GEMM stages its operand slices by LDS-DMA issued from INLINE ASSEMBLY (`buffer_load_dwordx4 ... offen lds`,
+    conv_mfma.hip `glds16`): the statement writes M0 -- a register the compiler reserves but does not preserve around asm -- and its loads are
+    absent from the compiler's wait bookkeeping.  Both are safe only under invariants the ISA shows: (i) nothing the COMPILER emitted in
+    these kernels reads or writes M0 (so the asm's M0 can neither clobber nor be clobbered), (ii) no scratch memory (a spill reload is a
+    vector load: its wait would cover the DMA in flight), (iii) every instantiation carries its DMA statements (ten per K-slice site:
+    four activation + six weight-plane loads at 128 x 128, four + three at 128 x 64) and the explicit `s_waitcnt vmcnt(0)` in front of the
+    slice barrier."""
+    import re
+    out = tmp_path / "conv_mfma.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-S", "--cuda-device-only",
+                        "-o", str(out), "conv_mfma.hip"], cwd=os.path.join(ROOT, "erd_amd", "csrc"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = open(out).read()
+    seen = 0
+    for m in re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)^\s*\.end_amdhsa_kernel", s, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if "offen lds" not in body:
+            continue
+        seen += 1
+        assert "conv_igemm_kernel" in name, name
+        in_asm, dma, asm_waits = False, 0, 0
+        for line in body.split("\n"):
+            t = line.strip()
+            if "#ASMSTART" in t:
+                in_asm = True
+            elif "#ASMEND" in t:
+                in_asm = False
+            elif t and not t.startswith(";"):
+                if in_asm:
+                    dma += "offen lds" in t
+                    asm_waits += t.startswith("s_waitcnt vmcnt(0)")
+                    if "m0" in t:
+                        assert t.startswith("s_mov_b32 m0") or t.startswith("s_add_i32 m0"), (name, t)
+                else:
+                    assert not re.search(r"\bm0\b", t), (name, t)              # (i)
+                    assert not t.startswith("scratch_"), (name, t)              # (ii)
+        assert dma in (14, 20), (name, dma)                                       # (iii): prologue + K-loop site, 128 x 64 / 128 x 128 tiles
+        assert asm_waits >= 2, (name, asm_waits)
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0, name
+    assert seen == 12, seen        # {128 x 128, 128 x 128 with per-segment taps, 128 x 64} x (residual, mask) presence
