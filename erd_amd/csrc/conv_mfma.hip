@@ -2037,6 +2037,7 @@ extern "C" int erd_conv_igemm(const erd_conv_desc* d, erd_stream_t stream) {
     static const int variant = getenv("ERD_IGEMM_VARIANT") ? atoi(getenv("ERD_IGEMM_VARIANT")) : 0;   // tuning aid
     bool seg_taps_any = false;
     for (int s = 0; s < d->nseg; ++s) seg_taps_any |= d->seg[s].ntaps > 0;
+    if (d->w_bf16 && erd::conv_thin_bf16_ok(d)) return erd::conv_thin_bf16(d, st);      // thin 1x1 layers on bf16 maps: activations stationary
     if (d->w_bf16) {    // bf16 matrix cores: the loaders, not the MFMAs, set the pace -> the plain 2-workgroup variant
         // storage of the maps (in_bf16 / out_bf16) picks the instantiation: 0 = fp32 in HBM, 1 = bf16 in HBM
 #define ERD_BF_LAUNCH(AB_, OB_)                                                                       \

@@ -338,6 +338,208 @@ __global__ __launch_bounds__(256, 2) void conv_thin_x3_kernel(const erd_conv_des
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------------------
+// The same loop nest for the bf16 mode (BASELINE configs[2]: bf16 multiplicands, exact products, fp32 accumulation; maps STORED as bf16;
+// round 6).  There the stream-K kernel's thin launches are all set-up and epilogue (128 -> 512 on 100 x 168: 53 us
+// of which 47 remain with its K loop's loads removed, EXPERIMENTS 7a) next to ~17 us of HBM traffic.  One limb: a lane's 16-byte load
+// of eight stored bf16 channels IS its MFMA A-fragment (no conversion, K / 16 x 4 registers for the whole reduction); one weight plane
+// (erd_conv_desc::w_bf16) through the LDS ring, ONE MFMA per k16 step in the stream-K kernel's order -- bit-identical results
+// (tests/test_gpu_thin.py) --; the block's epilogue as above with 8-byte row pieces (four bf16 channels), residual / mask rows stored
+// bf16 too.  36 KB of LDS, ~100 registers: four workgroups per CU.  With one limb the whole reduction of K = 256 fits as well (64
+// fragment registers, 32 KB of ring: three workgroups per CU): layer3's expanding convolutions, the input gradients of its reducing
+// ones, layer2's first block -- launches that are set-up and epilogue in the stream-K kernel's bf16 form too.
+// KH = 2 (K = 512): a cout block's weights pass through the ring in two K-halves (16 KB each) -- the ring stays at 32 KB, the 128 fragment
+// registers of the whole reduction leave room for two workgroups per CU.
+template <int KS, bool RES, bool MSK, int KH = (KS > 16 ? 2 : 1)>
+__global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS > 16 || (RES && MSK) ? 2 : 3))) void conv_thin_bf16_kernel(const erd_conv_desc p, const int mtiles, const int nb, const int xcd_order) {
+    constexpr int K = KS * 16;
+    constexpr int KU = K / KH, KSU = KS / KH;          // reduction length / k16 steps of one ring unit
+    constexpr int CPR = KU / 8;                        // 16-byte chunks (8 bf16) per weight row of a unit
+    constexpr int UNIT_B = 32 * KU * 2;                // one cout block (one K-half of it) of the one weight plane
+    constexpr int NQ = (UNIT_B / 16 + 255) / 256;      // 16-byte loads per thread and block (2 at K = 128, 1 at K = 64)
+    constexpr int NCH = UNIT_B / 16;                   // chunks of a block (512 / 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                                     // [2][UNIT_B]
+    float* stage = reinterpret_cast<float*>(smem + 2 * UNIT_B);            // [4 waves][32][SLD]
+    TRow* rows = reinterpret_cast<TRow*>(smem + 2 * UNIT_B + 4 * 32 * SLD * 4);   // [128]
+    float* red = reinterpret_cast<float*>(rows + 128);                   // [2][4 waves][32]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;
+    int wg = blockIdx.x;
+    if (xcd_order) {
+        const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long T = (long long)mtiles * nb;
+    const long long t_begin = T * wg / G, t_end = T * (wg + 1) / G;
+    if (t_begin >= t_end) return;
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_bf16), 0, (int)((long long)p.Cout * p.wrow * 2), 0x00020000);
+    unsigned w_off[NQ];
+    int l_off[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = q * 256 + tid;
+        const int row = idx / CPR, ch = idx - row * CPR;
+        w_off[q] = idx < NCH ? (unsigned)(row * p.wrow + p.wk[0] + ch * 8) * 2u : OOB;
+        const int sw = CPR >= 16 ? (ch ^ (row & 15)) : (ch ^ ((row >> 1) & 7));      // (rows of 256 B and more: the low four chunk bits)
+        l_off[q] = idx < NCH ? (row * CPR + sw) * 16 : -1;
+    }
+    u4v rb[NQ];
+    auto load_unit = [&](int cbn, int khn) {
+        const unsigned cb_off = (unsigned)(cbn * 32 * p.wrow + khn * KU) * 2u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rb[q] = buf_load16(rs_w, w_off[q] == OOB ? OOB : w_off[q] + cb_off);
+    };
+    auto store_unit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (l_off[q] >= 0) *reinterpret_cast<u4v*>(ring + buf * UNIT_B + l_off[q]) = rb[q];
+    };
+
+    u4v ah[KS];                            // the wave's activation rows: the stored bf16 values ARE the fragments
+    int pend_cb = -1;
+    float* const cs_row = p.colsum ? p.colsum + (p.colsum_copies > 1 ? (int64_t)(blockIdx.x & (p.colsum_copies - 1)) * p.Cout : 0) : nullptr;
+
+    load_unit((int)(t_begin % nb), 0);
+    int it = 0, ib = 0;                    // ring steps / cout blocks done by this workgroup (parities of the LDS ring / of `red`)
+#pragma unroll 1
+    for (int mt = (int)(t_begin / nb); (long long)mt * nb < t_end; ++mt) {
+        int seg_i = 0, mt_in_seg = mt;
+#pragma unroll 1
+        for (; seg_i < p.nseg - 1; ++seg_i) {
+            const int M = p.seg[seg_i].N * p.seg[seg_i].GH * p.seg[seg_i].GW;
+            const int tiles = (M + 127) / 128;
+            if (mt_in_seg < tiles) break;
+            mt_in_seg -= tiles;
+        }
+        const erd_conv_seg& sg = p.seg[seg_i];
+        __syncthreads();               // the previous tile's epilogues are done with the row table
+        if (tid < 128) {
+            const int GHW = sg.GH * sg.GW, M = sg.N * GHW, m = mt_in_seg * 128 + tid;
+            TRow ri;
+            ri.in_off = -1;
+            ri.out_off = -1;
+            if (m < M) {
+                const int n = m / GHW, rem = m - n * GHW, a = rem / sg.GW, b = rem - a * sg.GW;
+                const int ih = a * p.in_stride + p.dy[0], iw = b * p.in_stride + p.dx[0];
+                if ((unsigned)ih < (unsigned)sg.IH && (unsigned)iw < (unsigned)sg.IW)
+                    ri.in_off = (int)(n * sg.in_nstride) + (ih * sg.IW + iw) * p.Cin;
+                ri.out_off = (int)(n * sg.out_nstride) + ((a * p.out_stride + p.oy) * sg.OW + (b * p.out_stride + p.ox)) * p.Cout;
+            }
+            rows[tid] = ri;
+        }
+        __syncthreads();
+        {
+            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+                erd::uniform_ptr(const_cast<float*>(sg.in)), 0, erd::uniform_int((int)((long long)sg.N * sg.in_nstride * 2)), 0x00020000);
+            const int ibase = rows[wave * 32 + li].in_off;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) ah[s] = buf_load16(rs_in, ibase < 0 ? OOB : (unsigned)(ibase + 16 * s + 8 * h) * 2u);
+        }
+        const int out_bytes = erd::uniform_int((int)((long long)sg.N * sg.out_nstride * 2));
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(erd::uniform_ptr(sg.out), 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(erd::uniform_ptr(const_cast<float*>(RES ? sg.res : sg.out)), 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(erd::uniform_ptr(const_cast<float*>(MSK ? sg.mask : sg.out)), 0, out_bytes, 0x00020000);
+        const bool has_alpha = sg.alpha != nullptr;
+        const float alpha = has_alpha ? *sg.alpha : 1.f;
+        const long long tile_t0 = (long long)mt * nb;
+        const int cb_begin = (int)(t_begin > tile_t0 ? t_begin - tile_t0 : 0), cb_end = (int)(t_end < tile_t0 + nb ? t_end - tile_t0 : nb);
+#pragma unroll 1
+        for (int cb = cb_begin; cb < cb_end; ++cb, ++ib) {
+            const long long t = tile_t0 + cb;
+            store_unit(it & 1);
+            if (KH > 1) load_unit(cb, 1); else if (t + 1 < t_end) load_unit(cb + 1 == nb ? 0 : cb + 1, 0);
+            __syncthreads();
+            if (pend_cb >= 0 && tid < 32) {
+                const float* rp = red + ((ib - 1) & 1) * 128;
+                atomicAdd(cs_row + pend_cb * 32 + tid, (rp[tid] + rp[32 + tid]) + (rp[64 + tid] + rp[96 + tid]));
+            }
+            const int c4 = lane & 7, rsub = lane >> 3;
+            const int co = cb * 32 + c4 * 4;
+            unsigned off[4];
+            uint2 pfr[4], pfm[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = rows[wave * 32 + q * 8 + rsub].out_off;
+                off[q] = o < 0 ? OOB : (unsigned)(o + co) * 2u;
+                if constexpr (RES) pfr[q] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, off[q], 0, 0));
+                if constexpr (MSK) pfm[q] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_msk, off[q], 0, 0));
+            }
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+            if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + co);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            bf16x8 wf[2];
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                if (kh > 0) {              // the block's second K-half: the ring's other buffer (its loads were requested a half ago)
+                    store_unit(it & 1);
+                    if (t + 1 < t_end) load_unit(cb + 1 == nb ? 0 : cb + 1, 0);
+                    __syncthreads();
+                }
+                const char* Bb = ring + (it & 1) * UNIT_B;
+                auto read_w = [&](int s, int slot) {
+                    const int ch = 2 * s + h;
+                    const int sw = CPR >= 16 ? (ch ^ (li & 15)) : (ch ^ ((li >> 1) & 7));
+                    wf[slot] = *reinterpret_cast<const bf16x8*>(Bb + (li * CPR + sw) * 16);
+                };
+                read_w(0, 0);
+#pragma unroll
+                for (int s = 0; s < KSU; ++s) {
+                    if (s + 1 < KSU) read_w(s + 1, (s + 1) & 1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[kh * KSU + s]), wf[s & 1], acc, 0, 0, 0);
+                }
+                ++it;
+            }
+            float* wst = stage + wave * 32 * SLD;
+            float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wst[((r & 3) + 8 * (r >> 2) + 4 * h) * SLD + li] = acc[r];
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = *reinterpret_cast<const float4*>(wst + (q * 8 + rsub) * SLD + c4 * 4);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (has_alpha) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
+                if constexpr (RES) { const float4 rv = erd::unpack4_bf16(pfr[q]); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if constexpr (MSK) {
+                    const float4 mv = erd::unpack4_bf16(pfm[q]);
+                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                    v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                }
+                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                const uint2 pk = erd::pack4_bf16(v);
+                u2v o2; o2.x = pk.x; o2.y = pk.y;
+                __builtin_amdgcn_raw_buffer_store_b64(o2, rs_out, off[q], 0, 0);
+                if (off[q] != OOB) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (cs_row) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                    csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+                }
+                if (lane < 8) *reinterpret_cast<float4*>(red + (ib & 1) * 128 + wave * 32 + lane * 4) = csum;
+                pend_cb = cb;
+            }
+        }
+    }
+    if (pend_cb >= 0) {
+        __syncthreads();
+        if (tid < 32) {
+            const float* rp = red + ((ib - 1) & 1) * 128;
+            atomicAdd(cs_row + pend_cb * 32 + tid, (rp[tid] + rp[32 + tid]) + (rp[64 + tid] + rp[96 + tid]));
+        }
+    }
+}
+
 int num_cus_thin() {
     static int n = 0;
     if (n == 0) {
@@ -373,6 +575,28 @@ int launch_thin(const erd_conv_desc* d, hipStream_t st) {
     return erd::check_launch("conv_thin_x3");
 }
 
+template <int KS, bool RES, bool MSK>
+int launch_thin_bf16(const erd_conv_desc* d, hipStream_t st) {
+    constexpr int K = KS * 16;
+    int mtiles = 0;
+    for (int s = 0; s < d->nseg; ++s) mtiles += (int)(((int64_t)d->seg[s].N * d->seg[s].GH * d->seg[s].GW + 127) / 128);
+    const int nb = d->Cout / 32;
+    if (mtiles == 0) return 0;
+    const size_t lds = (size_t)2 * (32 * (K > 256 ? K / 2 : K) * 2) + 4 * 32 * SLD * 4 + 128 * sizeof(TRow) + 2 * 4 * 32 * 4;
+    static const int xcd = getenv("ERD_XCD") ? atoi(getenv("ERD_XCD")) : 1;
+    const long long T = (long long)mtiles * nb;
+    static const int wgs_env = getenv("ERD_THIN_BF16_WGS") ? atoi(getenv("ERD_THIN_BF16_WGS")) : 0;      // A/B aid
+    const int per_cu = wgs_env > 0 ? wgs_env : (KS <= 8 ? 4 : (KS > 16 || (RES && MSK) ? 2 : 3));      // (K = 256 with residual AND mask rows: 168 registers would spill)
+    const int G = (int)std::min<long long>(T, (long long)per_cu * erd::usable_cus(num_cus_thin()));
+    static bool attr_done = false;      // (K = 256: 52 KB of dynamic LDS)
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_bf16_kernel<KS, RES, MSK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_thin_bf16_kernel<KS, RES, MSK>), dim3(G), dim3(256), lds, st, *d, mtiles, nb, xcd ? 1 : 0);
+    return erd::check_launch("conv_thin_bf16");
+}
+
 }  // namespace
 
 namespace erd {
@@ -402,6 +626,35 @@ bool conv_thin_x3_ok(const erd_conv_desc* d) {
     return true;
 }
 
+// the bf16 mode's thin launches: one tap, Cin in {64, 128, 256, 512}, Cout % 32 == 0, maps stored bf16 on both sides
+bool conv_thin_bf16_ok(const erd_conv_desc* d) {
+    const int on = conv_thin_enable(-1);
+    if (!on || !d->w_bf16 || d->w_x3 || !d->in_bf16 || !d->out_bf16 || d->ntaps != 1) return false;
+    static const int k256 = getenv("ERD_THIN_BF16_K256") ? atoi(getenv("ERD_THIN_BF16_K256")) : 1;      // A/B aids
+    static const int k512 = getenv("ERD_THIN_BF16_K512") ? atoi(getenv("ERD_THIN_BF16_K512")) : 1;
+    if (!(d->Cin == 64 || d->Cin == 128 || (d->Cin == 256 && k256) || (d->Cin == 512 && k512)) || d->Cout % 32 != 0 || d->wrow % 8 != 0 || d->wk[0] % 8 != 0) return false;
+    for (int s = 0; s < d->nseg; ++s) {
+        const erd_conv_seg& g = d->seg[s];
+        if (g.ntaps > 0) return false;
+        if ((g.res != nullptr) != (d->seg[0].res != nullptr) || (g.mask != nullptr) != (d->seg[0].mask != nullptr)) return false;
+        if (g.res && g.res_nstride != g.out_nstride) return false;
+        if ((long long)g.N * g.out_nstride * 2 >= 0x7fffffffLL || (long long)g.N * g.in_nstride * 2 >= 0x7fffffffLL) return false;
+    }
+    return true;
+}
+
+int conv_thin_bf16(const erd_conv_desc* d, hipStream_t st) {
+    const bool r = d->seg[0].res != nullptr, m = d->seg[0].mask != nullptr;
+    if (d->Cin == 64) return r ? (m ? launch_thin_bf16<4, true, true>(d, st) : launch_thin_bf16<4, true, false>(d, st))
+                               : (m ? launch_thin_bf16<4, false, true>(d, st) : launch_thin_bf16<4, false, false>(d, st));
+    if (d->Cin == 512) return r ? (m ? launch_thin_bf16<32, true, true>(d, st) : launch_thin_bf16<32, true, false>(d, st))
+                                : (m ? launch_thin_bf16<32, false, true>(d, st) : launch_thin_bf16<32, false, false>(d, st));
+    if (d->Cin == 256) return r ? (m ? launch_thin_bf16<16, true, true>(d, st) : launch_thin_bf16<16, true, false>(d, st))
+                                : (m ? launch_thin_bf16<16, false, true>(d, st) : launch_thin_bf16<16, false, false>(d, st));
+    return r ? (m ? launch_thin_bf16<8, true, true>(d, st) : launch_thin_bf16<8, true, false>(d, st))
+             : (m ? launch_thin_bf16<8, false, true>(d, st) : launch_thin_bf16<8, false, false>(d, st));
+}
+
 int conv_thin_x3(const erd_conv_desc* d, hipStream_t st) {
     const bool r = d->seg[0].res != nullptr, m = d->seg[0].mask != nullptr;
     if (d->Cin == 64) return r ? (m ? launch_thin<4, 1, true, true>(d, st) : launch_thin<4, 1, true, false>(d, st))
@@ -413,7 +666,7 @@ int conv_thin_x3(const erd_conv_desc* d, hipStream_t st) {
 }  // namespace erd
 
 extern "C" int erd_conv_thin_enable(int on) { return erd::conv_thin_enable(on); }
-extern "C" int erd_conv_thin_ok(const erd_conv_desc* d) { return d && erd::conv_thin_x3_ok(d) ? 1 : 0; }
+extern "C" int erd_conv_thin_ok(const erd_conv_desc* d) { return d && (erd::conv_thin_x3_ok(d) || erd::conv_thin_bf16_ok(d)) ? 1 : 0; }
 #ifdef ERD_THIN_TRACE
 extern "C" int erd_thin_trace(unsigned long long* out) {       // trace builds only
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_thin_trace), sizeof(g_thin_trace));

@@ -18,6 +18,8 @@ int usable_cus(int physical);
 // conv_thin.hip: the activation-stationary three-limb kernel for 1x1 convolutions with Cin <= 128 (erd_conv_igemm dispatches to it)
 bool conv_thin_x3_ok(const erd_conv_desc* d);
 int conv_thin_x3(const erd_conv_desc* d, hipStream_t st);
+bool conv_thin_bf16_ok(const erd_conv_desc* d);      // ... and its bf16-mode twin (bf16 multiplicands, maps stored bf16)
+int conv_thin_bf16(const erd_conv_desc* d, hipStream_t st);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -24,7 +24,7 @@ from oracle import erd_oracle as O
 
 # The driver runs `pytest -m gpu` under a 1 200 s limit (<= 600 s asked): the default run takes the PINNED half of
 # each sample below; ERD_TEST_FULL=1 runs the full ones (12 fp64 seeds, 32 ERS images) -- once per round by the builder
-# (profiles/r05_gpu_suite_full.txt); the 144-seed statistics live in profiles/r05_parity_seeds.json either way.
+# (profiles/r05_gpu_suite_full.txt); the 144-seed statistics live in profiles/r06_parity_seeds.json either way.
 FULL = os.environ.get("ERD_TEST_FULL", "0") == "1"
 
 
@@ -163,7 +163,7 @@ def test_full_size_gradients_anchored_to_fp64(nets):
     flip moves every gradient tensor upstream by ~1e-3 and a small-norm one (a BN bias gradient: a sum over a map with heavy
     cancellation) by up to 1e-2.  Which implementation owns a flip on a given seed is chance, and the distribution is
     heavy-tailed -- twelve seeds cannot tell chance from a 20 % shift.  The statistics that CAN are in
-    profiles/r05_parity_seeds.json (tools/parity_seeds.py: 144 seeds, 7-150, same evaluation, round-5 library;
+    profiles/r06_parity_seeds.json (tools/parity_seeds.py: 144 seeds, 7-150, same evaluation, round-6 library -- round 5's file reads the same to three digits;
     tests/test_parity_seeds_profile.py asserts what this docstring quotes from it).  Whole-gradient distance to fp64 over the 144 seeds:
                                    mean +- s.e.m.        median     seeds > 1e-3   worst seed
         cpu fp32 (the reference)   9.2e-4 +- 1.4e-4      5.7e-4     27             1.8e-2

@@ -150,3 +150,94 @@ def test_segments_with_and_without_a_residual_in_one_launch(K, Cin):
     K.conv_forward(xs[1:], wg, one[1:], 1, 1, 0, scale=sc, shift=sh, relu=True)
     for a, b in zip(outs, one):
         assert not bool(torch.isnan(a).any()) and torch.equal(a, b)
+
+
+# ---- the bf16 mode's twin (conv_thin_bf16_kernel: bf16 multiplicands, maps stored bf16; BASELINE configs[2]) ---------------------------
+@pytest.fixture()
+def Kb():
+    from erd_amd import kernels as K, _lib
+    K.set_compute("bf16")
+    lib = _lib.load()
+    prev = lib.erd_conv_thin_enable(-1)
+    yield K
+    lib.erd_conv_thin_enable(prev)
+    K.set_compute(K.DEFAULT_COMPUTE)
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def nhwc_b(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda().to(torch.bfloat16)
+
+
+def _one_bf16_rounding(got, ref, extra=2e-5):
+    tol = 2.0 ** -8 * ref.abs() + extra * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), (int(bad.sum()), float(((got - ref).abs() - tol).max()))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,s", [(2, 128, 512, 25, 42, 1), (1, 64, 256, 30, 44, 1), (2, 64, 64, 17, 9, 1), (2, 128, 256, 26, 40, 2),
+                                              (4, 128, 512, 100, 168, 1), (2, 256, 1024, 25, 42, 1), (2, 256, 128, 31, 47, 1),
+                                              (2, 256, 512, 26, 40, 2), (4, 256, 1024, 50, 84, 1), (2, 512, 128, 31, 47, 1), (4, 512, 2048, 25, 42, 1),
+                                              (2, 512, 1024, 26, 40, 2)])
+def test_bf16_thin_forward_forms_are_bit_identical_to_the_stream_k_kernel(Kb, N, Cin, Cout, H, W, s):
+    """round 6: the bf16 mode's thin 1x1 launches on bf16-stored maps run on the activation-stationary kernel too -- the same MFMA
+    sequence per accumulator as the stream-K kernel's bf16 instantiation: bit-identical in every form, and one bf16 rounding away from
+    an fp64 evaluation on the same bf16-valued inputs"""
+    K = Kb
+    x = _rb(G.randn(1, N, Cin, H, W))
+    w = G.randn(2, Cout, Cin, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    scale, shift = 0.5 + G.rand(3, Cout), G.randn(4, Cout, scale=0.1)
+    ref = F.conv2d(x.double(), _rb(w).double(), None, s, 0)
+    OH, OW = ref.shape[2:]
+    res = _rb(G.randn(5, N, Cout, OH, OW))
+    ref2 = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xg, rg = nhwc_b(x), nhwc_b(res)
+
+    def run():
+        out = torch.empty((N, OH, OW, Cout), device="cuda", dtype=torch.bfloat16)
+        K.conv_forward([xg], wg, [out], 1, s, 0)
+        out2 = torch.empty_like(out)
+        K.conv_forward([xg], wg, [out2], 1, s, 0, scale=scale.cuda(), shift=shift.cuda(), res=[rg], relu=True)
+        out3 = rg.clone()
+        K.conv_forward([xg], wg, [out3], 1, s, 0, res=[out3])
+        return out, out2, out3
+
+    (a, a2, a3), (b, b2, b3) = both(K, run)
+    assert torch.equal(a, b) and torch.equal(a2, b2) and torch.equal(a3, b3)
+    _one_bf16_rounding(a.float().permute(0, 3, 1, 2).cpu().double(), ref)
+    _one_bf16_rounding(a2.float().permute(0, 3, 1, 2).cpu().double(), ref2)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 512, 128, 25, 42), (1, 256, 64, 30, 44), (4, 512, 128, 100, 168), (2, 1024, 256, 25, 42),
+                                            (4, 1024, 256, 50, 84), (2, 128, 512, 31, 47), (4, 2048, 512, 25, 42)])
+def test_bf16_thin_input_gradient_forms(Kb, N, Cin, Cout, H, W):
+    K = Kb
+    dz = _rb(G.randn(1, N, Cout, H, W))
+    w = G.randn(2, Cout, Cin, 1, 1, scale=(2.0 / Cin) ** 0.5)
+    short = _rb(G.randn(4, N, Cin, H, W))
+    mask = _rb(G.randn(5, N, Cin, H, W))
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    dzg, sg, mg = nhwc_b(dz), nhwc_b(short), nhwc_b(mask)
+    ref = F.conv_transpose2d(dz.double(), _rb(w).double())
+    ref_m = (ref + short.double()) * (mask.double() > 0)
+
+    def run():
+        wt = K.weight_transpose(wg)
+        dx = torch.empty((N, H, W, Cin), device="cuda", dtype=torch.bfloat16)
+        K.conv_dgrad([dzg], wt, [dx], 1, 1, 0)
+        dx2 = torch.empty_like(dx)
+        cs = torch.zeros((8, Cin), device="cuda")
+        K.conv_dgrad([dzg], wt, [dx2], 1, 1, 0, res=[sg], relu_mask=[mg], colsum=cs)
+        dx3 = sg.clone()
+        K.conv_dgrad([dzg], wt, [dx3], 1, 1, 0, accumulate=True)
+        return dx, dx2, cs.sum(0), dx3
+
+    (a, a2, ca, a3), (b, b2, cb, b3) = both(K, run)
+    assert torch.equal(a, b) and torch.equal(a2, b2) and torch.equal(a3, b3)
+    assert torch.allclose(ca, cb, rtol=1e-5, atol=1e-3)
+    _one_bf16_rounding(a.float().permute(0, 3, 1, 2).cpu().double(), ref)
+    _one_bf16_rounding(a2.float().permute(0, 3, 1, 2).cpu().double(), ref_m)

@@ -1,5 +1,5 @@
 """CPU: the statements README / DESIGN / tests/test_gpu_parity_full.py make about the fp32 forms' distance to an fp64 evaluation
-are read off profiles/r05_parity_seeds.json (tools/parity_seeds.py on the GPU box with the round-5 library, merged by
+are read off profiles/r06_parity_seeds.json (tools/parity_seeds.py on the GPU box with the round-6 library -- the round-5 file profiles/r05_parity_seeds.json gave the same statistics to three digits --, merged by
 tools/parity_merge.py) -- this test recomputes them from the committed per-seed rows, so a quoted number cannot drift from the data
 (">= 48 full-size seeds ... and assert what the 48 support").  No GPU, no oracle: arithmetic on a JSON file.
 
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_parity_seed_statistics_support_the_documented_claims():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_parity_seeds.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_parity_seeds.json")))
     rows = {k: np.array(v) for k, v in d["rows"].items()}
     n = len(d["seeds"])
     assert n >= 48 and len(set(d["seeds"])) == n and all(len(v) == n for v in rows.values())
