@@ -565,6 +565,8 @@ def main():
             # one symbol) and its roofline on the flops it EXECUTES
             wino_on_bf16 = K.wino_x3()       # "f32x3": the Winograd launches run as wino_x3_kernel (six bf16 limb products per transform-domain product)
             symbols = dict(SYMBOLS)
+            if args.compute == "bf16":      # the bf16 mode's thin 1x1 launches run on their own kernel (conv_thin.hip, round 6)
+                symbols["conv_thin_bf16_kernel"] = symbols.pop("conv_thin_x3_kernel")
             if wino_on_bf16:     # two symbols: items of 128 output channels (wino_x3p_kernel; the launch picks, kernels.wino_conv3x3 names it) and of 64
                 symbols["wino_x3_kernel"] = symbols.pop("wino_conv_kernel")
                 symbols["wino_x3p_kernel"] = ("conv_wino_fwd_p", "conv_wino_dgrad_p")
