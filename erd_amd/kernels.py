@@ -936,8 +936,12 @@ def _one_round(target: int) -> int:
 def _pick_nsplit(npix: int, Cout: int, Cin: int, ntaps: int) -> int:
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * ntaps
     kt = (npix + 31) // 32
-    target = _one_round(1024 if _os.environ.get("ERD_WGRAD_VARIANT", "1") == "0" else int(_os.environ.get("ERD_WGRAD_TARGET", "1024")))
-    want = max(1, target // tiles)          # ONE whole dispatch round of 4 workgroups per CU (measured: two rounds pay more partial-slab traffic than they gain; never a ragged extra round)
+    # ONE whole dispatch round: 4 workgroups per CU for the fp32 kernel (1024), TWO for the bf16 mode's kernel (conv_wgrad_bf16_kernel,
+    # launch bounds 2: 512 -- until round 6 it got 1024 = two rounds and twice the partial slabs, whose fp32 traffic exceeds the bf16
+    # operands': 229 -> 240 img/s in the bf16 mode, sweep 384 / 512 / 640 / 768 / 1024 in profiles/r06_bf16_wgrad_split.txt)
+    dflt = "512" if COMPUTE == "bf16" else "1024"
+    target = _one_round(int(dflt) if _os.environ.get("ERD_WGRAD_VARIANT", "1") == "0" else int(_os.environ.get("ERD_WGRAD_TARGET", dflt)))
+    want = max(1, target // tiles)          # (measured: two rounds pay more partial-slab traffic than they gain; never a ragged extra round)
     return int(max(1, min(want, kt // 8 if kt >= 8 else 1, 512)))
 
 
