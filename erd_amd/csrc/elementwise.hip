@@ -291,13 +291,32 @@ __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const T* __restric
     }
 }
 
-__global__ void bn_dgamma_kernel(const float* __restrict__ rowdot, const float* __restrict__ dbeta, int copies,
-                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                 float* __restrict__ dgamma, float* __restrict__ dbeta_out, int accumulate, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// dbeta: [copies][C] replicated column sums (the input-gradient epilogues add into row blockIdx & (copies - 1)).  32 channels per
+// workgroup, eight row lanes each: lane g folds rows g, g + 8, ... with four loads in flight (a single thread per channel walking 64
+// rows is a chain of dependent L2 round trips: 20 us per launch on the trailing stream), then thread (0, c) adds the eight shares in
+// row-lane order -- for copies <= 8 the sum order of the one-thread loop this replaces.
+__global__ void __launch_bounds__(256) bn_dgamma_kernel(const float* __restrict__ rowdot, const float* __restrict__ dbeta, int copies,
+                                                        const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta_out, int accumulate, int C) {
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    float s = 0.f;
     if (i < C) {
-        float db = dbeta[i];
-        for (int r = 1; r < copies; ++r) db += dbeta[(int64_t)r * C + i];
+        int r = g;
+        for (; r + 24 < copies; r += 32) {
+            const float a0 = dbeta[(int64_t)r * C + i], a1 = dbeta[(int64_t)(r + 8) * C + i];
+            const float a2 = dbeta[(int64_t)(r + 16) * C + i], a3 = dbeta[(int64_t)(r + 24) * C + i];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; r < copies; r += 8) s += dbeta[(int64_t)r * C + i];
+    }
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < C) {
+        float db = part[0][c];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) db += part[j][c];
         if (dbeta_out) dbeta_out[i] = db;
         const float v = (1.0f / sqrtf(var[i] + eps)) * (rowdot[i] - mean[i] * db);
         dgamma[i] = accumulate ? dgamma[i] + v : v;
@@ -878,7 +897,7 @@ extern "C" int erd_relu_bwd_colsum(const void* y, const void* dy, void* dz, int6
 extern "C" int erd_bn_dgamma(const float* rowdot, const float* dbeta, int copies, const float* mean, const float* var,
                              float eps, float* dgamma, float* dbeta_out, int accumulate, int C, erd_stream_t stream) {
     ERD_REQUIRE(rowdot && dbeta && mean && var && dgamma && copies >= 1, "bn_dgamma: bad args");
-    hipLaunchKernelGGL(bn_dgamma_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowdot, dbeta, copies,
+    hipLaunchKernelGGL(bn_dgamma_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, rowdot, dbeta, copies,
                        mean, var, eps, dgamma, dbeta_out, accumulate, C);
     return erd::check_launch("bn_dgamma");
 }

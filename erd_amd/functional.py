@@ -462,9 +462,9 @@ def _bottleneck_backward(x, o1, o2, s1, s2, s3, sd, P, need_p, need_x, stride, e
 
     wgrad(2, o2, dz3, 1, 1, 0, s3, db3)
     dz2 = torch.empty_like(o2)
-    # the epilogues of the two input-gradient convolutions add their column sums into 8 replicated rows (hundreds of
-    # tiles adding to ONE row would serialise on the memory-side atomic unit); wgrad()'s bn_dgamma folds them
-    rep_slot = lambda n: K.zeros_f32(K.COLSUM_COPIES * n, dev).view(K.COLSUM_COPIES, n)
+    # the epilogues of the two input-gradient convolutions add their column sums into 8-128 replicated rows (hundreds of
+    # tiles adding to ONE row would serialise on the memory-side atomic unit: K.colsum_copies); wgrad()'s bn_dgamma folds them
+    rep_slot = lambda n: K.zeros_f32(K.colsum_copies(n) * n, dev).view(K.colsum_copies(n), n)
     db2 = rep_slot(o2.shape[3])
     K.conv_dgrad([dz3], K.weight_transpose(ohwi(P[2][0]), s3), [dz2], 1, 1, 0, relu_mask=[o2], colsum=db2)
     wgrad(1, o1, dz2, 3, stride, 1, s2, db2)

@@ -123,7 +123,7 @@ def workspace(name: str, nbytes: int, device) -> Tensor:
 _ARENA = {"buf": None, "off": 0, "key": None, "ok": ()}
 
 
-def zero_arena_begin(device, nbytes: int = 8 << 20, forked_streams=()) -> None:
+def zero_arena_begin(device, nbytes: int = int(_os.environ.get("ERD_ZERO_ARENA_MB", "16")) << 20, forked_streams=()) -> None:
     """called once per step (on the stream the step runs on) by the trainer.  `forked_streams`: raw handles of streams
     that the step forks to AFTER this call and joins BEFORE zero_arena_end() (the trailing weight-gradient stream, the
     second tower stream): slices may be handed out there too -- they are ordered behind this memset by the fork and the
@@ -1101,7 +1101,20 @@ def relu_bwd_colsum(y: Optional[Tensor], dy: Tensor, use_relu: bool, want_colsum
     return dz, colsum
 
 
-COLSUM_COPIES = 8      # rows of a replicated column-sum accumulator (power of two): see erd_conv_desc::colsum_copies
+# Rows of a replicated column-sum accumulator (a power of two; erd_conv_desc::colsum_copies: workgroup b adds into row b mod copies).
+# Eight rows were enough for the 1x1 input gradients of wide layers, not for the narrow ones: 525 persistent items x 4 waves adding to
+# 8 x 128 addresses made the layer-2 Winograd input gradient 2x its forward twin (173 -> 103 us with 64 rows, 119 -> 99 for layer 3;
+# tools/dbg/wino_dgrad_epi.py), and atomics share the in-order memory counter with the next item's loads.  So: as many rows as keep the
+# accumulator at COLSUM_WIDTH floats (C = 64 / 128: 128 rows ... 2048: 8); bn_dgamma folds them, eight row lanes per channel.
+COLSUM_COPIES = 8
+COLSUM_WIDTH = int(_os.environ.get("ERD_COLSUM_WIDTH", "16384"))      # (0: eight rows everywhere, the rounds 2-5 layout)
+
+
+def colsum_copies(channels: int) -> int:
+    c = COLSUM_COPIES
+    while COLSUM_WIDTH > 0 and c * 2 * channels <= COLSUM_WIDTH and c < 128:
+        c *= 2
+    return c
 
 
 def bn_dgamma(rowdot: Tensor, dbeta: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-5,

@@ -152,6 +152,24 @@ def test_bn_fold_and_backward_pieces(K):
     assert relerr(dg.cpu(), (rd - m * db) / torch.sqrt(v + 1e-5)) < 1e-5
 
 
+@pytest.mark.parametrize("copies,Cc", [(1, 64), (8, 2048), (16, 72), (64, 128), (128, 64), (32, 1000)])
+def test_bn_dgamma_folds_replicated_column_sums(K, copies, Cc):
+    """the [copies, C] accumulators of the input-gradient epilogues (functional.py rep_slot): d gamma AND the folded d beta, for every
+    replication the step uses, a ragged channel count included (C % 32 != 0: the fold kernel's last workgroup)"""
+    m, v = G.randn(61, Cc), 0.5 + G.rand(62, Cc)
+    rd, rep = G.randn(63, Cc), G.randn(64, copies, Cc)
+    fold = torch.full((Cc,), float("nan"), device="cuda")
+    dg = K.bn_dgamma(rd.cuda(), rep.cuda(), m.cuda(), v.cuda(), dbeta_out=fold)
+    db = rep.double().sum(0)
+    assert relerr(fold.cpu().double(), db) < 1e-6
+    assert relerr(dg.cpu().double(), (rd.double() - m.double() * db) / torch.sqrt(v.double() + 1e-5)) < 1e-5
+    if copies <= 8:          # the sum order of the serial loop the kernel replaced: rows in order
+        seq = rep[0].clone()
+        for r in range(1, copies):
+            seq += rep[r]
+        assert torch.equal(fold.cpu(), seq)
+
+
 def test_groupnorm_relu_fwd_bwd(K):
     sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
     N, Cc = 2, 256
