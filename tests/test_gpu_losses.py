@@ -155,17 +155,23 @@ def test_head_losses_fwd_bwd_vs_reference_fixture(K, golden):
         off += h * w
 
 
-@pytest.mark.parametrize("i,seed", [(0, 500), (1, 510)])
-def test_nms_vs_restatement_unpinned(K, i, seed):
+@pytest.mark.parametrize("i,seed,size,want", [(0, 500, (50, 60), None), (1, 510, (50, 60), None), (2, 520, (100, 120), 2560),
+                                              (3, 530, (100, 120), 2561), (4, 540, (100, 120), None)])
+def test_nms_vs_restatement_unpinned(K, i, seed, size, want):
     """kernel vs oracle.nms_class_offset (mmcv restated; UNPINNED vs mmcv==2.0.0) through the distillation
-    entry point: craft teacher logits whose decoded boxes/scores/ids are the seeded ones."""
-    A = 3000
+    entry point: craft teacher logits whose decoded boxes/scores/ids are the seeded ones.  Candidate counts on both sides of the
+    kernel's LDS capacity (2 560 boxes: the greedy pass runs out of LDS up to there, out of the global workspace above) and at it."""
+    A = size[0] * size[1]
     t_cls = G.randn(seed + 5, 1, A, 40, scale=1.0, shift=-3.0)
     t_bbox = G.randn(seed + 6, 1, A, 68, scale=2.0)
-    sizes = [(50, 60)]
+    sizes = [size]
     anchors = K.grid_anchors(sizes, [8], "cuda")
-    idx = torch.sort(G.randint(seed + 7, 0, A, 700).unique()).values
+    idx = torch.sort(G.randint(seed + 7, 0, A, 700 if A == 3000 else 6000).unique()).values
+    if want is not None:
+        assert idx.numel() >= want
+        idx = idx[:want]
     kb = idx.numel()
+    assert (kb <= 2560) == (A == 3000 or want == 2560)
     idx_pad = torch.zeros((1, A), dtype=torch.long); idx_pad[0, :kb] = idx
     counts = torch.tensor([[0, kb]], dtype=torch.int32)
     keep, kcnt = K.distill_nms(t_cls.cuda(), t_bbox.cuda(), anchors, idx_pad.cuda(), counts.cuda(), 0.005)
