@@ -76,3 +76,25 @@ def test_lds_dma_kernels_own_m0_and_keep_their_k_loop_free_of_full_waits(tmp_pat
         assert asm_waits >= 2, (name, asm_waits)
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0, name
     assert seen == 12, seen        # {128 x 128, 128 x 128 with per-segment taps, 128 x 64} x (residual, mask) presence
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_distillation_nms_kernel_fits_static_lds_and_uses_no_scratch(tmp_path):
+    """Round 6: `distill_nms_kernel` keeps up to NMS_LDS_K sorted boxes, their anchors and suppression flags in STATIC LDS (the 64 KB a
+    kernel gets without the dynamic-LDS attribute): the kernel descriptor must say so, with no scratch and one workgroup of 1024 threads."""
+    import re
+    out = tmp_path / "losses.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-ffp-contract=off", "-S",
+                        "--cuda-device-only", "-o", str(out), "losses.hip"], cwd=os.path.join(ROOT, "erd_amd", "csrc"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = open(out).read()
+    m = re.search(r"\.amdhsa_kernel \S*distill_nms_kernel\S*\n(.*?)\.end_amdhsa_kernel", s, re.S)
+    assert m, "distill_nms_kernel not found"
+    desc = m.group(1)
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", desc).group(1))
+    scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1))
+    src = open(os.path.join(ROOT, "erd_amd", "csrc", "losses.hip")).read()
+    cap = int(re.search(r"constexpr int NMS_LDS_K = (\d+);", src).group(1))
+    assert cap * (16 + 4 + 4 + 1) <= lds <= 65536, (cap, lds)
+    assert scratch == 0

@@ -230,3 +230,20 @@ def test_integration_md_names_every_entry_point():
     names = set(re.findall(r"\b(erd_[a-z0-9_]+)\s*\(", open(os.path.join(root, "include", "erd_hip.h")).read()))
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     assert not [n for n in sorted(names) if n not in doc]
+
+
+def test_column_sum_replication_policy_fits_the_zero_arena():
+    """kernels.colsum_copies: rows of the replicated column-sum accumulators of the input-gradient epilogues (a power of two between 8
+    and 128, the accumulator at most COLSUM_WIDTH floats unless eight rows already exceed it), and the step's zero arena holds them for the
+    deepest backbone of the configs (ResNet-101: 33 bottlenecks x three accumulators) with room for the row dots / d-gamma scratch."""
+    import inspect
+    from erd_amd import kernels as K
+    assert K.COLSUM_WIDTH == 16384 and K.COLSUM_COPIES == 8
+    for C, want in ((64, 128), (128, 128), (256, 64), (512, 32), (1024, 16), (2048, 8), (4096, 8), (72, 128), (1000, 16)):
+        n = K.colsum_copies(C)
+        assert n == want and n & (n - 1) == 0 and 8 <= n <= 128, (C, n)
+        assert n * C <= max(K.COLSUM_WIDTH, 8 * C)
+    planes = [64] * 3 + [128] * 4 + [256] * 23 + [512] * 3          # ResNet-101
+    need = sum(4 * ((K.colsum_copies(p) * p) * 2 + K.colsum_copies(4 * p) * 4 * p) for p in planes)
+    arena = inspect.signature(K.zero_arena_begin).parameters["nbytes"].default
+    assert arena == 16 << 20 and need < arena // 2, (need, arena)
